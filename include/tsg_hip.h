@@ -1,0 +1,233 @@
+/*
+ * tsg_hip.h — C-ABI of libtsg_hip.so, the MI355X (gfx950) hot-path kernels
+ * behind TorchSeg's furnace.seg_opr / apex.parallel operator surface.
+ *
+ * Conventions (every entry point):
+ *   - plain `extern "C"`, raw device pointers + sizes, no torch / C++ types;
+ *   - returns 0 on success, <0 for an invalid argument (TSG_E_*), >0 = hipError_t;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never
+ *     synchronise; the caller owns every buffer including workspaces, whose size
+ *     comes from the matching *_ws_bytes() query;
+ *   - the library keeps no mutable global state; it is re-entrant across streams.
+ *
+ * Reference interfaces replaced are cited per group (paths relative to the
+ * TorchSeg checkout).
+ */
+#ifndef TSG_HIP_H
+#define TSG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSG_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* element types of activations / logits */
+enum { TSG_F32 = 0, TSG_BF16 = 1 };
+/* memory layout of a 4-D activation */
+enum { TSG_NCHW = 0, TSG_NHWC = 1 };
+/* label element types */
+enum { TSG_I64 = 0, TSG_U8 = 1 };
+
+/* error codes (negative) */
+#define TSG_E_DTYPE   (-1)
+#define TSG_E_LAYOUT  (-2)
+#define TSG_E_SHAPE   (-3)
+#define TSG_E_ALIGN   (-4)
+#define TSG_E_NULL    (-5)
+#define TSG_E_WS      (-6)
+
+int tsg_version(void);
+
+/* ------------------------------------------------------------------------
+ * SyncBatchNorm — replaces apex.parallel.SyncBatchNorm (imported at
+ * model/bisenet/cityscapes.bisenet.R18/train.py:24-25) whose in-tree statement
+ * is furnace/legacy/sync_bn: sumsquare_forward / batchnorm_forward /
+ * batchnorm_backward / sumsquare_backward (src/gpu/operator.h,
+ * src/gpu/syncbn_kernel.cu:73-174) and _compute_mean_std (syncbn.py:86-98).
+ *
+ * x is [N, C, HW] (TSG_NCHW) or [N*HW, C] (TSG_NHWC), contiguous.
+ * ---------------------------------------------------------------------- */
+
+/* number of per-channel partial rows the stats / bwd-reduce kernels write */
+int    tsg_bn_num_partials(int layout, int64_t N, int64_t C, int64_t HW);
+/* bytes of the fp32 partial buffer: num_partials * 2 * C * 4 */
+size_t tsg_bn_partial_ws_bytes(int layout, int64_t N, int64_t C, int64_t HW);
+
+/* partial[s][0][c] = sum x, partial[s][1][c] = sum x^2 over slice s (fp32);
+ * *rows (host int) receives the number of slices S actually written
+ * (<= tsg_bn_num_partials, depends on pointer alignment).
+ * Replaces Sum_Square_Forward_CUDA (syncbn_kernel.cu:142-157, 245-265). */
+int tsg_bn_stats(const void* x, int dtype, int layout,
+                 int64_t N, int64_t C, int64_t HW,
+                 float* partial, int* rows, void* stream);
+
+/* Collapse partial[S][2][C] to sums[2*C] (fp32, reduced in fp64, fixed order).
+ * Used before the cross-GPU all-reduce (syncbn.py:75 ReduceAddCoalesced). */
+int tsg_bn_collapse(const float* partial, int S, int64_t C, float* sums,
+                    void* stream);
+
+/* From (partial or all-reduced) sums and the global element count per channel:
+ *   mean = sum/n ; sumvar = sumsq - sum*mean ; invstd = (sumvar/n + eps)^-1/2
+ *   running_mean = (1-m)*running_mean + m*mean
+ *   running_var  = (1-m)*running_var  + m*sumvar/(n-1)      (syncbn.py:86-98)
+ * running_* and num_batches_tracked may be NULL.  count is the GLOBAL n.
+ * When count_dev != NULL the count is read from the device instead:
+ * n = count_dev[0]*4096 + count_dev[1] (two fp32 words that stay exact under an
+ * all-reduce SUM; lets ranks with unequal batches agree without a host sync). */
+int tsg_bn_finalize(const float* partial, int S, int64_t C, double count,
+                    const float* count_dev, float eps, float momentum,
+                    float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked,
+                    float* mean, float* invstd, void* stream);
+
+/* y = relu?( gamma*(x-mean)*invstd + beta (+ residual) ).
+ * Replaces BatchNorm_Forward_CUDA (syncbn_kernel.cu:73-89) fused with the
+ * nn.ReLU / residual add that follow it (seg_oprs.py:39-46, resnet.py:33-53).
+ * gamma/beta may be NULL (=1/0); residual may be NULL; y may alias x. */
+int tsg_bn_apply_fwd(const void* x, const void* residual, void* y,
+                     int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                     const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int relu,
+                     void* stream);
+
+/* Backward reduction: with dy' = dy * [pre-activation > 0] when relu, else dy:
+ *   partial[s][0][c] = sum dy' ; partial[s][1][c] = sum dy' * (x-mean)*invstd
+ * (GradOp, syncbn_kernel.cu:12-23,108-113).  When relu != 0 the mask is taken
+ * from y > 0 if y != NULL (needed when a residual was fused), otherwise it is
+ * recomputed from x with the forward's exact affine map (saves one read). */
+int tsg_bn_bwd_reduce(const void* dy, const void* x, const void* y,
+                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                      const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int relu,
+                      float* partial, int* rows, void* stream);
+
+/* From the (all-reduced) partials: dgamma = sum dy' xhat, dbeta = sum dy'
+ * (LOCAL sums are what the caller passes for dgamma/dbeta when it wants
+ * per-rank parameter grads; DDP averages them later) and the per-channel
+ * coefficients used by bwd_apply:  k[0][c] = sum dy'/n, k[1][c] = sum dy' xhat/n
+ * with n the GLOBAL count.  dgamma/dbeta may be NULL. */
+int tsg_bn_bwd_coeffs(const float* partial, int S, int64_t C, double count,
+                      const float* count_dev,
+                      float* dgamma, float* dbeta, float* k, void* stream);
+
+/* dx = gamma*invstd * (dy' - k0 - xhat*k1); optionally dres = dy' (gradient of
+ * the fused residual input).  Composition of syncbn_kernel.cu:118-135 and
+ * Sum_Square_Backward (160-174) as autograd chains them (functions.py:22-61). */
+int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y,
+                     void* dx, void* dres,
+                     int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                     const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, const float* k,
+                     int relu, void* stream);
+
+/* ------------------------------------------------------------------------
+ * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
+ * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.
+ * logits are [B, C, HW] (NCHW planar), labels [B*HW].
+ * ---------------------------------------------------------------------- */
+
+typedef struct tsg_ohem_plan {
+  int64_t P;          /* B*HW pixels                                   */
+  int     C;
+  int     grid;       /* blocks of the pixel passes                     */
+  int     levels;     /* radix-select refinement levels (1..3)          */
+  int     shift[3];   /* bit shift of each level                        */
+  int     bins[3];    /* bins of each level                             */
+  uint32_t thresh_bits;
+  size_t  ws_bytes;   /* workspace the caller must provide (zeroed by us) */
+} tsg_ohem_plan;
+
+/* Fill `plan` for a problem size / threshold. */
+int tsg_ohem_make_plan(int64_t B, int C, int64_t HW, float thresh,
+                       tsg_ohem_plan* plan);
+
+/* Forward.  Writes nll[P] (= lse - x_t, 0 for ignored pixels), lse[P],
+ * loss[1] (fp32 mean over kept pixels, NaN when none) and
+ * sel[4] = {thr (float bits), n_kept, num_valid, branch}.
+ * min_kept / thresh / ignore_label as in loss_opr.py:49-56.
+ * weight (class weights, loss_opr.py:57-63) may be NULL. */
+int tsg_ohem_fwd(const void* logits, int dtype, const void* labels, int ltype,
+                 int64_t B, int C, int64_t HW,
+                 int64_t ignore_label, float thresh, int64_t min_kept,
+                 const float* weight,
+                 float* nll, float* lse, float* loss, int32_t* sel,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* Backward: dlogits[b,c,p] = gscale * w_t * (softmax_c - [c==t]) / denom for
+ * kept pixels, 0 elsewhere; gscale is a device scalar (upstream grad). */
+int tsg_ohem_bwd(const void* logits, int dtype, const void* labels, int ltype,
+                 int64_t B, int C, int64_t HW, int64_t ignore_label,
+                 const float* weight,
+                 const float* nll, const float* lse, const int32_t* sel,
+                 const float* gscale, void* dlogits, void* ws, void* stream);
+
+/* Exact k-th order statistic of non-negative floats by radix select on their
+ * IEEE bit patterns — what torch.sort(mask_prob)[k-1] returns
+ * (loss_opr.py:86-88).  out[0] receives the value.  k is 1-based. */
+size_t tsg_kth_ws_bytes(int64_t n);
+int tsg_kth_value(const float* v, int64_t n, int64_t k, float* out,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Sigmoid focal loss — replaces SigmoidFocalLoss.forward
+ * (furnace/seg_opr/loss_opr.py:23-45), including its use of the sigmoid where
+ * logits were intended (line 32-39).  pred [B*HW], target [B*HW].
+ * ---------------------------------------------------------------------- */
+size_t tsg_focal_ws_bytes(int64_t P);
+int tsg_focal_fwd(const void* pred, int dtype, const void* target, int ltype,
+                  int64_t P, int64_t ignore_label, float gamma, float alpha,
+                  float* loss, void* ws, size_t ws_bytes, void* stream);
+int tsg_focal_bwd(const void* pred, int dtype, const void* target, int ltype,
+                  int64_t P, int64_t ignore_label, float gamma, float alpha,
+                  const float* gscale, void* dpred, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Bilinear upsample, align_corners=True — replaces the
+ * F.interpolate(..., mode='bilinear', align_corners=True) call sites
+ * (bisenet network.py:82-84,93-94,164-166; pspnet network.py:46-49,103-105)
+ * i.e. aten::upsample_bilinear2d / _backward.  x [NC, IH, IW] -> y [NC, OH, OW]
+ * planar; `add` (may be NULL) is added to the result ("upsample+fuse",
+ * bisenet network.py:91-95).
+ * ---------------------------------------------------------------------- */
+int tsg_upsample_bilinear_ac_fwd(const void* x, const void* add, void* y,
+                                 int dtype, int64_t NC, int IH, int IW,
+                                 int OH, int OW, void* stream);
+int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype,
+                                 int64_t NC, int IH, int IW, int OH, int OW,
+                                 void* stream);
+/* nearest (floor(dst*in/out)) variant used for label maps. */
+int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes,
+                             int64_t NC, int IH, int IW, int OH, int OW,
+                             void* stream);
+
+/* ------------------------------------------------------------------------
+ * PSANet collect / distribute attention — replaces
+ *   torch.bmm(X, torch.softmax(A, dim=1))
+ * (model/psanet/ade.psanet.R101_v1c/network.py:125-126,135-136).
+ * X [B, Cx, L], A [B, L, L] (softmax over dim 1 = the row index i), out [B, Cx, L].
+ * ---------------------------------------------------------------------- */
+size_t tsg_psa_ws_bytes(int64_t B, int64_t Cx, int64_t L);
+int tsg_psa_fwd(const void* X, const void* A, void* out, float* colstat,
+                int dtype, int64_t B, int64_t Cx, int64_t L,
+                void* ws, size_t ws_bytes, void* stream);
+int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
+                const float* colstat, void* dX, void* dA,
+                int dtype, int64_t B, int64_t Cx, int64_t L,
+                void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused SGD step over a flat parameter bucket (torch.optim.SGD semantics as
+ * configured at train.py:86-89: momentum, weight decay, no nesterov).
+ * ---------------------------------------------------------------------- */
+int tsg_sgd_step(float* param, const float* grad, float* momentum_buf,
+                 int64_t n, float lr, float momentum, float weight_decay,
+                 float grad_scale, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSG_HIP_H */

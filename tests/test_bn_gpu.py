@@ -1,0 +1,103 @@
+"""GPU parity: HIP SyncBN kernels (through the SyncBatchNorm module, i.e. the
+C-ABI) vs the numpy oracle.  fp32: 1e-4 (north_star tolerance); bf16: the
+oracle is fed the same bf16-rounded inputs and compared at bf16 resolution."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import syncbn_ref as R
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 64, 33, 47), (4, 128, 16, 16), (16, 128, 1, 1), (3, 24, 8, 8), (2, 19, 7, 5),
+          (2, 2048, 6, 6), (2, 4096, 4, 4), (2, 64, 96, 128), (1, 8, 300, 300)]
+
+
+def _run(cuda, shape, layout, dtype, relu, res, seed=0):
+    from torchseg_amd.syncbn import SyncBatchNorm
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.4
+    r = torch.randn(shape, generator=g) if res else None
+    dy = torch.randn(shape, generator=g)
+    gamma = torch.randn(C, generator=g) * 0.5 + 1.0
+    beta = torch.randn(C, generator=g) * 0.5
+    x, dy = x.to(dtype), dy.to(dtype)
+    if res:
+        r = r.to(dtype)
+    fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+    bn = SyncBatchNorm(C, eps=1e-5, momentum=0.1).to(cuda)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    xd = x.to(cuda).contiguous(memory_format=fmt).requires_grad_(True)
+    rd = r.to(cuda).contiguous(memory_format=fmt).requires_grad_(True) if res else None
+    y = bn(xd, residual=rd, relu=relu)
+    assert y.dtype == dtype and y.stride() == xd.stride()
+    y.backward(dy.to(cuda).contiguous(memory_format=fmt))
+    torch.cuda.synchronize()
+
+    xs = [x.float().numpy().astype(np.float64)]
+    rs = [r.float().numpy().astype(np.float64)] if res else None
+    ys, mean, inv_std, rm, rv = R.forward(xs, gamma.numpy(), beta.numpy(), 1e-5, 0.1,
+                                          np.zeros(C), np.ones(C), rs, relu)
+    y_ref = ys[0]
+    if dtype == torch.bfloat16:
+        # the device masks with its own (bf16-rounded) y; use the same mask source
+        ys = [y.detach().float().cpu().numpy().astype(np.float64)] if res else ys
+    dxs, dres, dg, db = R.backward(xs, [dy.float().numpy()], ys, gamma.numpy(), mean, inv_std, relu)
+    return dict(y=y.detach().float().cpu().numpy(), y_ref=y_ref,
+                dx=xd.grad.float().cpu().numpy(), dx_ref=dxs[0],
+                dres=rd.grad.float().cpu().numpy() if res else None, dres_ref=dres[0],
+                dg=bn.weight.grad.cpu().numpy(), dg_ref=dg[0], db=bn.bias.grad.cpu().numpy(), db_ref=db[0],
+                rm=bn.running_mean.cpu().numpy(), rm_ref=rm, rv=bn.running_var.cpu().numpy(), rv_ref=rv,
+                nbt=int(bn.num_batches_tracked.item()))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_bn_fp32(cuda, shape, layout, relu, res):
+    o = _run(cuda, shape, layout, torch.float32, relu, res)
+    n = shape[0] * shape[2] * shape[3]
+    np.testing.assert_allclose(o["y"], o["y_ref"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(o["dx"], o["dx_ref"], rtol=1e-4, atol=1e-4)
+    if res:
+        np.testing.assert_allclose(o["dres"], o["dres_ref"], rtol=0, atol=0)
+    np.testing.assert_allclose(o["dg"], o["dg_ref"], rtol=1e-4, atol=1e-4 * np.sqrt(n))
+    np.testing.assert_allclose(o["db"], o["db_ref"], rtol=1e-4, atol=1e-4 * np.sqrt(n))
+    np.testing.assert_allclose(o["rm"], o["rm_ref"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o["rv"], o["rv_ref"], rtol=1e-4, atol=1e-6)
+    assert o["nbt"] == 1
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True)])
+def test_bn_bf16(cuda, shape, layout, relu, res):
+    o = _run(cuda, shape, layout, torch.bfloat16, relu, res)
+    n = shape[0] * shape[2] * shape[3]
+    # outputs are rounded to bf16 (8 bits of mantissa): 2^-8 relative
+    np.testing.assert_allclose(o["y"], o["y_ref"], rtol=8e-3, atol=8e-3)
+    # a ReLU mask decided on a value that rounds to 0 in bf16 may differ: allow a handful
+    bad = np.abs(o["dx"] - o["dx_ref"]) > (8e-3 + 8e-3 * np.abs(o["dx_ref"]))
+    assert bad.mean() < 1e-3, bad.mean()
+    np.testing.assert_allclose(o["dg"], o["dg_ref"], rtol=2e-2, atol=2e-2 * np.sqrt(n))
+    np.testing.assert_allclose(o["db"], o["db_ref"], rtol=2e-2, atol=2e-2 * np.sqrt(n))
+    np.testing.assert_allclose(o["rm"], o["rm_ref"], rtol=1e-4, atol=1e-5)
+
+
+def test_bn_eval_and_errors(cuda):
+    from torchseg_amd.syncbn import SyncBatchNorm
+    bn = SyncBatchNorm(16).to(cuda)
+    x = torch.randn(4, 16, 9, 9, device=cuda)
+    bn.train()
+    for _ in range(3):
+        bn(x)
+    bn.eval()
+    ref = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.1, bn.eps)
+    torch.testing.assert_close(bn(x), ref, rtol=1e-5, atol=1e-5)
+    bn.train()
+    with pytest.raises(ValueError):
+        bn(torch.randn(1, 16, 1, 1, device=cuda))
+    with pytest.raises(Exception):
+        bn(torch.randn(4, 16, 3, 3))  # CPU tensor: no fallback

@@ -1,0 +1,114 @@
+"""ctypes binding of libtsg_hip.so (C-ABI in include/tsg_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+returns non-zero, the caller gets an exception.  The product path never routes
+around the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsg_hip.so")
+
+F32, BF16 = 0, 1
+NCHW, NHWC = 0, 1
+I64, U8 = 0, 1
+
+_ERR = {-1: "unsupported dtype", -2: "unsupported layout", -3: "bad shape",
+        -4: "misaligned pointer", -5: "null pointer", -6: "workspace too small"}
+
+
+class TsgError(RuntimeError):
+    pass
+
+
+class OhemPlan(C.Structure):
+    _fields_ = [("P", C.c_int64), ("C", C.c_int), ("grid", C.c_int), ("levels", C.c_int),
+                ("shift", C.c_int * 3), ("bins", C.c_int * 3), ("thresh_bits", C.c_uint32),
+                ("ws_bytes", C.c_size_t)]
+
+
+_p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); kept in lock-step with include/tsg_hip.h
+# (tests/test_abi.py parses the header and checks every symbol is exported).
+_PROTOS = {
+    "tsg_version": (_i, []),
+    "tsg_bn_num_partials": (_i, [_i, _i64, _i64, _i64]),
+    "tsg_bn_partial_ws_bytes": (_sz, [_i, _i64, _i64, _i64]),
+    "tsg_bn_stats": (_i, [_p, _i, _i, _i64, _i64, _i64, _p, _ip, _p]),
+    "tsg_bn_collapse": (_i, [_p, _i, _i64, _p, _p]),
+    "tsg_bn_finalize": (_i, [_p, _i, _i64, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "tsg_bn_apply_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _p]),
+    "tsg_bn_bwd_reduce": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _p, _ip, _p]),
+    "tsg_bn_bwd_coeffs": (_i, [_p, _i, _i64, _d, _p, _p, _p, _p, _p]),
+    "tsg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i, _p]),
+    "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),
+    "tsg_ohem_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _f, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "tsg_ohem_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "tsg_kth_ws_bytes": (_sz, [_i64]),
+    "tsg_kth_value": (_i, [_p, _i64, _i64, _p, _p, _sz, _p]),
+    "tsg_focal_ws_bytes": (_sz, [_i64]),
+    "tsg_focal_fwd": (_i, [_p, _i, _p, _i, _i64, _i64, _f, _f, _p, _p, _sz, _p]),
+    "tsg_focal_bwd": (_i, [_p, _i, _p, _i, _i64, _i64, _f, _f, _p, _p, _p]),
+    "tsg_upsample_bilinear_ac_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "tsg_upsample_bilinear_ac_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "tsg_upsample_nearest_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "tsg_psa_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_psa_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Return the loaded CDLL; raise if libtsg_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TsgError(
+                f"{LIB_PATH} not found: build it with `python -m torchseg_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        if handle.tsg_version() < 100:
+            raise TsgError("libtsg_hip.so is older than this package")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise TsgError(f"{what}: invalid argument ({_ERR.get(rc, rc)})")
+    raise TsgError(f"{what}: hipError_t {rc}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TsgError(f"unsupported activation dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def stream_ptr(t):
+    """hipStream_t of torch's current stream on the tensor's device."""
+    import torch
+    if not t.is_cuda:
+        raise TsgError("torchseg_amd kernels need tensors on an AMD GPU (got a CPU tensor); "
+                       "there is no CPU fallback in the product path")
+    return torch.cuda.current_stream(t.device).cuda_stream

@@ -1,0 +1,125 @@
+"""Tensor-level wrappers over the C-ABI (one method per libtsg_hip entry point).
+
+`HipKernels` is the only kernel provider the product registers.  The host
+logic (syncbn.py, ohem.py, ...) talks to a provider object so that the
+multi-process CPU tests can drive the same host logic with a stand-in provider
+that lives under tests/ — the package itself never falls back to anything.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def bn_layout(x):
+    """(layout, N, C, HW) of a dense activation, or None if it must be copied.
+
+    [N,C,H,W] contiguous -> NCHW; channels_last -> NHWC; HW == 1 is both, and the
+    NHWC kernels are the coalesced choice there.
+    """
+    if x.dim() == 2:
+        return L.NHWC, x.shape[0], x.shape[1], 1
+    n, c = x.shape[0], x.shape[1]
+    hw = 1
+    for s in x.shape[2:]:
+        hw *= s
+    if hw == 1 and x.is_contiguous():
+        return L.NHWC, n, c, 1
+    if x.is_contiguous():
+        return L.NCHW, n, c, hw
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return L.NHWC, n, c, hw
+    return None
+
+
+class HipKernels:
+    """libtsg_hip.so kernels on torch's current HIP stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = L.lib()
+
+    # ---- SyncBN -----------------------------------------------------------
+    def bn_stats(self, x, layout, N, Cc, HW):
+        """-> (partial fp32 [S,2,C], S)"""
+        lib = self.lib
+        smax = lib.tsg_bn_num_partials(layout, N, Cc, HW)
+        partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
+        rows = C.c_int(0)
+        L.check(lib.tsg_bn_stats(x.data_ptr(), L.dtype_code(x), layout, N, Cc, HW,
+                                 partial.data_ptr(), C.byref(rows), L.stream_ptr(x)), "tsg_bn_stats")
+        return partial, rows.value
+
+    def bn_collapse(self, partial, S, Cc, out):
+        L.check(self.lib.tsg_bn_collapse(partial.data_ptr(), S, Cc, out.data_ptr(),
+                                         L.stream_ptr(partial)), "tsg_bn_collapse")
+
+    def bn_finalize(self, partial, S, Cc, count, count_dev, eps, momentum,
+                    running_mean, running_var, nbt):
+        mean = torch.empty(Cc, dtype=torch.float32, device=partial.device)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=partial.device)
+        L.check(self.lib.tsg_bn_finalize(partial.data_ptr(), S, Cc, float(count), L.ptr(count_dev),
+                                         eps, momentum, L.ptr(running_mean), L.ptr(running_var),
+                                         L.ptr(nbt), mean.data_ptr(), invstd.data_ptr(),
+                                         L.stream_ptr(partial)), "tsg_bn_finalize")
+        return mean, invstd
+
+    def bn_apply_fwd(self, x, residual, layout, N, Cc, HW, mean, invstd, gamma, beta, relu, out=None):
+        y = torch.empty_like(x) if out is None else out
+        L.check(self.lib.tsg_bn_apply_fwd(x.data_ptr(), L.ptr(residual), y.data_ptr(),
+                                          L.dtype_code(x), layout, N, Cc, HW, mean.data_ptr(),
+                                          invstd.data_ptr(), L.ptr(gamma), L.ptr(beta),
+                                          int(relu), L.stream_ptr(x)), "tsg_bn_apply_fwd")
+        return y
+
+    def bn_bwd_reduce(self, dy, x, y, layout, N, Cc, HW, mean, invstd, gamma, beta, relu):
+        lib = self.lib
+        smax = lib.tsg_bn_num_partials(layout, N, Cc, HW)
+        partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
+        rows = C.c_int(0)
+        L.check(lib.tsg_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), L.ptr(y), L.dtype_code(x),
+                                      layout, N, Cc, HW, mean.data_ptr(), invstd.data_ptr(),
+                                      L.ptr(gamma), L.ptr(beta), int(relu), partial.data_ptr(),
+                                      C.byref(rows), L.stream_ptr(x)), "tsg_bn_bwd_reduce")
+        return partial, rows.value
+
+    def bn_bwd_coeffs(self, partial, S, Cc, count, count_dev, want_param_grads, want_k):
+        dev = partial.device
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=dev) if want_param_grads else None
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=dev) if want_param_grads else None
+        k = torch.empty((2, Cc), dtype=torch.float32, device=dev) if want_k else None
+        L.check(self.lib.tsg_bn_bwd_coeffs(partial.data_ptr(), S, Cc, float(count), L.ptr(count_dev),
+                                           L.ptr(dgamma), L.ptr(dbeta), L.ptr(k),
+                                           L.stream_ptr(partial)), "tsg_bn_bwd_coeffs")
+        return dgamma, dbeta, k
+
+    def bn_bwd_apply(self, dy, x, y, layout, N, Cc, HW, mean, invstd, gamma, beta, k, relu, want_dres):
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_dres else None
+        L.check(self.lib.tsg_bn_bwd_apply(dy.data_ptr(), x.data_ptr(), L.ptr(y), dx.data_ptr(),
+                                          L.ptr(dres), L.dtype_code(x), layout, N, Cc, HW,
+                                          mean.data_ptr(), invstd.data_ptr(), L.ptr(gamma),
+                                          L.ptr(beta), k.data_ptr(), int(relu),
+                                          L.stream_ptr(x)), "tsg_bn_bwd_apply")
+        return dx, dres
+
+
+_provider = None
+
+
+def provider():
+    """The kernel provider of the product path: HipKernels, or an exception."""
+    global _provider
+    if _provider is None:
+        _provider = HipKernels()
+    return _provider
+
+
+def _set_provider_for_tests(p):
+    """tests/ only: swap in a stand-in provider to exercise host logic on CPU."""
+    global _provider
+    old = _provider
+    _provider = p
+    return old

@@ -1,0 +1,181 @@
+"""SyncBatchNorm host logic: the autograd function and the nn.Module that the
+reference obtains from `apex.parallel` (model/*/train.py:24-25,54-55).
+
+Arithmetic: furnace/legacy/sync_bn/syncbn.py:32-52,86-98 (sum / square-sum ->
+mean, biased var for normalisation, unbiased var for the running estimate) and
+syncbn_kernel.cu:92-138,160-174 for the backward.  Exchange steps (one per
+direction, as §8(e) of SURVEY.md lists):
+  forward : all-reduce(SUM) of [sum x | sum x^2 | count_hi | count_lo]  (2C+2 fp32)
+  backward: all-reduce(SUM) of [sum dy' | sum dy' xhat]                 (2C fp32)
+With world_size 1 both collectives are skipped.
+
+Extension over the reference surface (used by our furnace/seg_opr and
+base_model, invisible to an unchanged network.py): `forward(x, residual=None,
+relu=False)` fuses the residual add and the ReLU that follow the BN into the
+normalise kernel, and their backward into the BN backward kernels.
+"""
+import torch
+import torch.distributed as dist
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import kernels as K
+
+_count_cache = {}
+
+
+def _count_words(n, device):
+    """Device tensor [n // 4096, n % 4096] (fp32): an exactly summable count."""
+    key = (n, device)
+    t = _count_cache.get(key)
+    if t is None:
+        t = torch.tensor([float(n // 4096), float(n % 4096)], dtype=torch.float32, device=device)
+        _count_cache[key] = t
+    return t
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def _dense(x):
+    """Return (x_dense, layout tuple): copies only when x is neither NCHW- nor NHWC-dense."""
+    lay = K.bn_layout(x)
+    if lay is None:
+        if x.dim() == 4 and x.stride(1) == 1:
+            x = x.contiguous(memory_format=torch.channels_last)
+        else:
+            x = x.contiguous()
+        lay = K.bn_layout(x)
+    return x, lay
+
+
+def _like(t, ref):
+    """t with ref's dtype and strides (no copy when it already matches)."""
+    if t.dtype != ref.dtype:
+        t = t.to(ref.dtype)
+    if t.stride() != ref.stride():
+        out = torch.empty_like(ref)
+        out.copy_(t)
+        t = out
+    return t
+
+
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, mod, relu, use_batch_stats, group):
+        kp = K.provider()
+        x, (layout, N, C, HW) = _dense(x)
+        if residual is not None:
+            residual = _like(residual, x)
+        world = _world(group) if use_batch_stats else 1
+        count_dev = None
+        n_local = N * HW
+        if use_batch_stats:
+            if world == 1 and n_local <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size {}"
+                                 .format(tuple(x.shape)))
+            partial, S = kp.bn_stats(x, layout, N, C, HW)
+            rm = mod.running_mean if mod.track_running_stats else None
+            rv = mod.running_var if mod.track_running_stats else None
+            nbt = mod.num_batches_tracked if mod.track_running_stats else None
+            momentum = 0.0 if mod.momentum is None else float(mod.momentum)
+            if world > 1:
+                msg = torch.empty(2 * C + 2, dtype=torch.float32, device=x.device)
+                kp.bn_collapse(partial, S, C, msg)
+                msg[2 * C:].copy_(_count_words(n_local, x.device))
+                dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+                count_dev = msg[2 * C:]
+                mean, invstd = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum, rm, rv, nbt)
+            else:
+                mean, invstd = kp.bn_finalize(partial, S, C, float(n_local), None, float(mod.eps),
+                                              momentum, rm, rv, nbt)
+        else:
+            mean = mod.running_mean.float()
+            invstd = torch.rsqrt(mod.running_var.float() + mod.eps)
+        y = kp.bn_apply_fwd(x, residual, layout, N, C, HW, mean, invstd, weight, bias, relu)
+        need_y = relu and residual is not None
+        ctx.save_for_backward(x, y if need_y else None, weight, bias, mean, invstd, count_dev)
+        ctx.cfg = (layout, N, C, HW, relu, use_batch_stats, group, world, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        kp = K.provider()
+        x, y, weight, bias, mean, invstd, count_dev = ctx.saved_tensors
+        layout, N, C, HW, relu, use_batch_stats, group, world, has_res = ctx.cfg
+        dy = _like(dy, x)
+        partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, mean, invstd, weight, bias, relu)
+        want_pg = weight is not None
+        if not use_batch_stats:
+            dgamma, dbeta, _ = kp.bn_bwd_coeffs(partial, S, C, 1.0, None, True, False)
+            k = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        elif world > 1:
+            sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+            kp.bn_collapse(partial, S, C, sums)
+            dgamma, dbeta, _ = kp.bn_bwd_coeffs(sums, 1, C, 1.0, None, True, False)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            _, _, k = kp.bn_bwd_coeffs(sums, 1, C, 0.0, count_dev, False, True)
+        else:
+            dgamma, dbeta, k = kp.bn_bwd_coeffs(partial, S, C, float(N * HW), None, True, True)
+        dx, dres = kp.bn_bwd_apply(dy, x, y, layout, N, C, HW, mean, invstd, weight, bias, k, relu, has_res)
+        if not want_pg:
+            dgamma = dbeta = None
+        else:
+            dgamma = dgamma.to(weight.dtype)
+            dbeta = dbeta.to(bias.dtype) if bias is not None else None
+        return dx, dres, dgamma, dbeta, None, None, None, None
+
+
+class SyncBatchNorm(_BatchNorm):
+    """Drop-in for apex.parallel.SyncBatchNorm / torch.nn.BatchNorm{1,2,3}d.
+
+    Constructor as the reference calls it: norm_layer(planes, eps=, momentum=)
+    (furnace/base_model/resnet.py:24,28), norm_layer(planes, eps=)
+    (seg_oprs.py:34), norm_layer(channels) (seg_oprs.py:85).  `.eps`,
+    `.momentum`, `.weight`, `.bias` stay writable (utils/init_func.py:16-21) and
+    the buffers keep torch's names so ImageNet checkpoints load.
+    """
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True,
+                 track_running_stats=True, process_group=None, channel_last=False,
+                 fuse_relu=False):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine,
+                         track_running_stats=track_running_stats)
+        self.process_group = process_group
+        self.channel_last = channel_last
+        self.fuse_relu = fuse_relu
+
+    def _check_input_dim(self, input):
+        if input.dim() < 2:
+            raise ValueError("expected at least 2D input (got {}D input)".format(input.dim()))
+        if input.shape[1] != self.num_features:
+            raise ValueError("expected {} channels, got {}".format(self.num_features, input.shape[1]))
+
+    def forward(self, input, residual=None, relu=None):
+        self._check_input_dim(input)
+        if self.momentum is None:
+            raise NotImplementedError("cumulative moving average (momentum=None) is not supported")
+        relu = self.fuse_relu if relu is None else bool(relu)
+        use_batch_stats = self.training or not self.track_running_stats
+        return _SyncBNFn.apply(input, residual, self.weight, self.bias, self, relu,
+                               use_batch_stats, self.process_group)
+
+
+def convert_syncbn_model(module, process_group=None, channel_last=False):
+    """apex.parallel.convert_syncbn_model: swap torch BatchNorm layers for ours."""
+    mod = module
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(module, SyncBatchNorm):
+        mod = SyncBatchNorm(module.num_features, module.eps, module.momentum, module.affine,
+                            module.track_running_stats, process_group, channel_last)
+        if module.affine:
+            mod.weight = module.weight
+            mod.bias = module.bias
+        if module.track_running_stats:
+            mod.running_mean = module.running_mean
+            mod.running_var = module.running_var
+            mod.num_batches_tracked = module.num_batches_tracked
+    for name, child in module.named_children():
+        mod.add_module(name, convert_syncbn_model(child, process_group, channel_last))
+    return mod
