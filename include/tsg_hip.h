@@ -147,7 +147,9 @@ int tsg_ohem_make_plan(int64_t B, int C, int64_t HW, float thresh,
 
 /* Forward.  Writes nll[P] (= lse - x_t, 0 for ignored pixels), lse[P],
  * loss[1] (fp32 mean over kept pixels, NaN when none) and
- * sel[4] = {thr (float bits), n_kept, num_valid, branch}.
+ * sel[8] = {thr (float bits), n_kept, num_valid, branch, denominator (float
+ * bits), 0, 0, 0}; branch 0: thr == thresh, 1: thr == k-th smallest p_t,
+ * 2: no hard-example mining applied (loss_opr.py:78-80, :85).
  * min_kept / thresh / ignore_label as in loss_opr.py:49-56.
  * weight (class weights, loss_opr.py:57-63) may be NULL. */
 int tsg_ohem_fwd(const void* logits, int dtype, const void* labels, int ltype,
@@ -203,21 +205,6 @@ int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype,
 int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes,
                              int64_t NC, int IH, int IW, int OH, int OW,
                              void* stream);
-
-/* ------------------------------------------------------------------------
- * PSANet collect / distribute attention — replaces
- *   torch.bmm(X, torch.softmax(A, dim=1))
- * (model/psanet/ade.psanet.R101_v1c/network.py:125-126,135-136).
- * X [B, Cx, L], A [B, L, L] (softmax over dim 1 = the row index i), out [B, Cx, L].
- * ---------------------------------------------------------------------- */
-size_t tsg_psa_ws_bytes(int64_t B, int64_t Cx, int64_t L);
-int tsg_psa_fwd(const void* X, const void* A, void* out, float* colstat,
-                int dtype, int64_t B, int64_t Cx, int64_t L,
-                void* ws, size_t ws_bytes, void* stream);
-int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
-                const float* colstat, void* dX, void* dA,
-                int dtype, int64_t B, int64_t Cx, int64_t L,
-                void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused SGD step over a flat parameter bucket (torch.optim.SGD semantics as

@@ -1,0 +1,111 @@
+"""Generate golden vectors from the REFERENCE's own Python (run in the build
+container only: needs /root/reference).  Output: tests/golden/*.npz (committed).
+
+    python tests/golden/make_golden.py
+
+The only edit applied to reference source (in memory, nothing is copied into
+this repo) is `1 - valid_mask` -> `~valid_mask` in loss_opr.py:81,95, which
+torch >= 1.2 requires and which does not change results.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference_loss_opr():
+    sys.path.insert(0, os.path.join(REF, "furnace"))
+    import utils.pyt_utils  # noqa: F401  (must precede engine.logger: circular import in the reference)
+    src = open(os.path.join(REF, "furnace/seg_opr/loss_opr.py")).read()
+    assert src.count("1 - valid_mask") == 2
+    src = src.replace("1 - valid_mask", "~valid_mask")
+    mod = types.ModuleType("ref_loss_opr")
+    exec(compile(src, "ref_loss_opr.py", "exec"), mod.__dict__)
+    return mod
+
+
+def ohem_cases():
+    g = torch.Generator().manual_seed(1234)
+    B, C, H, W = 2, 19, 24, 24
+    P = B * H * W
+
+    def labels(ignore_rows=2, all_ignored=False):
+        t = torch.randint(0, C, (B, H, W), generator=g)
+        t[:, :ignore_rows] = 255
+        if all_ignored:
+            t[:] = 255
+        return t
+
+    def confident(t, sharp=8.0, flip=0.1):
+        t2 = t.clone()
+        t2[t2 == 255] = 0
+        flipm = torch.rand(t.shape, generator=g) < flip
+        t2[flipm] = torch.randint(0, C, (int(flipm.sum()),), generator=g)
+        return sharp * torch.nn.functional.one_hot(t2, C).permute(0, 3, 1, 2).float() + torch.randn(B, C, H, W, generator=g)
+
+    cases = {}
+    t = labels()
+    cases["random_thr"] = dict(pred=torch.randn(B, C, H, W, generator=g), target=t, thresh=0.7, min_kept=P // 16, use_weight=False)
+    t = labels()
+    cases["confident_kth"] = dict(pred=confident(t), target=t, thresh=0.7, min_kept=P // 2, use_weight=False)
+    t = labels()
+    cases["confident_thr"] = dict(pred=confident(t, flip=0.4), target=t, thresh=0.7, min_kept=P // 16, use_weight=False)
+    t = labels(ignore_rows=20)
+    cases["minkept_gt_valid"] = dict(pred=torch.randn(B, C, H, W, generator=g), target=t, thresh=0.7, min_kept=P // 2, use_weight=False)
+    t = labels(all_ignored=True)
+    cases["all_ignored"] = dict(pred=torch.randn(B, C, H, W, generator=g), target=t, thresh=0.7, min_kept=0, use_weight=False)
+    t = labels()
+    cases["minkept_zero"] = dict(pred=confident(t), target=t, thresh=0.7, min_kept=0, use_weight=False)
+    t = labels()
+    cases["weighted_kth"] = dict(pred=confident(t), target=t, thresh=0.6, min_kept=256, use_weight=True)
+    t = labels(ignore_rows=0)
+    cases["kept_all"] = dict(pred=confident(t), target=t, thresh=0.7, min_kept=P, use_weight=False)
+    return cases
+
+
+def main():
+    ref = load_reference_loss_opr()
+    out = {}
+    for name, c in ohem_cases().items():
+        crit = ref.ProbOhemCrossEntropy2d(ignore_label=255, thresh=c["thresh"], min_kept=c["min_kept"],
+                                          use_weight=c["use_weight"])
+        pred = c["pred"].clone().requires_grad_(True)
+        loss = crit(pred, c["target"].clone())
+        if torch.isfinite(loss):
+            loss.backward()
+            grad = pred.grad
+        else:
+            grad = torch.zeros_like(pred)
+        out[name + "/pred"] = c["pred"].numpy()
+        out[name + "/target"] = c["target"].numpy().astype(np.uint8)
+        out[name + "/cfg"] = np.array([c["thresh"], c["min_kept"], float(c["use_weight"])], dtype=np.float64)
+        out[name + "/loss"] = np.array(loss.item(), dtype=np.float64)
+        out[name + "/grad"] = grad.numpy()
+        print(name, "loss", loss.item(), "kept", int((grad.abs().sum(1) > 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "ohem_golden.npz"), **out)
+
+    out = {}
+    g = torch.Generator().manual_seed(99)
+    for name, (gamma, alpha) in {"dfn_default": (2.0, 0.25), "dfn_city": (2.0, 0.1), "g15": (1.5, 0.4)}.items():
+        crit = ref.SigmoidFocalLoss(ignore_label=255, gamma=gamma, alpha=alpha)
+        pred = (torch.randn(2, 1, 20, 28, generator=g) * 2).requires_grad_(True)
+        tgt = torch.randint(0, 2, (2, 20, 28), generator=g)
+        tgt[torch.rand(2, 20, 28, generator=g) < 0.15] = 255
+        loss = crit(pred, tgt)
+        loss.backward()
+        out[name + "/pred"] = pred.detach().numpy()
+        out[name + "/target"] = tgt.numpy().astype(np.uint8)
+        out[name + "/cfg"] = np.array([gamma, alpha])
+        out[name + "/loss"] = np.array(loss.item(), dtype=np.float64)
+        out[name + "/grad"] = pred.grad.numpy()
+        print(name, "focal", loss.item())
+    np.savez_compressed(os.path.join(HERE, "focal_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tsg_hip.h declares,
+and the ctypes prototype table covers exactly that set (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "tsg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(tsg_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol():
+    from torchseg_amd import _lib, build
+    build.build()
+    names = _declared()
+    assert len(names) >= 20
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(h, n)]
+    assert not missing, missing
+    assert set(_lib._PROTOS) == names
+    assert _lib.lib().tsg_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    from torchseg_amd import _lib
+    lib = _lib.lib()
+    assert lib.tsg_bn_num_partials(_lib.NCHW, 16, 64, 512 * 512) >= 1
+    assert lib.tsg_bn_num_partials(_lib.NHWC, 0, 64, 4) < 0
+    plan = _lib.OhemPlan()
+    assert lib.tsg_ohem_make_plan(16, 19, 1024 * 1024, 0.7, ctypes.byref(plan)) == 0
+    assert plan.P == 16 * 1024 * 1024 and plan.levels == 2 and plan.bins[0] == 1229 and plan.bins[1] == 4096
+    assert plan.ws_bytes > 0
+    assert lib.tsg_ohem_make_plan(0, 19, 4, 0.7, ctypes.byref(plan)) < 0
+    # NULL pointers are rejected before any launch
+    assert lib.tsg_bn_stats(None, 0, 0, 1, 1, 1, None, None, None) < 0
+    assert lib.tsg_sgd_step(None, None, None, 4, 0.1, 0.9, 0.0, 1.0, 1, None) < 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    import pytest
+    import torch
+    from torchseg_amd.losses import ProbOhemCrossEntropy2d
+    from torchseg_amd.syncbn import SyncBatchNorm
+    with pytest.raises(Exception):
+        SyncBatchNorm(4)(torch.randn(2, 4, 3, 3))
+    with pytest.raises(Exception):
+        ProbOhemCrossEntropy2d(255, thresh=0.7, min_kept=1)(torch.randn(1, 3, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))

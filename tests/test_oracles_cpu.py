@@ -1,0 +1,69 @@
+"""CPU: pin the oracle restatements against (a) golden vectors produced by the
+reference's own Python (tests/golden/make_golden.py) and (b) torch CPU ops."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import focal_ref, ohem_ref, upsample_ref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cases(npz):
+    return sorted({k.split("/")[0] for k in npz.files})
+
+
+def test_ohem_oracle_matches_reference_golden():
+    z = np.load(os.path.join(GOLD, "ohem_golden.npz"))
+    assert len(_cases(z)) >= 8
+    for name in _cases(z):
+        pred = torch.from_numpy(z[name + "/pred"]).requires_grad_(True)
+        target = torch.from_numpy(z[name + "/target"].astype(np.int64))
+        thresh, min_kept, use_w = z[name + "/cfg"]
+        w = torch.tensor(ohem_ref.CITYSCAPES_WEIGHT) if use_w else None
+        loss, info = ohem_ref.ohem_cross_entropy(pred, target, 255, float(thresh), int(min_kept), w, return_info=True)
+        ref_loss = float(z[name + "/loss"])
+        if np.isnan(ref_loss):
+            assert torch.isnan(loss), name
+            continue
+        assert loss.item() == pytest.approx(ref_loss, rel=0, abs=0), name   # same ops => bit-equal
+        loss.backward()
+        np.testing.assert_array_equal(pred.grad.numpy(), z[name + "/grad"], err_msg=name)
+        kept_ref = np.abs(z[name + "/grad"]).sum(1) > 0
+        np.testing.assert_array_equal(info["kept"].numpy(), kept_ref, err_msg=name)
+
+
+def test_focal_oracle_matches_reference_golden():
+    z = np.load(os.path.join(GOLD, "focal_golden.npz"))
+    for name in _cases(z):
+        pred = torch.from_numpy(z[name + "/pred"]).requires_grad_(True)
+        target = torch.from_numpy(z[name + "/target"].astype(np.int64))
+        gamma, alpha = z[name + "/cfg"]
+        loss = focal_ref.sigmoid_focal_loss(pred, target, 255, float(gamma), float(alpha))
+        assert loss.item() == pytest.approx(float(z[name + "/loss"]), rel=1e-7)
+        loss.backward()
+        np.testing.assert_allclose(pred.grad.numpy(), z[name + "/grad"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("ih,iw,oh,ow", [(1, 1, 32, 32), (32, 32, 64, 64), (8, 8, 64, 64), (7, 5, 13, 9),
+                                         (16, 12, 128, 96), (6, 6, 6, 6), (9, 9, 4, 3), (3, 4, 1, 1)])
+def test_upsample_oracle_matches_torch_cpu(ih, iw, oh, ow):
+    g = torch.Generator().manual_seed(ih * 100 + ow)
+    x = torch.randn(2, 3, ih, iw, generator=g, dtype=torch.float32, requires_grad=True)
+    y = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float32)
+    y.backward(dy)
+    np.testing.assert_allclose(upsample_ref.upsample_bilinear_ac(x.detach().numpy(), oh, ow), y.detach().numpy(),
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(upsample_ref.upsample_bilinear_ac_backward(dy.numpy(), ih, iw), x.grad.numpy(),
+                               rtol=1e-4, atol=1e-4)
+
+
+def test_nearest_oracle_matches_torch_cpu():
+    x = torch.arange(2 * 20 * 30, dtype=torch.float32).reshape(1, 2, 20, 30)
+    for oh, ow in [(10, 15), (40, 45), (7, 11), (20, 30)]:
+        y = F.interpolate(x, size=(oh, ow), mode="nearest")
+        np.testing.assert_array_equal(upsample_ref.upsample_nearest(x.numpy(), oh, ow), y.numpy())

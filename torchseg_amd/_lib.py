@@ -55,9 +55,6 @@ _PROTOS = {
     "tsg_upsample_bilinear_ac_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_upsample_bilinear_ac_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_upsample_nearest_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
-    "tsg_psa_ws_bytes": (_sz, [_i64, _i64, _i64]),
-    "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _p, _sz, _p]),
-    "tsg_psa_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
 }
 

@@ -123,3 +123,105 @@ def _set_provider_for_tests(p):
     old = _provider
     _provider = p
     return old
+
+
+def _label_code(t):
+    if t.dtype == torch.int64:
+        return L.I64
+    if t.dtype == torch.uint8:
+        return L.U8
+    raise L.TsgError(f"labels must be int64 or uint8, got {t.dtype}")
+
+
+def _ohem_methods():
+    def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
+        """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
+        B, Cc = logits.shape[0], logits.shape[1]
+        HW = logits.numel() // (B * Cc)
+        P = B * HW
+        dev = logits.device
+        plan = L.OhemPlan()
+        L.check(self.lib.tsg_ohem_make_plan(B, Cc, HW, float(thresh), C.byref(plan)), "tsg_ohem_make_plan")
+        ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+        nll = torch.empty(P, dtype=torch.float32, device=dev)
+        lse = torch.empty(P, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        sel = torch.empty(8, dtype=torch.int32, device=dev)
+        L.check(self.lib.tsg_ohem_fwd(logits.data_ptr(), L.dtype_code(logits), labels.data_ptr(),
+                                      _label_code(labels), B, Cc, HW, int(ignore_label), float(thresh),
+                                      int(min_kept), L.ptr(weight), nll.data_ptr(), lse.data_ptr(),
+                                      loss.data_ptr(), sel.data_ptr(), ws.data_ptr(), plan.ws_bytes,
+                                      L.stream_ptr(logits)), "tsg_ohem_fwd")
+        return loss, nll, lse, sel
+
+    def ohem_bwd(self, logits, labels, ignore_label, weight, nll, lse, sel, gscale):
+        B, Cc = logits.shape[0], logits.shape[1]
+        HW = logits.numel() // (B * Cc)
+        dlogits = torch.empty_like(logits)
+        L.check(self.lib.tsg_ohem_bwd(logits.data_ptr(), L.dtype_code(logits), labels.data_ptr(),
+                                      _label_code(labels), B, Cc, HW, int(ignore_label), L.ptr(weight),
+                                      nll.data_ptr(), lse.data_ptr(), sel.data_ptr(), gscale.data_ptr(),
+                                      dlogits.data_ptr(), None, L.stream_ptr(logits)), "tsg_ohem_bwd")
+        return dlogits
+
+    def kth_value(self, v, k):
+        n = v.numel()
+        wsb = self.lib.tsg_kth_ws_bytes(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=v.device)
+        out = torch.empty(1, dtype=torch.float32, device=v.device)
+        L.check(self.lib.tsg_kth_value(v.data_ptr(), n, int(k), out.data_ptr(), ws.data_ptr(), wsb,
+                                       L.stream_ptr(v)), "tsg_kth_value")
+        return out
+
+    def focal_fwd(self, pred, target, ignore_label, gamma, alpha):
+        P = pred.numel()
+        wsb = self.lib.tsg_focal_ws_bytes(P)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=pred.device)
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        L.check(self.lib.tsg_focal_fwd(pred.data_ptr(), L.dtype_code(pred), target.data_ptr(),
+                                       _label_code(target), P, int(ignore_label), float(gamma),
+                                       float(alpha), loss.data_ptr(), ws.data_ptr(), wsb,
+                                       L.stream_ptr(pred)), "tsg_focal_fwd")
+        return loss
+
+    def focal_bwd(self, pred, target, ignore_label, gamma, alpha, gscale):
+        dpred = torch.empty_like(pred)
+        L.check(self.lib.tsg_focal_bwd(pred.data_ptr(), L.dtype_code(pred), target.data_ptr(),
+                                       _label_code(target), pred.numel(), int(ignore_label), float(gamma),
+                                       float(alpha), gscale.data_ptr(), dpred.data_ptr(),
+                                       L.stream_ptr(pred)), "tsg_focal_bwd")
+        return dpred
+
+    def upsample_fwd(self, x, add, OH, OW):
+        """x [N,C,IH,IW] contiguous -> [N,C,OH,OW]"""
+        N, Cc, IH, IW = x.shape
+        y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device)
+        L.check(self.lib.tsg_upsample_bilinear_ac_fwd(x.data_ptr(), L.ptr(add), y.data_ptr(),
+                                                      L.dtype_code(x), N * Cc, IH, IW, OH, OW,
+                                                      L.stream_ptr(x)), "tsg_upsample_bilinear_ac_fwd")
+        return y
+
+    def upsample_bwd(self, dy, IH, IW):
+        N, Cc, OH, OW = dy.shape
+        dx = torch.empty((N, Cc, IH, IW), dtype=dy.dtype, device=dy.device)
+        L.check(self.lib.tsg_upsample_bilinear_ac_bwd(dy.data_ptr(), dx.data_ptr(), L.dtype_code(dy),
+                                                      N * Cc, IH, IW, OH, OW, L.stream_ptr(dy)),
+                "tsg_upsample_bilinear_ac_bwd")
+        return dx
+
+    def upsample_nearest(self, x, OH, OW):
+        shp = x.shape
+        IH, IW = shp[-2], shp[-1]
+        NC = x.numel() // (IH * IW)
+        y = torch.empty(tuple(shp[:-2]) + (OH, OW), dtype=x.dtype, device=x.device)
+        L.check(self.lib.tsg_upsample_nearest_fwd(x.data_ptr(), y.data_ptr(), x.element_size(), NC,
+                                                  IH, IW, OH, OW, L.stream_ptr(x)),
+                "tsg_upsample_nearest_fwd")
+        return y
+
+    for f in (ohem_fwd, ohem_bwd, kth_value, focal_fwd, focal_bwd, upsample_fwd, upsample_bwd,
+              upsample_nearest):
+        setattr(HipKernels, f.__name__, f)
+
+
+_ohem_methods()
