@@ -1,0 +1,118 @@
+"""CPU, gloo, world_size 2: the N>1 host path (SyncBN exchange steps + bucketed
+overlapped gradient averaging) — identical numbers to one process on the
+concatenated batch.  The SyncBN math here comes from a tests/-only stand-in
+provider (tests/_cpu_provider.py); the HIP provider is covered by -m gpu tests."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Net(nn.Module):
+    def __init__(self, norm):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 8, 3, padding=1, bias=False)
+        self.b1 = norm(8)
+        self.c2 = nn.Conv2d(8, 8, 3, padding=1, bias=False)
+        self.b2 = norm(8)
+        self.unused = nn.Conv2d(8, 4, 1)           # never used: DDP must tolerate (DFN has 5 such tensors)
+        self.head = nn.Conv2d(8, 5, 1)
+
+    def forward(self, x, y):
+        from torchseg_amd.syncbn import SyncBatchNorm
+        h = self.c1(x)
+        h = self.b1(h, relu=True) if isinstance(self.b1, SyncBatchNorm) else torch.relu(self.b1(h))
+        r = h
+        h = self.c2(h)
+        h = self.b2(h, residual=r, relu=True) if isinstance(self.b2, SyncBatchNorm) else torch.relu(self.b2(h) + r)
+        return nn.functional.cross_entropy(self.head(h), y)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _cpu_provider import OracleProvider
+    from torchseg_amd import kernels as K
+    from torchseg_amd.ddp import DistributedDataParallel
+    from torchseg_amd.syncbn import SyncBatchNorm
+    K._set_provider_for_tests(OracleProvider())
+    torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
+    model = DistributedDataParallel(Net(SyncBatchNorm), message_size=300)
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn(world, 3, 3, 6, 6, generator=g)       # unequal batches are allowed: rank r uses 3 (+1 for rank 1)
+    ys = torch.randint(0, 5, (world, 3, 6, 6), generator=g)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    losses = []
+    for step in range(3):                          # step 0 builds the bucket plan, 1-2 use overlapped buckets
+        opt.zero_grad()
+        loss = model(xs[rank], ys[rank])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    sd = {k: v.clone().numpy() for k, v in model.module.state_dict().items()}   # numpy: no fd-sharing through the queue
+    q.put((rank, losses, sd, len(model.reducer.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_and_ddp_world2_match_single_process():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, losses, sd, nb = q.get(timeout=180)
+        res[r] = (losses, sd, nb)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    # single-process reference: plain BatchNorm2d on the concatenated batch; mean loss over ranks
+    torch.manual_seed(100)                        # rank 0's init is what gets broadcast
+    ref = Net(nn.BatchNorm2d)
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn(world, 3, 3, 6, 6, generator=g)
+    ys = torch.randint(0, 5, (world, 3, 6, 6), generator=g)
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    ref_losses = []
+    for step in range(3):
+        opt.zero_grad()
+        x = xs.reshape(-1, 3, 6, 6)
+        h = ref.c1(x); h = torch.relu(ref.b1(h)); r_ = h
+        h = torch.relu(ref.b2(ref.c2(h)) + r_)
+        logits = ref.head(h)
+        per_rank = [nn.functional.cross_entropy(logits[i * 3:(i + 1) * 3], ys[i]) for i in range(world)]
+        loss = sum(per_rank) / world
+        loss.backward()
+        opt.step()
+        ref_losses.append([l.item() for l in per_rank])
+    assert res[0][2] >= 2                          # message_size=300 elements => several buckets
+    for r in range(world):
+        for step in range(3):
+            assert abs(res[r][0][step] - ref_losses[step][r]) < 2e-5, (r, step)
+    sd_ref = ref.state_dict()
+    for k, v in sd_ref.items():
+        for r in range(world):
+            torch.testing.assert_close(torch.from_numpy(res[r][1][k]), v, rtol=2e-4, atol=2e-5, msg=k)
+    for k in res[0][1]:
+        assert (res[0][1][k] == res[1][1][k]).all(), k   # replicas stay bit-identical

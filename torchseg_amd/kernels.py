@@ -33,6 +33,15 @@ def bn_layout(x):
     return None
 
 
+def _label_code(t):
+    if t.dtype == torch.int64:
+        return L.I64
+    if t.dtype == torch.uint8:
+        return L.U8
+    raise L.TsgError(f"labels must be int64 or uint8, got {t.dtype}")
+
+
+
 class HipKernels:
     """libtsg_hip.so kernels on torch's current HIP stream."""
 
@@ -105,35 +114,7 @@ class HipKernels:
                                           L.stream_ptr(x)), "tsg_bn_bwd_apply")
         return dx, dres
 
-
-_provider = None
-
-
-def provider():
-    """The kernel provider of the product path: HipKernels, or an exception."""
-    global _provider
-    if _provider is None:
-        _provider = HipKernels()
-    return _provider
-
-
-def _set_provider_for_tests(p):
-    """tests/ only: swap in a stand-in provider to exercise host logic on CPU."""
-    global _provider
-    old = _provider
-    _provider = p
-    return old
-
-
-def _label_code(t):
-    if t.dtype == torch.int64:
-        return L.I64
-    if t.dtype == torch.uint8:
-        return L.U8
-    raise L.TsgError(f"labels must be int64 or uint8, got {t.dtype}")
-
-
-def _ohem_methods():
+    # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
         B, Cc = logits.shape[0], logits.shape[1]
@@ -219,9 +200,103 @@ def _ohem_methods():
                 "tsg_upsample_nearest_fwd")
         return y
 
-    for f in (ohem_fwd, ohem_bwd, kth_value, focal_fwd, focal_bwd, upsample_fwd, upsample_bwd,
-              upsample_nearest):
-        setattr(HipKernels, f.__name__, f)
+
+_provider = None
 
 
-_ohem_methods()
+def provider():
+    """The kernel provider of the product path: HipKernels, or an exception."""
+    global _provider
+    if _provider is None:
+        _provider = HipKernels()
+    return _provider
+
+
+def _set_provider_for_tests(p):
+    """tests/ only: swap in a stand-in provider to exercise host logic on CPU."""
+    global _provider
+    old = _provider
+    _provider = p
+    return old
+
+
+def _nbytes(t):
+    return 0 if t is None else t.numel() * t.element_size()
+
+
+# algorithmic bytes per launch (each operand read once + each result written once, the
+# convention of the reference's own tools/benchmark/compute_memory.py:49-72); DESIGN.md §4
+_ALGO_BYTES = {
+    "bn_stats": lambda a, r: _nbytes(a[0]),
+    "bn_apply_fwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]),
+    "bn_bwd_reduce": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[2]),
+    "bn_bwd_apply": lambda a, r: 3 * _nbytes(a[0]) + _nbytes(a[2]) + (_nbytes(a[0]) if a[13] else 0),
+    "ohem_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
+    "ohem_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
+    "upsample_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
+    "upsample_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+}
+
+
+class KernelTimer:
+    """Brackets every launch of the streaming kernels with HIP events recorded on
+    the stream the kernel is enqueued on (torch's current stream) and accumulates
+    algorithmic bytes, so bench.py can report achieved GB/s per kernel live."""
+
+    def __init__(self, prov, names=None):
+        self.prov = prov
+        self.names = list(names or _ALGO_BYTES.keys())
+        self.records = {n: [] for n in self.names}
+        self._orig = {}
+        for n in self.names:
+            self._wrap(n)
+
+    def _wrap(self, name):
+        fn = getattr(self.prov, name)
+        self._orig[name] = fn
+        rec = self.records[name]
+        cost = _ALGO_BYTES[name]
+
+        def timed(*args, **kw):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*args, **kw)
+            e.record()
+            rec.append((s, e, cost(args, out[0] if isinstance(out, tuple) else out)))
+            return out
+
+        setattr(self.prov, name, timed)
+
+    def stop(self):
+        for n, fn in self._orig.items():
+            try:
+                delattr(self.prov, n)
+            except AttributeError:
+                setattr(self.prov, n, fn)
+        torch.cuda.synchronize()
+        self.stats = {}
+        for n, recs in self.records.items():
+            if recs:
+                ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+                by = sum(b for _, _, b in recs)
+                self.stats[n] = {"launches": len(recs), "total_ms": round(ms, 3), "avg_us": round(ms * 1e3 / len(recs), 2),
+                                 "algo_MB_per_launch": round(by / len(recs) / 1e6, 3),
+                                 "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+
+    def summary(self):
+        return self.stats
+
+    def roofline(self, peak_gbs, profiles_dir=None):
+        name = max(self.stats, key=lambda n: self.stats[n]["total_ms"])
+        st = self.stats[name]
+        traffic = None
+        if profiles_dir:
+            import json
+            import os
+            f = os.path.join(profiles_dir, "traffic.json")
+            if os.path.exists(f):
+                traffic = json.load(open(f)).get(name)
+        return {"bound": "hbm", "kernel": name, "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
+                "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic,
+                "algo_bytes_per_launch": int(st["algo_MB_per_launch"] * 1e6), "avg_launch_us": st["avg_us"]}

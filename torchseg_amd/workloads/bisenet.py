@@ -1,0 +1,109 @@
+"""BiSeNet (ResNet-18 context path) — the BASELINE.json metric model.
+
+Architecture of model/bisenet/cityscapes.bisenet.R18/network.py:18-168
+(BiSeNet :18-111, SpatialPath :114-137, BiSeNetHead :140-168), reproduced on
+top of the furnace surface so that bench.py / smoke() can run where the
+reference tree is absent.  Module attribute names and construction order match
+the reference file, hence state dicts are interchangeable and a fixed seed
+initialises both identically (tests/test_dropin_cpu.py checks both).
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ensure_furnace_on_path
+
+ensure_furnace_on_path()
+from base_model import resnet18  # noqa: E402
+from seg_opr.seg_oprs import AttentionRefinement, ConvBnRelu, FeatureFusion  # noqa: E402
+
+
+def _cbr(cin, cout, k, s, p, norm_layer, relu=True):
+    return ConvBnRelu(cin, cout, k, s, p, has_bn=True, norm_layer=norm_layer, has_relu=relu, has_bias=False)
+
+
+def _up(x, size=None, scale=None):
+    return F.interpolate(x, size=size, scale_factor=scale, mode='bilinear', align_corners=True)
+
+
+class SpatialPath(nn.Module):
+    """7x7/2 -> 3x3/2 -> 3x3/2 -> 1x1: 1/8-resolution detail branch (network.py:114-137)."""
+
+    def __init__(self, in_planes, out_planes, norm_layer=nn.BatchNorm2d):
+        super(SpatialPath, self).__init__()
+        mid = 64
+        self.conv_7x7 = _cbr(in_planes, mid, 7, 2, 3, norm_layer)
+        self.conv_3x3_1 = _cbr(mid, mid, 3, 2, 1, norm_layer)
+        self.conv_3x3_2 = _cbr(mid, mid, 3, 2, 1, norm_layer)
+        self.conv_1x1 = _cbr(mid, out_planes, 1, 1, 0, norm_layer)
+
+    def forward(self, x):
+        return self.conv_1x1(self.conv_3x3_2(self.conv_3x3_1(self.conv_7x7(x))))
+
+
+class BiSeNetHead(nn.Module):
+    """3x3 CBR -> 1x1 classifier -> bilinear x`scale` (network.py:140-168)."""
+
+    def __init__(self, in_planes, out_planes, scale, is_aux=False, norm_layer=nn.BatchNorm2d):
+        super(BiSeNetHead, self).__init__()
+        mid = 256 if is_aux else 64
+        self.conv_3x3 = _cbr(in_planes, mid, 3, 1, 1, norm_layer)
+        self.conv_1x1 = nn.Conv2d(mid, out_planes, kernel_size=1, stride=1, padding=0)
+        self.scale = scale
+
+    def forward(self, x):
+        out = self.conv_1x1(self.conv_3x3(x))
+        return _up(out, scale=self.scale) if self.scale > 1 else out
+
+
+class BiSeNet(nn.Module):
+    def __init__(self, out_planes, is_training, criterion, pretrained_model=None,
+                 norm_layer=nn.BatchNorm2d, bn_eps=1e-5, bn_momentum=0.1):
+        super(BiSeNet, self).__init__()
+        self.context_path = resnet18(pretrained_model, norm_layer=norm_layer, bn_eps=bn_eps,
+                                     bn_momentum=bn_momentum, deep_stem=False, stem_width=64)
+        self.business_layer = []
+        self.is_training = is_training
+        self.spatial_path = SpatialPath(3, 128, norm_layer)
+        ch = 128
+        self.global_context = nn.Sequential(nn.AdaptiveAvgPool2d(1), _cbr(512, ch, 1, 1, 0, norm_layer))
+        arms = [AttentionRefinement(512, ch, norm_layer), AttentionRefinement(256, ch, norm_layer)]
+        refines = [_cbr(ch, ch, 3, 1, 1, norm_layer), _cbr(ch, ch, 3, 1, 1, norm_layer)]
+        heads = [BiSeNetHead(ch, out_planes, 16, True, norm_layer),
+                 BiSeNetHead(ch, out_planes, 8, True, norm_layer),
+                 BiSeNetHead(ch * 2, out_planes, 8, False, norm_layer)]
+        self.ffm = FeatureFusion(ch * 2, ch * 2, 1, norm_layer)
+        self.arms = nn.ModuleList(arms)
+        self.refines = nn.ModuleList(refines)
+        self.heads = nn.ModuleList(heads)
+        self.business_layer += [self.spatial_path, self.global_context, self.arms, self.refines,
+                                self.heads, self.ffm]
+        if is_training:
+            self.criterion = criterion
+
+    def features(self, data):
+        """-> [1/16 aux fm, 1/8 aux fm, fused 1/8 fm] (network.py:75-101)."""
+        spatial_out = self.spatial_path(data)
+        c2, c3, c4, c5 = self.context_path(data)
+        last_fm = _up(self.global_context(c5), size=c5.shape[2:])
+        outs = []
+        for fm, nxt, arm, refine in zip((c5, c4), (c4, c3), self.arms, self.refines):
+            fm = arm(fm)
+            fm = fm + last_fm
+            last_fm = refine(_up(fm, size=nxt.shape[2:]))
+            outs.append(last_fm)
+        outs.append(self.ffm(spatial_out, last_fm))
+        return outs
+
+    def forward(self, data, label=None):
+        f16, f8, fused = self.features(data)
+        if self.is_training:
+            aux0 = self.criterion(self.heads[0](f16), label)
+            aux1 = self.criterion(self.heads[1](f8), label)
+            main = self.criterion(self.heads[-1](fused), label)
+            return main + aux0 + aux1                      # network.py:108
+        return F.log_softmax(self.heads[-1](fused), dim=1)  # network.py:111
+
+    def logits(self, data):
+        """The three full-resolution head outputs (parity checks)."""
+        f16, f8, fused = self.features(data)
+        return self.heads[0](f16), self.heads[1](f8), self.heads[-1](fused)
