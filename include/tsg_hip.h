@@ -70,59 +70,69 @@ int tsg_bn_stats(const void* x, int dtype, int layout,
 int tsg_bn_collapse(const float* partial, int S, int64_t C, float* sums,
                     void* stream);
 
+/* Per-channel constants are folded into two small device arrays so the
+ * streaming kernels touch 2-5 floats per channel:
+ *   fwd_pack fp[3][C] = { a = gamma*invstd, b = beta - mean*a, mean }
+ *   bwd_pack bp[5][C] = { a, b, mean, Bc = -a*k1*invstd, C2 = -a*k0 }
+ * with k0 = sum dy'/n, k1 = sum dy'*xhat/n (n = GLOBAL count).  Both must be
+ * 16-byte aligned. */
+
 /* From (partial or all-reduced) sums and the global element count per channel:
  *   mean = sum/n ; sumvar = sumsq - sum*mean ; invstd = (sumvar/n + eps)^-1/2
  *   running_mean = (1-m)*running_mean + m*mean
  *   running_var  = (1-m)*running_var  + m*sumvar/(n-1)      (syncbn.py:86-98)
- * running_* and num_batches_tracked may be NULL.  count is the GLOBAL n.
- * When count_dev != NULL the count is read from the device instead:
- * n = count_dev[0]*4096 + count_dev[1] (two fp32 words that stay exact under an
- * all-reduce SUM; lets ranks with unequal batches agree without a host sync). */
+ * gamma/beta (may be NULL = 1/0), running_* and num_batches_tracked may be NULL.
+ * count is the GLOBAL n.  When count_dev != NULL the count is read from the
+ * device instead: n = count_dev[0]*4096 + count_dev[1] (two fp32 words that stay
+ * exact under an all-reduce SUM; lets ranks with unequal batches agree without a
+ * host sync).  Writes mean[C], invstd[C] and fwd_pack[3][C]. */
 int tsg_bn_finalize(const float* partial, int S, int64_t C, double count,
                     const float* count_dev, float eps, float momentum,
+                    const float* gamma, const float* beta,
                     float* running_mean, float* running_var,
                     int64_t* num_batches_tracked,
-                    float* mean, float* invstd, void* stream);
+                    float* mean, float* invstd, float* fwd_pack, void* stream);
 
-/* y = relu?( gamma*(x-mean)*invstd + beta (+ residual) ).
+/* fwd_pack from given statistics (eval mode: running mean / rsqrt(var+eps)). */
+int tsg_bn_affine(const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, int64_t C, float* fwd_pack, void* stream);
+
+/* y = relu?( a*x + b (+ residual) )  ==  relu?(gamma*(x-mean)*invstd + beta (+ residual)).
  * Replaces BatchNorm_Forward_CUDA (syncbn_kernel.cu:73-89) fused with the
  * nn.ReLU / residual add that follow it (seg_oprs.py:39-46, resnet.py:33-53).
- * gamma/beta may be NULL (=1/0); residual may be NULL; y may alias x. */
+ * residual may be NULL; y may alias x. */
 int tsg_bn_apply_fwd(const void* x, const void* residual, void* y,
                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
-                     const float* mean, const float* invstd,
-                     const float* gamma, const float* beta, int relu,
-                     void* stream);
+                     const float* fwd_pack, int relu, void* stream);
 
 /* Backward reduction: with dy' = dy * [pre-activation > 0] when relu, else dy:
- *   partial[s][0][c] = sum dy' ; partial[s][1][c] = sum dy' * (x-mean)*invstd
+ *   partial[s][0][c] = sum dy' ; partial[s][1][c] = sum dy' * (x-mean)
  * (GradOp, syncbn_kernel.cu:12-23,108-113).  When relu != 0 the mask is taken
  * from y > 0 if y != NULL (needed when a residual was fused), otherwise it is
  * recomputed from x with the forward's exact affine map (saves one read). */
 int tsg_bn_bwd_reduce(const void* dy, const void* x, const void* y,
                       int dtype, int layout, int64_t N, int64_t C, int64_t HW,
-                      const float* mean, const float* invstd,
-                      const float* gamma, const float* beta, int relu,
+                      const float* fwd_pack, int relu,
                       float* partial, int* rows, void* stream);
 
-/* From the (all-reduced) partials: dgamma = sum dy' xhat, dbeta = sum dy'
- * (LOCAL sums are what the caller passes for dgamma/dbeta when it wants
- * per-rank parameter grads; DDP averages them later) and the per-channel
- * coefficients used by bwd_apply:  k[0][c] = sum dy'/n, k[1][c] = sum dy' xhat/n
- * with n the GLOBAL count.  dgamma/dbeta may be NULL. */
+/* From partials of the backward reduction:
+ *   dgamma = sum dy'(x-mean) * invstd, dbeta = sum dy'   (syncbn_kernel.cu:130,135;
+ *   pass the LOCAL sums: DDP averages parameter grads across ranks later), and/or
+ *   bwd_pack from the GLOBAL (all-reduced) sums and count.  batch_stats == 0
+ *   (eval mode) gives Bc = C2 = 0.  dgamma/dbeta/bwd_pack may each be NULL. */
 int tsg_bn_bwd_coeffs(const float* partial, int S, int64_t C, double count,
-                      const float* count_dev,
-                      float* dgamma, float* dbeta, float* k, void* stream);
+                      const float* count_dev, int batch_stats,
+                      const float* invstd, const float* fwd_pack,
+                      float* dgamma, float* dbeta, float* bwd_pack, void* stream);
 
-/* dx = gamma*invstd * (dy' - k0 - xhat*k1); optionally dres = dy' (gradient of
- * the fused residual input).  Composition of syncbn_kernel.cu:118-135 and
- * Sum_Square_Backward (160-174) as autograd chains them (functions.py:22-61). */
+/* dx = a*dy' + Bc*(x-mean) + C2  ==  gamma*invstd*(dy' - k0 - xhat*k1); optionally
+ * dres = dy' (gradient of the fused residual input).  Composition of
+ * syncbn_kernel.cu:118-135 and Sum_Square_Backward (160-174) as autograd chains
+ * them (functions.py:22-61). */
 int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y,
                      void* dx, void* dres,
                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
-                     const float* mean, const float* invstd,
-                     const float* gamma, const float* beta, const float* k,
-                     int relu, void* stream);
+                     const float* bwd_pack, int relu, void* stream);
 
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
@@ -205,6 +215,28 @@ int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype,
 int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes,
                              int64_t NC, int IH, int IW, int OH, int OW,
                              void* stream);
+
+/* ------------------------------------------------------------------------
+ * PSANet collect / distribute attention — replaces
+ *   torch.bmm(X, torch.softmax(A, dim=1))
+ * (model/psanet/ade.psanet.R101_v1c/network.py:125-126,135-136).
+ * X [B, Cx, K], A [B, K, N] (softmax over dim 1 = the K rows of each column),
+ * out [B, Cx, N]; lse [B, N] (fp32 log-sum-exp of every column, saved for the
+ * backward).  K, N, Cx must be multiples of 8 (3600 and 512 in PSANet).
+ * dtype TSG_BF16: bf16 MFMA; TSG_F32: the same MFMA kernels with bf16 hi/lo
+ * operand splitting (3 passes) to hold the 1e-4 fp32 parity bar.
+ * ---------------------------------------------------------------------- */
+size_t tsg_psa_ws_bytes(int dtype, int backward, int64_t B, int64_t Cx,
+                        int64_t K, int64_t N);
+int tsg_psa_fwd(const void* X, const void* A, void* out, float* lse,
+                int dtype, int64_t B, int64_t Cx, int64_t K, int64_t N,
+                void* ws, size_t ws_bytes, void* stream);
+/* dX [B, Cx, K], dA [B, K, N] from dout [B, Cx, N]:
+ *   dX = dout * P^T ; dA = P o (X^T dout - delta), delta_j = sum_c out*dout. */
+int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
+                const float* lse, void* dX, void* dA,
+                int dtype, int64_t B, int64_t Cx, int64_t K, int64_t N,
+                void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused SGD step over a flat parameter bucket (torch.optim.SGD semantics as

@@ -1,0 +1,94 @@
+"""GPU parity of the PSA attention MFMA kernels vs the torch-CPU oracle
+(= the reference's own softmax + bmm).  fp32: 1e-4 relative to the output scale
+(north_star); bf16: bf16 resolution."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import psa_ref
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 64, 72, 72), (1, 128, 200, 136), (2, 512, 256, 320), (1, 24, 8, 8)]
+
+
+def _inputs(B, Cx, K, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.relu(torch.randn(B, Cx, K, generator=g))       # post-ReLU features
+    # asymmetric, structured A so that a row/col swap cannot pass
+    A = torch.randn(B, K, N, generator=g) * 2 + torch.arange(K).view(1, K, 1) * 0.01 - torch.arange(N).view(1, 1, N) * 0.02
+    dout = torch.randn(B, Cx, N, generator=g)
+    return X, A, dout
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_psa_fp32(cuda, shape):
+    from torchseg_amd.psa import psa_attention
+    X, A, dout = _inputs(*shape, seed=1)
+    out_ref, dX_ref, dA_ref = psa_ref.psa_attention_with_grads(X, A, dout)
+    Xd, Ad = X.to(cuda).requires_grad_(True), A.to(cuda).requires_grad_(True)
+    out = psa_attention(Xd, Ad)
+    out.backward(dout.to(cuda))
+    for got, ref, name in ((out, out_ref, "out"), (Xd.grad, dX_ref, "dX"), (Ad.grad, dA_ref, "dA")):
+        scale = ref.abs().max().item()
+        err = (got.detach().cpu().double() - ref).abs().max().item()
+        assert err <= 1e-4 * scale, (name, err, scale)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_psa_bf16(cuda, shape):
+    from torchseg_amd.psa import psa_attention
+    X, A, dout = _inputs(*shape, seed=2)
+    X, A, dout = X.bfloat16(), A.bfloat16(), dout.bfloat16()
+    out_ref, dX_ref, dA_ref = psa_ref.psa_attention_with_grads(X.float(), A.float(), dout.float())
+    Xd, Ad = X.to(cuda).requires_grad_(True), A.to(cuda).requires_grad_(True)
+    out = psa_attention(Xd, Ad)
+    assert out.dtype == torch.bfloat16
+    out.backward(dout.to(cuda))
+    for got, ref, name in ((out, out_ref, "out"), (Xd.grad, dX_ref, "dX"), (Ad.grad, dA_ref, "dA")):
+        scale = ref.abs().max().item()
+        err = (got.detach().float().cpu().double() - ref).abs().max().item()
+        assert err <= 2e-2 * scale, (name, err, scale)
+
+
+def test_psa_full_size_matches_gpu_fp32_reference(cuda):
+    """PSANet's real size (Cx 512, 3600 x 3600), one sample: against torch's fp32
+    softmax+bmm on the same device (CPU fp64 at this size is too slow for the suite)
+    and a linearity property: psa(X1 + X2, A) == psa(X1, A) + psa(X2, A)."""
+    from torchseg_amd.psa import psa_attention
+    g = torch.Generator(device=cuda).manual_seed(3)
+    X = torch.relu(torch.randn(1, 512, 3600, generator=g, device=cuda))
+    X2 = torch.randn(1, 512, 3600, generator=g, device=cuda)
+    A = torch.randn(1, 3600, 3600, generator=g, device=cuda)
+    ref = torch.bmm(X, torch.softmax(A, dim=1))
+    out = psa_attention(X, A)
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    lin = psa_attention(X + X2, A) - psa_attention(X2, A)
+    assert (lin - out).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    outb = psa_attention(X.bfloat16(), A.bfloat16()).float()
+    refb = torch.bmm(X.bfloat16().float(), torch.softmax(A.bfloat16().float(), dim=1))
+    assert (outb - refb).abs().max().item() <= 2e-2 * refb.abs().max().item()
+
+
+def test_fuse_mode_intercepts_unchanged_call_pattern(cuda):
+    """The reference writes torch.bmm(x, torch.softmax(a, dim=1)); under FusePsaMode
+    that exact expression must run the fused kernel and stay differentiable."""
+    from torchseg_amd import kernels as K
+    from torchseg_amd.psa import FusePsaMode
+    kp = K.provider()
+    n = {"fwd": 0}
+    orig = kp.psa_fwd
+    kp.psa_fwd = lambda *a: (n.__setitem__("fwd", n["fwd"] + 1), orig(*a))[1]
+    try:
+        x = torch.randn(2, 64, 80, device=cuda, requires_grad=True)
+        a = torch.randn(2, 80, 80, device=cuda, requires_grad=True)
+        with FusePsaMode():
+            y = torch.bmm(x, torch.softmax(a, dim=1))
+            z = torch.softmax(a, dim=1).sum()          # non-bmm consumer: materialises
+        (y.sum() + z).backward()
+    finally:
+        kp.psa_fwd = orig
+    assert n["fwd"] == 1
+    ref = torch.bmm(x.detach(), torch.softmax(a.detach(), dim=1))
+    torch.testing.assert_close(y.detach(), ref, rtol=1e-4, atol=1e-5)
+    assert x.grad is not None and a.grad is not None

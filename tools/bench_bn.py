@@ -24,14 +24,14 @@ for dtype in (torch.bfloat16, torch.float32):
             nb = x.numel() * x.element_size()
             t_stats = timeit(lambda: kp.bn_stats(x, lay, N, C, HW))
             partial, S = kp.bn_stats(x, lay, N, C, HW)
-            mean, invstd = kp.bn_finalize(partial, S, C, N * HW, None, 1e-5, 0.1, None, None, None)
+            mean, invstd, fp = kp.bn_finalize(partial, S, C, N * HW, None, 1e-5, 0.1, g, b, None, None, None)
             y = torch.empty_like(x)
-            t_fwd = timeit(lambda: kp.bn_apply_fwd(x, None, lay, N, C, HW, mean, invstd, g, b, True, out=y))
-            t_red = timeit(lambda: kp.bn_bwd_reduce(dy, x, None, lay, N, C, HW, mean, invstd, g, b, True))
-            p2, S2 = kp.bn_bwd_reduce(dy, x, None, lay, N, C, HW, mean, invstd, g, b, True)
-            _, _, k = kp.bn_bwd_coeffs(p2, S2, C, N * HW, None, True, True)
-            t_bwd = timeit(lambda: kp.bn_bwd_apply(dy, x, None, lay, N, C, HW, mean, invstd, g, b, k, True, False))
-            t_fin = timeit(lambda: kp.bn_finalize(partial, S, C, N * HW, None, 1e-5, 0.1, None, None, None))
+            t_fwd = timeit(lambda: kp.bn_apply_fwd(x, None, lay, N, C, HW, fp, True, out=y))
+            t_red = timeit(lambda: kp.bn_bwd_reduce(dy, x, None, lay, N, C, HW, fp, True))
+            p2, S2 = kp.bn_bwd_reduce(dy, x, None, lay, N, C, HW, fp, True)
+            _, _, bp = kp.bn_bwd_coeffs(p2, S2, C, N * HW, None, True, invstd, fp, True, True)
+            t_bwd = timeit(lambda: kp.bn_bwd_apply(dy, x, None, lay, N, C, HW, bp, True, False))
+            t_fin = timeit(lambda: kp.bn_finalize(partial, S, C, N * HW, None, 1e-5, 0.1, g, b, None, None, None))
             print(f"{str(dtype).split('.')[-1]:8s} {'nhwc' if lay else 'nchw'} {shp}  S={S:4d} "
                   f"stats {nb/t_stats/1e9:7.0f} GB/s ({t_stats*1e6:6.1f}us)  fwd {2*nb/t_fwd/1e9:7.0f} GB/s ({t_fwd*1e6:6.1f}us)  "
                   f"bwd_red {2*nb/t_red/1e9:7.0f} GB/s ({t_red*1e6:6.1f}us)  bwd_apply {3*nb/t_bwd/1e9:7.0f} GB/s ({t_bwd*1e6:6.1f}us)  fin {t_fin*1e6:.1f}us",

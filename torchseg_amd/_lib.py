@@ -39,11 +39,12 @@ _PROTOS = {
     "tsg_bn_partial_ws_bytes": (_sz, [_i, _i64, _i64, _i64]),
     "tsg_bn_stats": (_i, [_p, _i, _i, _i64, _i64, _i64, _p, _ip, _p]),
     "tsg_bn_collapse": (_i, [_p, _i, _i64, _p, _p]),
-    "tsg_bn_finalize": (_i, [_p, _i, _i64, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
-    "tsg_bn_apply_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _p]),
-    "tsg_bn_bwd_reduce": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _p, _ip, _p]),
-    "tsg_bn_bwd_coeffs": (_i, [_p, _i, _i64, _d, _p, _p, _p, _p, _p]),
-    "tsg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i, _p]),
+    "tsg_bn_finalize": (_i, [_p, _i, _i64, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "tsg_bn_affine": (_i, [_p, _p, _p, _p, _i64, _p, _p]),
+    "tsg_bn_apply_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p]),
+    "tsg_bn_bwd_reduce": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p, _ip, _p]),
+    "tsg_bn_bwd_coeffs": (_i, [_p, _i, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "tsg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p]),
     "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),
     "tsg_ohem_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _f, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tsg_ohem_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
@@ -55,6 +56,9 @@ _PROTOS = {
     "tsg_upsample_bilinear_ac_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_upsample_bilinear_ac_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_upsample_nearest_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "tsg_psa_ws_bytes": (_sz, [_i, _i, _i64, _i64, _i64, _i64]),
+    "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_psa_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
 }
 

@@ -4,10 +4,14 @@
 // (furnace/legacy/sync_bn/syncbn.py:86-98, src/gpu/syncbn_kernel.cu:12-23,
 // 73-174) but none of its launch shape: the reference runs ONE block per
 // channel (<= C blocks, <= 512 threads, strided NCHW reads).  Here every pass
-// is a streaming kernel with 16-byte loads, >= ~2048 workgroups, fp32
-// per-lane accumulators, a fixed-order (deterministic) two-stage reduction
-// whose second stage runs in fp64, and BN+ReLU(+residual) fused so an
-// activation is read once and written once per pass.
+// is a streaming kernel with 16-byte loads, ~1-2k workgroups, fp32 per-lane
+// accumulators, a fixed-order (deterministic) two-stage reduction whose second
+// stage runs in fp64, and BN+ReLU(+residual) fused so an activation is read
+// once and written once per pass.  Per-channel constants are folded once into
+// small "packs" so the streaming kernels load 2-5 floats per channel:
+//   fwd pack  fp[3][C] = { a = gamma*invstd, b = beta - mean*a, mean }
+//   bwd pack  bp[5][C] = { a, b, mean, Bc = -a*k1*invstd, C2 = -a*k0 }
+//   y  = relu?(a*x + b (+res))                     dx = a*dy' + Bc*(x-mean) + C2
 //
 // All passes are HBM-bound: algorithmic bytes per element (s = element size)
 //   stats        1 read            = s
@@ -20,7 +24,8 @@ namespace tsg {
 
 constexpr int kThreads = 256;
 constexpr int kUnroll = 4;
-constexpr int kTargetBlocks = 2048;  // 8 per CU
+constexpr int kTargetBlocks = 2048;       // NCHW: 8 per CU
+constexpr int kTargetBlocksNhwc = 1024;   // NHWC: 4 per CU, more rows per block
 constexpr int kMaxSplit = 256;
 
 // ---- element packs: V elements per lane-access, unpacked to fp32 ----------
@@ -33,15 +38,18 @@ template <typename T> struct Pack<T, 1> {
   __device__ __forceinline__ void store(T* p) const { st1<T>(p, v[0]); }
 };
 
-// scale/shift of the affine map y = a*x + b for channel c; shared by forward
-// and the backward mask recompute so both see bit-identical pre-activations.
-__device__ __forceinline__ void bn_coef(const float* mean, const float* invstd,
-                                        const float* gamma, const float* beta,
-                                        int64_t c, float& a, float& b) {
-  const float g = gamma ? gamma[c] : 1.f;
-  const float be = beta ? beta[c] : 0.f;
-  a = g * invstd[c];
-  b = fmaf(-mean[c], a, be);
+// V consecutive per-channel floats starting at c0 (c0 % V == 0 => 16-B aligned)
+template <int V>
+__device__ __forceinline__ void ldc(const float* __restrict__ p, int64_t c0, float (&o)[V]) {
+  if (V == 1) {
+    o[0] = p[c0];
+  } else {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p + c0 + 4 * q);
+      o[4 * q + 0] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+    }
+  }
 }
 
 struct NchwGeom {
@@ -77,14 +85,13 @@ static NhwcGeom nhwc_geom(int64_t M, int64_t C, int V) {
   g.gt = (int)(G < kThreads ? G : kThreads);
   g.rows_per_iter = kThreads / g.gt;
   g.ytiles = ceil_div_i(G, g.gt);
-  int64_t min_rows = (int64_t)g.rows_per_iter * kUnroll;
-  int64_t s = ceil_div_i(kTargetBlocks, g.ytiles);
+  // at least two unrolled iterations per thread so the per-channel constants amortise
+  int64_t min_rows = (int64_t)g.rows_per_iter * kUnroll * 2;
+  int64_t s = ceil_div_i(kTargetBlocksNhwc, g.ytiles);
   int64_t max_s = (M + min_rows - 1) / min_rows;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
-  if (s > 4096) s = 4096;
   g.rows_per_block = (M + s - 1) / s;
-  // keep each block's row range a multiple of R so that lanes stay row-aligned
   g.rows_per_block = ((g.rows_per_block + g.rows_per_iter - 1) / g.rows_per_iter) * g.rows_per_iter;
   g.split = ceil_div_i(M, g.rows_per_block);
   return g;
@@ -104,21 +111,20 @@ static int pick_vec(int dtype, int layout, int64_t C, int64_t HW, const void* p0
 // =========================================================================
 // reductions (stats and bwd_reduce share one skeleton)
 //   MODE 0: (x)          -> sum x, sum x^2
-//   MODE 1: (dy, x)      -> sum dy', sum dy' * xhat   (MASK: 0 none, 1 y>0, 2 recompute)
+//   MODE 1: (dy, x)      -> sum dy', sum dy' * (x - mean)   (MASK: 0 none, 1 y>0, 2 recompute)
+// fp[0]=a, fp[1]=b, fp[2]=mean
 // =========================================================================
 template <typename T, int V, int MODE, int MASK>
 __global__ __launch_bounds__(kThreads) void bn_reduce_nchw(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
     int64_t N, int64_t C, int64_t HW, int seg, int segs, int S,
-    const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ partial) {
+    const float* __restrict__ fp, float* __restrict__ partial) {
   __shared__ float sm[2 * (kThreads / 64)];
   const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-  float mu = 0.f, is = 0.f, ca = 0.f, cb = 0.f;
+  float mu = 0.f, ca = 0.f, cb = 0.f;
   if (MODE == 1) {
-    mu = mean[c]; is = invstd[c];
-    if (MASK == 2) bn_coef(mean, invstd, gamma, beta, c, ca, cb);
+    mu = fp[2 * C + c];
+    if (MASK == 2) { ca = fp[c]; cb = fp[C + c]; }
   }
   float a1[V], a2[V];
 #pragma unroll
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nchw(
 #pragma unroll
           for (int j = 0; j < V; ++j) {
             a1[j] += pd.v[j];
-            a2[j] = fmaf(pd.v[j], (px.v[j] - mu) * is, a2[j]);
+            a2[j] = fmaf(pd.v[j], px.v[j] - mu, a2[j]);
           }
         }
       }
@@ -174,9 +180,7 @@ template <typename T, int V, int MODE, int MASK>
 __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
     int64_t M, int64_t C, int GT, int R, int64_t rows_per_block,
-    const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ partial) {
+    const float* __restrict__ fp, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][R][GT*V]
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
@@ -184,16 +188,13 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
   const int64_t g = (int64_t)blockIdx.y * GT + gl;
   const bool live = (r < R) && (g < G);
   const int64_t c0 = g * V;
-  float mu[V], is[V], ca[V], cb[V];
+  float mu[V], ca[V], cb[V];
   float a1[V], a2[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) { a1[j] = 0.f; a2[j] = 0.f; mu[j] = 0.f; is[j] = 0.f; ca[j] = 0.f; cb[j] = 0.f; }
+  for (int j = 0; j < V; ++j) { a1[j] = 0.f; a2[j] = 0.f; mu[j] = 0.f; ca[j] = 0.f; cb[j] = 0.f; }
   if (MODE == 1 && live) {
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
-      if (MASK == 2) bn_coef(mean, invstd, gamma, beta, c0 + j, ca[j], cb[j]);
-    }
+    ldc<V>(fp + 2 * C, c0, mu);
+    if (MASK == 2) { ldc<V>(fp, c0, ca); ldc<V>(fp + C, c0, cb); }
   }
   const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
 #pragma unroll
             for (int j = 0; j < V; ++j) {
               a1[j] += pd.v[j];
-              a2[j] = fmaf(pd.v[j], (px.v[j] - mu[j]) * is[j], a2[j]);
+              a2[j] = fmaf(pd.v[j], px.v[j] - mu[j], a2[j]);
             }
           }
         }
@@ -257,21 +258,16 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
 
 // =========================================================================
 // element-wise passes
-//   FWD:  y  = act(a*x + b (+res))
-//   BWD:  dx = a * (dy' - k0 - xhat*k1) ; dres = dy'
 // =========================================================================
 template <typename T, int V, bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void bn_fwd_nchw(
     const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-    int64_t C, int64_t HW, int seg, int segs,
-    const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta) {
+    int64_t C, int64_t HW, int seg, int segs, const float* __restrict__ fp) {
   const int64_t bid = blockIdx.x;
   const int64_t plane = bid / segs;
   const int sg = (int)(bid - plane * segs);
   const int64_t c = plane % C;
-  float a, b;
-  bn_coef(mean, invstd, gamma, beta, c, a, b);
+  const float a = fp[c], b = fp[C + c];
   const int64_t off = plane * HW + (int64_t)sg * seg;
   const int64_t rem = HW - (int64_t)sg * seg;
   const int len = rem < seg ? (int)rem : seg;
@@ -297,17 +293,15 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw(
 template <typename T, int V, bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
     const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block,
-    const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta) {
+    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ fp) {
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
   const int64_t g = (int64_t)blockIdx.y * GT + gl;
   if (r >= R || g >= C / V) return;
   const int64_t c0 = g * V;
   float a[V], b[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) bn_coef(mean, invstd, gamma, beta, c0 + j, a[j], b[j]);
+  ldc<V>(fp, c0, a);
+  ldc<V>(fp + C, c0, b);
   const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
@@ -333,22 +327,17 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
   }
 }
 
+// bp[0]=a, bp[1]=b, bp[2]=mean, bp[3]=Bc, bp[4]=C2 ; dx = a*dy' + Bc*(x-mean) + C2
 template <typename T, int V, int MASK, bool DRES>
 __global__ __launch_bounds__(kThreads) void bn_bwd_nchw(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
     T* __restrict__ dx, T* __restrict__ dres,
-    int64_t C, int64_t HW, int seg, int segs,
-    const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ kc) {
+    int64_t C, int64_t HW, int seg, int segs, const float* __restrict__ bp) {
   const int64_t bid = blockIdx.x;
   const int64_t plane = bid / segs;
   const int sg = (int)(bid - plane * segs);
   const int64_t c = plane % C;
-  float a, b;
-  bn_coef(mean, invstd, gamma, beta, c, a, b);
-  const float mu = mean[c], is = invstd[c];
-  const float k0 = kc[c], k1 = kc[C + c];
+  const float a = bp[c], b = bp[C + c], mu = bp[2 * C + c], bc = bp[3 * C + c], c2 = bp[4 * C + c];
   const int64_t off = plane * HW + (int64_t)sg * seg;
   const int64_t rem = HW - (int64_t)sg * seg;
   const int len = rem < seg ? (int)rem : seg;
@@ -370,10 +359,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw(
       }
       if (DRES) pd.store(dres + off + i);
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float xh = (px.v[j] - mu) * is;
-        px.v[j] = a * (pd.v[j] - k0 - xh * k1);
-      }
+      for (int j = 0; j < V; ++j) px.v[j] = fmaf(a, pd.v[j], fmaf(bc, px.v[j] - mu, c2));
       px.store(dx + off + i);
     }
   }
@@ -383,22 +369,20 @@ template <typename T, int V, int MASK, bool DRES>
 __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
     T* __restrict__ dx, T* __restrict__ dres,
-    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block,
-    const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ kc) {
+    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ bp) {
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
   const int64_t g = (int64_t)blockIdx.y * GT + gl;
   if (r >= R || g >= C / V) return;
   const int64_t c0 = g * V;
-  float a[V], b[V], mu[V], is[V], k0[V], k1[V];
+  float a[V], b[V], mu[V], bc[V], c2[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) {
-    bn_coef(mean, invstd, gamma, beta, c0 + j, a[j], b[j]);
-    mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
-    k0[j] = kc[c0 + j]; k1[j] = kc[C + c0 + j];
-  }
+  for (int j = 0; j < V; ++j) b[j] = 0.f;
+  ldc<V>(bp, c0, a);
+  if (MASK == 2) ldc<V>(bp + C, c0, b);
+  ldc<V>(bp + 2 * C, c0, mu);
+  ldc<V>(bp + 3 * C, c0, bc);
+  ldc<V>(bp + 4 * C, c0, c2);
   const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
@@ -422,10 +406,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
         }
         if (DRES) pd.store(dres + off);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float xh = (px.v[j] - mu[j]) * is[j];
-          px.v[j] = a[j] * (pd.v[j] - k0[j] - xh * k1[j]);
-        }
+        for (int j = 0; j < V; ++j) px.v[j] = fmaf(a[j], pd.v[j], fmaf(bc[j], px.v[j] - mu[j], c2[j]));
         px.store(dx + off);
       }
     }
@@ -433,19 +414,31 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
 }
 
 // =========================================================================
-// per-channel tail kernels (C threads, trivially small)
+// per-channel tail kernels: block = 32 channels x 8 slice-lanes, fp64, fixed order
 // =========================================================================
-__global__ void bn_collapse_k(const float* __restrict__ partial, int S, int64_t C,
-                              float* __restrict__ sums) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double t1 = 0.0, t2 = 0.0;
-  for (int s = 0; s < S; ++s) {
-    t1 += (double)partial[((int64_t)s * 2 + 0) * C + c];
-    t2 += (double)partial[((int64_t)s * 2 + 1) * C + c];
+constexpr int kTc = 32, kTs = 8;
+
+__device__ __forceinline__ void tail_sums(const float* __restrict__ partial, int S, int64_t C,
+                                          double& t1, double& t2, bool& owner, int64_t& c) {
+  __shared__ double sh[2][kTs][kTc];
+  const int tc = threadIdx.x % kTc, ts = threadIdx.x / kTc;
+  c = (int64_t)blockIdx.x * kTc + tc;
+  double p1 = 0.0, p2 = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int s = ts; s < S; s += kTs) {
+      p1 += (double)partial[((int64_t)s * 2 + 0) * C + c];
+      p2 += (double)partial[((int64_t)s * 2 + 1) * C + c];
+    }
   }
-  sums[c] = (float)t1;
-  sums[C + c] = (float)t2;
+  sh[0][ts][tc] = p1;
+  sh[1][ts][tc] = p2;
+  __syncthreads();
+  owner = (ts == 0) && (c < C);
+  t1 = 0.0; t2 = 0.0;
+  if (owner) {
+    for (int q = 0; q < kTs; ++q) { t1 += sh[0][q][tc]; t2 += sh[1][q][tc]; }
+  }
 }
 
 // global element count: host double, or (hi, lo) floats on the device with
@@ -454,65 +447,94 @@ __device__ __forceinline__ double bn_count(double count, const float* cd) {
   return cd ? (double)cd[0] * 4096.0 + (double)cd[1] : count;
 }
 
-__global__ void bn_finalize_k(const float* __restrict__ partial, int S, int64_t C,
-                              double count, const float* __restrict__ count_dev,
-                              float eps, float momentum,
-                              float* __restrict__ rmean, float* __restrict__ rvar,
-                              int64_t* __restrict__ nbt,
-                              float* __restrict__ mean, float* __restrict__ invstd) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double t1 = 0.0, t2 = 0.0;
-  for (int s = 0; s < S; ++s) {
-    t1 += (double)partial[((int64_t)s * 2 + 0) * C + c];
-    t2 += (double)partial[((int64_t)s * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(kTc * kTs) void bn_collapse_k(const float* __restrict__ partial, int S,
+                                                          int64_t C, float* __restrict__ sums) {
+  double t1, t2; bool owner; int64_t c;
+  tail_sums(partial, S, C, t1, t2, owner, c);
+  if (!owner) return;
+  sums[c] = (float)t1;
+  sums[C + c] = (float)t2;
+}
+
+__global__ __launch_bounds__(kTc * kTs) void bn_finalize_k(
+    const float* __restrict__ partial, int S, int64_t C, double count,
+    const float* __restrict__ count_dev, float eps, float momentum,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ fp) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double t1, t2; bool owner; int64_t c;
+  tail_sums(partial, S, C, t1, t2, owner, c);
+  if (!owner) return;
   count = bn_count(count, count_dev);
   const double m = t1 / count;
   double sumvar = t2 - t1 * m;          // syncbn.py:91
   if (sumvar < 0.0) sumvar = 0.0;
   const double bias_var = sumvar / count;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(bias_var + (double)eps));
+  const float mf = (float)m;
+  const float isf = (float)(1.0 / sqrt(bias_var + (double)eps));
+  mean[c] = mf;
+  invstd[c] = isf;
+  const float a = (gamma ? gamma[c] : 1.f) * isf;
+  fp[c] = a;
+  fp[C + c] = fmaf(-mf, a, beta ? beta[c] : 0.f);
+  fp[2 * C + c] = mf;
   if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
   if (rvar) {
-    const double unbias = sumvar / (count - 1.0);  // syncbn.py:92 (inf/nan when count==1, as the reference asserts)
+    const double unbias = sumvar / (count - 1.0);  // syncbn.py:92
     rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbias);
   }
 }
 
-__global__ void bn_bwd_coeffs_k(const float* __restrict__ partial, int S, int64_t C,
-                                double count, const float* __restrict__ count_dev,
-                                float* __restrict__ dgamma,
-                                float* __restrict__ dbeta, float* __restrict__ kc) {
+__global__ void bn_affine_k(const float* __restrict__ mean, const float* __restrict__ invstd,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, int64_t C,
+                            float* __restrict__ fp) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double t1 = 0.0, t2 = 0.0;
-  for (int s = 0; s < S; ++s) {
-    t1 += (double)partial[((int64_t)s * 2 + 0) * C + c];
-    t2 += (double)partial[((int64_t)s * 2 + 1) * C + c];
-  }
+  const float a = (gamma ? gamma[c] : 1.f) * invstd[c];
+  fp[c] = a;
+  fp[C + c] = fmaf(-mean[c], a, beta ? beta[c] : 0.f);
+  fp[2 * C + c] = mean[c];
+}
+
+__global__ __launch_bounds__(kTc * kTs) void bn_bwd_coeffs_k(
+    const float* __restrict__ partial, int S, int64_t C, double count,
+    const float* __restrict__ count_dev, int batch_stats, const float* __restrict__ invstd,
+    const float* __restrict__ fp, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ bp) {
+  double t1, t2; bool owner; int64_t c;
+  tail_sums(partial, S, C, t1, t2, owner, c);
+  if (!owner) return;
+  const double is = (double)invstd[c];
   if (dbeta) dbeta[c] = (float)t1;
-  if (dgamma) dgamma[c] = (float)t2;
-  if (kc) {
-    count = bn_count(count, count_dev);
-    kc[c] = (float)(t1 / count);
-    kc[C + c] = (float)(t2 / count);
+  if (dgamma) dgamma[c] = (float)(t2 * is);      // sum dy' * xhat   (syncbn_kernel.cu:130)
+  if (bp) {
+    const float a = fp[c];
+    float bc = 0.f, c2 = 0.f;
+    if (batch_stats) {
+      count = bn_count(count, count_dev);
+      const double k0 = t1 / count, k1 = t2 * is / count;
+      bc = (float)(-(double)a * k1 * is);
+      c2 = (float)(-(double)a * k0);
+    }
+    bp[c] = a;
+    bp[C + c] = fp[C + c];
+    bp[2 * C + c] = fp[2 * C + c];
+    bp[3 * C + c] = bc;
+    bp[4 * C + c] = c2;
   }
 }
 
 // ---- host-side dispatch helpers ------------------------------------------
 template <typename T, int V, int MODE>
 static int launch_reduce(const T* x, const T* dy, const T* y, int layout, int64_t N,
-                         int64_t C, int64_t HW, const float* mean, const float* invstd,
-                         const float* gamma, const float* beta, int mask,
+                         int64_t C, int64_t HW, const float* fp, int mask,
                          float* partial, hipStream_t st) {
   if (layout == TSG_NCHW) {
     NchwGeom g = nchw_geom(N, C, HW, V);
     dim3 grid((unsigned)C, (unsigned)g.split);
 #define L_(MK) hipLaunchKernelGGL((bn_reduce_nchw<T, V, MODE, MK>), grid, dim3(kThreads), 0, st, \
-      x, dy, y, N, C, HW, g.seg, g.segs, g.split, mean, invstd, gamma, beta, partial)
+      x, dy, y, N, C, HW, g.seg, g.segs, g.split, fp, partial)
     if (MODE == 0 || mask == 0) L_(0); else if (mask == 1) L_(1); else L_(2);
 #undef L_
   } else {
@@ -521,7 +543,7 @@ static int launch_reduce(const T* x, const T* dy, const T* y, int layout, int64_
     dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
     const size_t sh = (size_t)2 * g.rows_per_iter * g.gt * V * sizeof(float);
 #define L_(MK) hipLaunchKernelGGL((bn_reduce_nhwc<T, V, MODE, MK>), grid, dim3(kThreads), sh, st, \
-      x, dy, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, mean, invstd, gamma, beta, partial)
+      x, dy, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, fp, partial)
     if (MODE == 0 || mask == 0) L_(0); else if (mask == 1) L_(1); else L_(2);
 #undef L_
   }
@@ -531,15 +553,14 @@ static int launch_reduce(const T* x, const T* dy, const T* y, int layout, int64_
 
 template <typename T, int V>
 static int launch_fwd(const T* x, const T* res, T* y, int layout, int64_t N, int64_t C,
-                      int64_t HW, const float* mean, const float* invstd,
-                      const float* gamma, const float* beta, int relu, hipStream_t st) {
+                      int64_t HW, const float* fp, int relu, hipStream_t st) {
   const bool R_ = relu != 0, S_ = res != nullptr;
   if (layout == TSG_NCHW) {
     NchwGeom g = nchw_geom(N, C, HW, V);
     const int64_t blocks = N * C * g.segs;
     if (blocks > 0x7fffffffLL) return TSG_E_SHAPE;
 #define L_(A, B) hipLaunchKernelGGL((bn_fwd_nchw<T, V, A, B>), dim3((unsigned)blocks), dim3(kThreads), 0, st, \
-      x, res, y, C, HW, g.seg, g.segs, mean, invstd, gamma, beta)
+      x, res, y, C, HW, g.seg, g.segs, fp)
     if (R_ && S_) L_(true, true); else if (R_) L_(true, false); else if (S_) L_(false, true); else L_(false, false);
 #undef L_
   } else {
@@ -547,7 +568,7 @@ static int launch_fwd(const T* x, const T* res, T* y, int layout, int64_t N, int
     NhwcGeom g = nhwc_geom(M, C, V);
     dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
 #define L_(A, B) hipLaunchKernelGGL((bn_fwd_nhwc<T, V, A, B>), grid, dim3(kThreads), 0, st, \
-      x, res, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, mean, invstd, gamma, beta)
+      x, res, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, fp)
     if (R_ && S_) L_(true, true); else if (R_) L_(true, false); else if (S_) L_(false, true); else L_(false, false);
 #undef L_
   }
@@ -557,16 +578,14 @@ static int launch_fwd(const T* x, const T* res, T* y, int layout, int64_t N, int
 
 template <typename T, int V>
 static int launch_bwd(const T* dy, const T* x, const T* y, T* dx, T* dres, int layout,
-                      int64_t N, int64_t C, int64_t HW, const float* mean,
-                      const float* invstd, const float* gamma, const float* beta,
-                      const float* kc, int mask, hipStream_t st) {
+                      int64_t N, int64_t C, int64_t HW, const float* bp, int mask, hipStream_t st) {
   const bool D_ = dres != nullptr;
   if (layout == TSG_NCHW) {
     NchwGeom g = nchw_geom(N, C, HW, V);
     const int64_t blocks = N * C * g.segs;
     if (blocks > 0x7fffffffLL) return TSG_E_SHAPE;
 #define L_(MK, D) hipLaunchKernelGGL((bn_bwd_nchw<T, V, MK, D>), dim3((unsigned)blocks), dim3(kThreads), 0, st, \
-      dy, x, y, dx, dres, C, HW, g.seg, g.segs, mean, invstd, gamma, beta, kc)
+      dy, x, y, dx, dres, C, HW, g.seg, g.segs, bp)
     if (mask == 0) { if (D_) L_(0, true); else L_(0, false); }
     else if (mask == 1) { if (D_) L_(1, true); else L_(1, false); }
     else { if (D_) L_(2, true); else L_(2, false); }
@@ -576,7 +595,7 @@ static int launch_bwd(const T* dy, const T* x, const T* y, T* dx, T* dres, int l
     NhwcGeom g = nhwc_geom(M, C, V);
     dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
 #define L_(MK, D) hipLaunchKernelGGL((bn_bwd_nhwc<T, V, MK, D>), grid, dim3(kThreads), 0, st, \
-      dy, x, y, dx, dres, M, C, g.gt, g.rows_per_iter, g.rows_per_block, mean, invstd, gamma, beta, kc)
+      dy, x, y, dx, dres, M, C, g.gt, g.rows_per_iter, g.rows_per_block, bp)
     if (mask == 0) { if (D_) L_(0, true); else L_(0, false); }
     else if (mask == 1) { if (D_) L_(1, true); else L_(1, false); }
     else { if (D_) L_(2, true); else L_(2, false); }
@@ -593,6 +612,29 @@ static int check_dims(int dtype, int layout, int64_t N, int64_t C, int64_t HW) {
   return 0;
 }
 
+static int partial_rows(int layout, int64_t N, int64_t C, int64_t HW, int V) {
+  return layout == TSG_NCHW ? nchw_geom(N, C, HW, V).split : nhwc_geom(N * HW, C, V).split;
+}
+
+static int bn_reduce_dispatch(int mode, const void* x, const void* dy, const void* y,
+                              int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                              const float* fp, int mask, float* partial, void* stream, int* rows) {
+  int e = check_dims(dtype, layout, N, C, HW);
+  if (e) return e;
+  if (!x || !partial) return TSG_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const int V = pick_vec(dtype, layout, C, HW, x, dy, mask == 1 ? y : nullptr, nullptr, nullptr);
+  *rows = partial_rows(layout, N, C, HW, V);
+#define GO(T, VV)                                                                          \
+  (mode == 0 ? launch_reduce<T, VV, 0>((const T*)x, nullptr, nullptr, layout, N, C, HW,    \
+                                       fp, 0, partial, st)                                 \
+             : launch_reduce<T, VV, 1>((const T*)x, (const T*)dy, (const T*)y, layout, N,  \
+                                       C, HW, fp, mask, partial, st))
+  if (dtype == TSG_F32) return V == 4 ? GO(float, 4) : GO(float, 1);
+  return V == 8 ? GO(bf16_t, 8) : GO(bf16_t, 1);
+#undef GO
+}
+
 }  // namespace tsg
 
 using namespace tsg;
@@ -600,16 +642,16 @@ using namespace tsg;
 extern "C" {
 
 // The partial count must not depend on pointer alignment, so it is computed for
-// the scalar and the vector geometry and the larger one is reported.
+// the scalar and the vector geometries and the largest one is reported.
 int tsg_bn_num_partials(int layout, int64_t N, int64_t C, int64_t HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  if (layout != TSG_NCHW && layout != TSG_NHWC) return TSG_E_LAYOUT;
   int best = 1;
   const int vs[3] = {1, 4, 8};
   for (int i = 0; i < 3; ++i) {
     const int V = vs[i];
-    int s;
-    if (layout == TSG_NCHW) s = nchw_geom(N, C, HW, V).split;
-    else { if (C % V) continue; s = nhwc_geom(N * HW, C, V).split; }
+    if (layout == TSG_NHWC && C % V) continue;
+    const int s = partial_rows(layout, N, C, HW, V);
     if (s > best) best = s;
   }
   return best;
@@ -621,37 +663,11 @@ size_t tsg_bn_partial_ws_bytes(int layout, int64_t N, int64_t C, int64_t HW) {
   return (size_t)s * 2 * (size_t)C * sizeof(float);
 }
 
-static int partial_rows(int layout, int64_t N, int64_t C, int64_t HW, int V) {
-  return layout == TSG_NCHW ? nchw_geom(N, C, HW, V).split : nhwc_geom(N * HW, C, V).split;
-}
-
-// returns the number of partial rows actually written (>0) or an error (<0 / hipError)
-static int bn_reduce_dispatch(int mode, const void* x, const void* dy, const void* y,
-                              int dtype, int layout, int64_t N, int64_t C, int64_t HW,
-                              const float* mean, const float* invstd, const float* gamma,
-                              const float* beta, int mask, float* partial, void* stream,
-                              int* rows) {
-  int e = check_dims(dtype, layout, N, C, HW);
-  if (e) return e;
-  if (!x || !partial) return TSG_E_NULL;
-  hipStream_t st = (hipStream_t)stream;
-  const int V = pick_vec(dtype, layout, C, HW, x, dy, mask == 1 ? y : nullptr, nullptr, nullptr);
-  *rows = partial_rows(layout, N, C, HW, V);
-#define GO(T, VV)                                                                          \
-  (mode == 0 ? launch_reduce<T, VV, 0>((const T*)x, nullptr, nullptr, layout, N, C, HW,    \
-                                       mean, invstd, gamma, beta, 0, partial, st)          \
-             : launch_reduce<T, VV, 1>((const T*)x, (const T*)dy, (const T*)y, layout, N,  \
-                                       C, HW, mean, invstd, gamma, beta, mask, partial, st))
-  if (dtype == TSG_F32) return V == 4 ? GO(float, 4) : GO(float, 1);
-  return V == 8 ? GO(bf16_t, 8) : GO(bf16_t, 1);
-#undef GO
-}
-
 int tsg_bn_stats(const void* x, int dtype, int layout, int64_t N, int64_t C, int64_t HW,
                  float* partial, int* rows, void* stream) {
   int r = 0;
-  int e = bn_reduce_dispatch(0, x, nullptr, nullptr, dtype, layout, N, C, HW, nullptr,
-                             nullptr, nullptr, nullptr, 0, partial, stream, &r);
+  int e = bn_reduce_dispatch(0, x, nullptr, nullptr, dtype, layout, N, C, HW, nullptr, 0, partial,
+                             stream, &r);
   if (rows) *rows = r;
   return e;
 }
@@ -659,76 +675,85 @@ int tsg_bn_stats(const void* x, int dtype, int layout, int64_t N, int64_t C, int
 int tsg_bn_collapse(const float* partial, int S, int64_t C, float* sums, void* stream) {
   if (!partial || !sums) return TSG_E_NULL;
   if (S <= 0 || C <= 0) return TSG_E_SHAPE;
-  hipLaunchKernelGGL(bn_collapse_k, dim3(ceil_div_i(C, 128)), dim3(128), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_collapse_k, dim3(ceil_div_i(C, kTc)), dim3(kTc * kTs), 0, (hipStream_t)stream,
                      partial, S, C, sums);
   TSG_CHECK_LAUNCH();
   return 0;
 }
 
-int tsg_bn_finalize(const float* partial, int S, int64_t C, double count,
-                    const float* count_dev, float eps,
-                    float momentum, float* running_mean, float* running_var,
-                    int64_t* num_batches_tracked, float* mean, float* invstd, void* stream) {
-  if (!partial || !mean || !invstd) return TSG_E_NULL;
+int tsg_bn_finalize(const float* partial, int S, int64_t C, double count, const float* count_dev,
+                    float eps, float momentum, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* mean, float* invstd, float* fwd_pack, void* stream) {
+  if (!partial || !mean || !invstd || !fwd_pack) return TSG_E_NULL;
   if (S <= 0 || C <= 0 || (!count_dev && !(count > 0.0))) return TSG_E_SHAPE;
-  hipLaunchKernelGGL(bn_finalize_k, dim3(ceil_div_i(C, 128)), dim3(128), 0, (hipStream_t)stream,
-                     partial, S, C, count, count_dev, eps, momentum, running_mean, running_var,
-                     num_batches_tracked, mean, invstd);
+  hipLaunchKernelGGL(bn_finalize_k, dim3(ceil_div_i(C, kTc)), dim3(kTc * kTs), 0, (hipStream_t)stream,
+                     partial, S, C, count, count_dev, eps, momentum, gamma, beta, running_mean,
+                     running_var, num_batches_tracked, mean, invstd, fwd_pack);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_bn_affine(const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  int64_t C, float* fwd_pack, void* stream) {
+  if (!mean || !invstd || !fwd_pack) return TSG_E_NULL;
+  if (C <= 0) return TSG_E_SHAPE;
+  hipLaunchKernelGGL(bn_affine_k, dim3(ceil_div_i(C, 128)), dim3(128), 0, (hipStream_t)stream, mean,
+                     invstd, gamma, beta, C, fwd_pack);
   TSG_CHECK_LAUNCH();
   return 0;
 }
 
 int tsg_bn_apply_fwd(const void* x, const void* residual, void* y, int dtype, int layout,
-                     int64_t N, int64_t C, int64_t HW, const float* mean, const float* invstd,
-                     const float* gamma, const float* beta, int relu, void* stream) {
+                     int64_t N, int64_t C, int64_t HW, const float* fwd_pack, int relu,
+                     void* stream) {
   int e = check_dims(dtype, layout, N, C, HW);
   if (e) return e;
-  if (!x || !y || !mean || !invstd) return TSG_E_NULL;
+  if (!x || !y || !fwd_pack) return TSG_E_NULL;
+  if (!aligned16(fwd_pack)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int V = pick_vec(dtype, layout, C, HW, x, residual, y, nullptr, nullptr);
-#define GO(T, VV) launch_fwd<T, VV>((const T*)x, (const T*)residual, (T*)y, layout, N, C, HW, \
-                                    mean, invstd, gamma, beta, relu, st)
+#define GO(T, VV) launch_fwd<T, VV>((const T*)x, (const T*)residual, (T*)y, layout, N, C, HW, fwd_pack, relu, st)
   if (dtype == TSG_F32) return V == 4 ? GO(float, 4) : GO(float, 1);
   return V == 8 ? GO(bf16_t, 8) : GO(bf16_t, 1);
 #undef GO
 }
 
 int tsg_bn_bwd_reduce(const void* dy, const void* x, const void* y, int dtype, int layout,
-                      int64_t N, int64_t C, int64_t HW, const float* mean,
-                      const float* invstd, const float* gamma, const float* beta, int relu,
+                      int64_t N, int64_t C, int64_t HW, const float* fwd_pack, int relu,
                       float* partial, int* rows, void* stream) {
-  if (!dy || !mean || !invstd) return TSG_E_NULL;
+  if (!dy || !fwd_pack) return TSG_E_NULL;
+  if (!aligned16(fwd_pack)) return TSG_E_ALIGN;
   const int mask = relu ? (y ? 1 : 2) : 0;
   int r = 0;
-  int e = bn_reduce_dispatch(1, x, dy, y, dtype, layout, N, C, HW, mean, invstd, gamma, beta,
-                             mask, partial, stream, &r);
+  int e = bn_reduce_dispatch(1, x, dy, y, dtype, layout, N, C, HW, fwd_pack, mask, partial, stream, &r);
   if (rows) *rows = r;
   return e;
 }
 
-int tsg_bn_bwd_coeffs(const float* partial, int S, int64_t C, double count,
-                      const float* count_dev, float* dgamma,
-                      float* dbeta, float* k, void* stream) {
-  if (!partial) return TSG_E_NULL;
-  if (S <= 0 || C <= 0 || (k && !count_dev && !(count > 0.0))) return TSG_E_SHAPE;
-  hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3(ceil_div_i(C, 128)), dim3(128), 0, (hipStream_t)stream,
-                     partial, S, C, count, count_dev, dgamma, dbeta, k);
+int tsg_bn_bwd_coeffs(const float* partial, int S, int64_t C, double count, const float* count_dev,
+                      int batch_stats, const float* invstd, const float* fwd_pack, float* dgamma,
+                      float* dbeta, float* bwd_pack, void* stream) {
+  if (!partial || !invstd || (bwd_pack && !fwd_pack)) return TSG_E_NULL;
+  if (S <= 0 || C <= 0 || (bwd_pack && batch_stats && !count_dev && !(count > 0.0))) return TSG_E_SHAPE;
+  hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3(ceil_div_i(C, kTc)), dim3(kTc * kTs), 0, (hipStream_t)stream,
+                     partial, S, C, count, count_dev, batch_stats, invstd, fwd_pack, dgamma, dbeta, bwd_pack);
   TSG_CHECK_LAUNCH();
   return 0;
 }
 
 int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, void* dres,
                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
-                     const float* mean, const float* invstd, const float* gamma,
-                     const float* beta, const float* k, int relu, void* stream) {
+                     const float* bwd_pack, int relu, void* stream) {
   int e = check_dims(dtype, layout, N, C, HW);
   if (e) return e;
-  if (!dy || !x || !dx || !mean || !invstd || !k) return TSG_E_NULL;
+  if (!dy || !x || !dx || !bwd_pack) return TSG_E_NULL;
+  if (!aligned16(bwd_pack)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int mask = relu ? (y ? 1 : 2) : 0;
   const int V = pick_vec(dtype, layout, C, HW, x, dy, mask == 1 ? y : nullptr, dx, dres);
 #define GO(T, VV) launch_bwd<T, VV>((const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, \
-                                    layout, N, C, HW, mean, invstd, gamma, beta, k, mask, st)
+                                    layout, N, C, HW, bwd_pack, mask, st)
   if (dtype == TSG_F32) return V == 4 ? GO(float, 4) : GO(float, 1);
   return V == 8 ? GO(bf16_t, 8) : GO(bf16_t, 1);
 #undef GO

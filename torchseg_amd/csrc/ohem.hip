@@ -200,7 +200,9 @@ __global__ __launch_bounds__(kT) void ohem_pass_a(
         if (valid[j]) { cnt_le_valid++; sum_le += w * nl[j]; wsum_le += w; }
       } else if (bins0 > 0) {
         const int64_t d = (int64_t)__float_as_uint(pr) - tb - 1;
-        atomicAdd(&lh[(int)(d >> shift0)], 1u);
+        int bin = (int)(d >> shift0);
+        bin = bin < 0 ? 0 : (bin >= bins0 ? bins0 - 1 : bin);   // NaN logits must not index outside the histogram
+        atomicAdd(&lh[bin], 1u);
       }
     }
   }
@@ -320,7 +322,10 @@ __global__ __launch_bounds__(kT) void sel_refine(
     const float pr = XF ? prob_of_nll(v[i]) : v[i];
     if (pr > thresh) {
       const int64_t d = (int64_t)__float_as_uint(pr) - tb - 1;
-      if (d >= lo && d < hi) atomicAdd(&lh[(int)((d - lo) >> shift)], 1u);
+      if (d >= lo && d < hi) {
+        int bin = (int)((d - lo) >> shift);
+        if (bin < bins) atomicAdd(&lh[bin], 1u);
+      }
     }
   }
   __syncthreads();

@@ -1,0 +1,462 @@
+// PSANet collect / distribute attention for gfx950 — the one MFMA kernel.
+//
+// Restates  out = torch.bmm(X, torch.softmax(A, dim=1))
+// (model/psanet/ade.psanet.R101_v1c/network.py:125-126,135-136):
+//   X [B, Cx, K], A [B, K, N] (softmax over the K rows of every column j),
+//   out[b,c,j] = sum_i X[b,c,i] * P[b,i,j],  P = exp(A - lse_j).
+// The reference materialises the fp32 softmax (51.8 MB/sample/branch) and calls
+// a library bmm; backward runs softmax-backward plus two more GEMMs.  Here:
+//   colstat   one streaming read of A -> lse[b,j]                      (HBM-bound)
+//   prob      P (or P^T) in bf16 with the K index contiguous             (HBM-bound)
+//   gemm_nt   C[M,N] (+)= sum_k Aop[M,k] * Bop[N,k] on v_mfma_f32_32x32x16_bf16,
+//             128x128x64 block tiles, 4 waves x (64x64), LDS rows padded to
+//             144 B so ds_read_b128 fragment reads are conflict-free,
+//             register-prefetched double buffering                        (MFMA-bound)
+//   backward  dX = dOut * P^T (gemm_nt), delta_j = sum_c out*dOut,
+//             dA = P o (X^T dOut - delta_j) fused into the gemm epilogue.
+// fp32 inputs take the same kernels with bf16 hi/lo operand splitting
+// (a*b ~= ah*bh + ah*bl + al*bh, three accumulating passes, ~2^-16 relative),
+// which keeps the 1e-4 parity bar without an fp32 tensor-core path.
+#include "tsg_common.h"
+#include <math.h>
+
+namespace tsg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_ROW = 72;                 // bf16 elements per padded tile row (144 B)
+constexpr int GT = 256;                     // threads per gemm block (4 waves)
+
+// ---------------------------------------------------------------------------
+// column statistics of A [K, N]: lse[j] = log sum_i exp(A[i][j])
+// stage 1: block (jt, chunk, b): 256 columns x rows [chunk*RC, ...): running (m, l)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void psa_colstat1(const T* __restrict__ A, int64_t K, int64_t N,
+                                                    int rows_per_chunk, float* __restrict__ pm,
+                                                    float* __restrict__ pl) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y, nchunk = gridDim.y;
+  const int64_t b = blockIdx.z;
+  if (j >= N) return;
+  const T* a = A + b * K * N;
+  int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = r0 + rows_per_chunk;
+  if (r1 > K) r1 = K;
+  float m = -INFINITY, l = 0.f;
+  for (int64_t i = r0; i < r1; ++i) {
+    const float v = ld1<T>(a + i * N + j);
+    const float mn = fmaxf(m, v);
+    l = l * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+  }
+  pm[(b * nchunk + chunk) * N + j] = m;
+  pl[(b * nchunk + chunk) * N + j] = l;
+}
+
+__global__ __launch_bounds__(256) void psa_colstat2(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                    int nchunk, int64_t N, float* __restrict__ lse) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (j >= N) return;
+  float m = -INFINITY;
+  for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pm[(b * nchunk + c) * N + j]);
+  float l = 0.f;
+  for (int c = 0; c < nchunk; ++c) l += pl[(b * nchunk + c) * N + j] * __expf(pm[(b * nchunk + c) * N + j] - m);
+  lse[b * N + j] = m + logf(l);
+}
+
+__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16(v);
+  lo = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
+// P[i][j] = exp(A[i][j] - lse[j]) as bf16 (hi [+ lo]), same layout as A
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(256) void psa_prob(const T* __restrict__ A, const float* __restrict__ lse,
+                                                int64_t K, int64_t N, bf16_t* __restrict__ Phi,
+                                                bf16_t* __restrict__ Plo) {
+  const int64_t b = blockIdx.y;
+  const int64_t total = K * N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t j = e % N;
+    const float p = __expf(ld1<T>(A + b * total + e) - lse[b * N + j]);
+    bf16_t h, l;
+    split_bf16(p, h, l);
+    Phi[b * total + e] = h;
+    if (SPLIT) Plo[b * total + e] = l;
+  }
+}
+
+// generic tiled transpose with optional exp(. - lse[col]) : in [R, C] -> out [C, R] bf16 hi/lo
+// MODE 0: plain value; MODE 1: exp(v - lse[c])
+template <typename T, int MODE, bool SPLIT>
+__global__ __launch_bounds__(256) void psa_transpose(const T* __restrict__ in, const float* __restrict__ lse,
+                                                     int64_t R, int64_t Cn, bf16_t* __restrict__ ohi,
+                                                     bf16_t* __restrict__ olo) {
+  __shared__ float tile[64][65];
+  const int64_t b = blockIdx.z;
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const T* src = in + b * R * Cn;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int64_t r = r0 + rr, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < Cn) {
+      v = ld1<T>(src + r * Cn + c);
+      if (MODE == 1) v = __expf(v - lse[b * Cn + c]);
+    }
+    tile[rr][tx] = v;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int64_t c = c0 + cc, r = r0 + tx;
+    if (c < Cn && r < R) {
+      bf16_t h, l;
+      split_bf16(tile[tx][cc], h, l);
+      ohi[b * R * Cn + c * R + r] = h;
+      if (SPLIT) olo[b * R * Cn + c * R + r] = l;
+    }
+  }
+}
+
+// fp32 -> bf16 hi/lo, same layout
+__global__ __launch_bounds__(256) void psa_split_k(const float* __restrict__ in, int64_t n,
+                                                   bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    bf16_t h, l;
+    split_bf16(in[e], h, l);
+    hi[e] = h; lo[e] = l;
+  }
+}
+
+// delta[b][j] = sum_c out[b][c][j] * dout[b][c][j]
+template <typename T>
+__global__ __launch_bounds__(256) void psa_delta(const T* __restrict__ out, const T* __restrict__ dout,
+                                                 int64_t Cx, int64_t N, float* __restrict__ delta) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (j >= N) return;
+  float acc = 0.f;
+  for (int64_t c = 0; c < Cx; ++c)
+    acc += ld1<T>(out + (b * Cx + c) * N + j) * ld1<T>(dout + (b * Cx + c) * N + j);
+  delta[b * N + j] = acc;
+}
+
+// fp32 path: dA = exp(A - lse_j) * (dP - delta_j)
+__global__ __launch_bounds__(256) void psa_da_f32(const float* __restrict__ A, const float* __restrict__ lse,
+                                                  const float* __restrict__ dP, const float* __restrict__ delta,
+                                                  int64_t K, int64_t N, float* __restrict__ dA) {
+  const int64_t b = blockIdx.y;
+  const int64_t total = K * N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t j = e % N;
+    const float p = __expf(A[b * total + e] - lse[b * N + j]);
+    dA[b * total + e] = p * (dP[b * total + e] - delta[b * N + j]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C[M,N] (+)= Aop[M,K] * Bop[N,K]^T   (bf16 operands, K contiguous, fp32 accumulate)
+// EPI 0: store (ACC: read-modify-write of an fp32 C)      TO = float | bf16_t
+// EPI 1: C[m][n] = P[m][n] * (acc - delta[n])             (dA epilogue, P bf16 [M,N])
+// ---------------------------------------------------------------------------
+struct GemmArgs {
+  const bf16_t* A; const bf16_t* B; void* C;
+  int64_t M, N, K;
+  int64_t sA, sB, sC;          // batch strides (elements)
+  const bf16_t* P; const float* delta; int64_t sP, sD;
+  int accumulate;
+};
+
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <typename TO, int EPI>
+__global__ __launch_bounds__(GT) void gemm_nt_bf16(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // 2 stages x (A tile + B tile)
+  constexpr int TILE = BM * LDS_ROW;                             // elements per operand tile (BM == BN)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;                       // 2 x 2 waves, 64 x 64 each
+  const int64_t b = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const bf16_t* Ag = g.A + b * g.sA;
+  const bf16_t* Bg = g.B + b * g.sB;
+
+  // global -> register staging: each tile is 128 rows x 8 chunks of 16 B; 4 chunks per thread per operand
+  const int lrow = tid >> 3, lchk = tid & 7;                     // rows lrow + 32*q, q = 0..3
+  uint4 ra[4], rb[4];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = lrow + 32 * q;
+      const int64_t k = k0 + lchk * 8;
+      const bool kin = k < g.K;                                  // K % 8 == 0 (host check)
+      ra[q] = (kin && m0 + r < g.M) ? ld16(Ag + (m0 + r) * g.K + k) : make_uint4(0, 0, 0, 0);
+      rb[q] = (kin && n0 + r < g.N) ? ld16(Bg + (n0 + r) * g.K + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int stage) {
+    bf16_t* sa = lds + (size_t)stage * 2 * TILE;
+    bf16_t* sb = sa + TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = lrow + 32 * q;
+      *reinterpret_cast<uint4*>(sa + r * LDS_ROW + lchk * 8) = ra[q];
+      *reinterpret_cast<uint4*>(sb + r * LDS_ROW + lchk * 8) = rb[q];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (int)((g.K + BK - 1) / BK);
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) fetch((int64_t)(kt + 1) * BK);             // in flight during the MFMAs below
+    const bf16_t* sa = lds + (size_t)cur * 2 * TILE + (wm * 64) * LDS_ROW;
+    const bf16_t* sb = lds + (size_t)cur * 2 * TILE + TILE + (wn * 64) * LDS_ROW;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int kof = ks * 16 + (lane >> 5) * 8;
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8*>(sa + (i * 32 + (lane & 31)) * LDS_ROW + kof);
+        fb[i] = *reinterpret_cast<const bf16x8*>(sb + (i * 32 + (lane & 31)) * LDS_ROW + kof);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  TO* Cg = reinterpret_cast<TO*>(g.C) + b * g.sC;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
+      float dl = 0.f;
+      if (EPI == 1 && n < g.N) dl = g.delta[b * g.sD + n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M && n < g.N) {
+          float v = acc[i][j][r];
+          if (EPI == 1) v = bf16_to_f32(g.P[b * g.sP + m * g.N + n]) * (v - dl);
+          if (EPI == 0 && g.accumulate) v += ld1<TO>(Cg + m * g.N + n);
+          st1<TO>(Cg + m * g.N + n, v);
+        }
+      }
+    }
+}
+
+template <typename TO, int EPI>
+static int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t st) {
+  if (g.K % 8 != 0) return TSG_E_SHAPE;
+  if (!aligned16(g.A) || !aligned16(g.B)) return TSG_E_ALIGN;
+  dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)batch);
+  const size_t sh = (size_t)2 * 2 * BM * LDS_ROW * sizeof(bf16_t);   // 73,728 B (> the 64 KiB default cap)
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16<TO, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  hipLaunchKernelGGL((gemm_nt_bf16<TO, EPI>), grid, dim3(GT), sh, st, g);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+static size_t au(size_t v) { return (v + 255) / 256 * 256; }
+
+struct PsaWs {
+  // common
+  float* pm; float* pl; float* lse_tmp;
+  bf16_t* P_hi; bf16_t* P_lo;        // [B, K, N] or transposed [B, N, K]
+  bf16_t* X_hi; bf16_t* X_lo;        // fp32 path fwd: split X; bwd: X^T (hi/lo)
+  bf16_t* D_hi; bf16_t* D_lo;        // bwd: dOut (split) and dOut^T
+  bf16_t* Dt_hi; bf16_t* Dt_lo;
+  float* delta;
+  float* dP;                         // fp32 path bwd: [B, K, N]
+  size_t total;
+};
+
+constexpr int kChunks = 30;
+
+static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, bool f32, bool bwd) {
+  PsaWs w;
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* q = p + off; off += au(bytes); return q; };
+  w.pm = (float*)take((size_t)B * kChunks * N * 4);
+  w.pl = (float*)take((size_t)B * kChunks * N * 4);
+  w.lse_tmp = (float*)take((size_t)B * N * 4);
+  w.P_hi = (bf16_t*)take((size_t)B * K * N * 2);
+  w.P_lo = f32 ? (bf16_t*)take((size_t)B * K * N * 2) : nullptr;
+  w.X_hi = (bf16_t*)take((size_t)B * Cx * K * 2);
+  w.X_lo = f32 ? (bf16_t*)take((size_t)B * Cx * K * 2) : nullptr;
+  w.D_hi = w.D_lo = w.Dt_hi = w.Dt_lo = nullptr; w.delta = nullptr; w.dP = nullptr;
+  if (bwd) {
+    w.D_hi = (bf16_t*)take((size_t)B * Cx * N * 2);
+    w.D_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
+    w.Dt_hi = (bf16_t*)take((size_t)B * Cx * N * 2);
+    w.Dt_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
+    w.delta = (float*)take((size_t)B * N * 4);
+    w.dP = f32 ? (float*)take((size_t)B * K * N * 4) : nullptr;
+  }
+  w.total = off;
+  return w;
+}
+
+static int egrid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <typename T>
+static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float* lse, hipStream_t st) {
+  const int rpc = (int)((K + kChunks - 1) / kChunks);
+  hipLaunchKernelGGL((psa_colstat1<T>), dim3((unsigned)((N + 255) / 256), kChunks, (unsigned)B), dim3(256), 0, st,
+                     A, K, N, rpc, w.pm, w.pl);
+  TSG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(psa_colstat2, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st, w.pm, w.pl,
+                     kChunks, N, lse);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" {
+
+size_t tsg_psa_ws_bytes(int dtype, int backward, int64_t B, int64_t Cx, int64_t K, int64_t N) {
+  if (B <= 0 || Cx <= 0 || K <= 0 || N <= 0) return 0;
+  return psa_carve(nullptr, B, Cx, K, N, dtype == TSG_F32, backward != 0).total;
+}
+
+int tsg_psa_fwd(const void* X, const void* A, void* out, float* lse, int dtype, int64_t B, int64_t Cx,
+                int64_t K, int64_t N, void* ws, size_t ws_bytes, void* stream) {
+  if (!X || !A || !out || !lse || !ws) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (B <= 0 || Cx <= 0 || K <= 0 || N <= 0 || K % 8 != 0) return TSG_E_SHAPE;
+  const bool f32 = dtype == TSG_F32;
+  if (ws_bytes < tsg_psa_ws_bytes(dtype, 0, B, Cx, K, N)) return TSG_E_WS;
+  if (!aligned16(ws) || !aligned16(X)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  PsaWs w = psa_carve(ws, B, Cx, K, N, f32, false);
+  int e;
+  dim3 tgrid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
+  GemmArgs g = {};
+  g.M = Cx; g.N = N; g.K = K; g.sA = Cx * K; g.sB = N * K; g.sC = Cx * N; g.C = out;
+  if (f32) {
+    if ((e = colstat<float>((const float*)A, B, K, N, w, lse, st))) return e;
+    // P^T [N, K] hi/lo and X hi/lo
+    hipLaunchKernelGGL((psa_transpose<float, 1, true>), tgrid, dim3(256), 0, st, (const float*)A, lse, K, N,
+                       w.P_hi, w.P_lo);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(psa_split_k, dim3(egrid(B * Cx * K)), dim3(256), 0, st, (const float*)X, B * Cx * K,
+                       w.X_hi, w.X_lo);
+    TSG_CHECK_LAUNCH();
+    g.A = w.X_hi; g.B = w.P_hi; g.accumulate = 0;
+    if ((e = launch_gemm<float, 0>(g, B, st))) return e;
+    g.accumulate = 1;
+    g.A = w.X_hi; g.B = w.P_lo;
+    if ((e = launch_gemm<float, 0>(g, B, st))) return e;
+    g.A = w.X_lo; g.B = w.P_hi;
+    if ((e = launch_gemm<float, 0>(g, B, st))) return e;
+  } else {
+    if ((e = colstat<bf16_t>((const bf16_t*)A, B, K, N, w, lse, st))) return e;
+    hipLaunchKernelGGL((psa_transpose<bf16_t, 1, false>), tgrid, dim3(256), 0, st, (const bf16_t*)A, lse, K, N,
+                       w.P_hi, (bf16_t*)nullptr);
+    TSG_CHECK_LAUNCH();
+    g.A = (const bf16_t*)X; g.B = w.P_hi; g.accumulate = 0;
+    if ((e = launch_gemm<bf16_t, 0>(g, B, st))) return e;
+  }
+  return 0;
+}
+
+int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout, const float* lse,
+                void* dX, void* dA, int dtype, int64_t B, int64_t Cx, int64_t K, int64_t N, void* ws,
+                size_t ws_bytes, void* stream) {
+  if (!X || !A || !out || !dout || !lse || !dX || !dA || !ws) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (B <= 0 || Cx <= 0 || K <= 0 || N <= 0 || K % 8 != 0 || N % 8 != 0 || Cx % 8 != 0) return TSG_E_SHAPE;
+  const bool f32 = dtype == TSG_F32;
+  if (ws_bytes < tsg_psa_ws_bytes(dtype, 1, B, Cx, K, N)) return TSG_E_WS;
+  if (!aligned16(ws) || !aligned16(dout)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  PsaWs w = psa_carve(ws, B, Cx, K, N, f32, true);
+  int e;
+  dim3 pgrid((unsigned)egrid(K * N), (unsigned)B);
+  dim3 xgrid((unsigned)((K + 63) / 64), (unsigned)((Cx + 63) / 64), (unsigned)B);   // X [Cx, K] -> [K, Cx]
+  dim3 dgrid((unsigned)((N + 63) / 64), (unsigned)((Cx + 63) / 64), (unsigned)B);   // dOut [Cx, N] -> [N, Cx]
+  dim3 jgrid((unsigned)((N + 255) / 256), (unsigned)B);
+  GemmArgs gx = {};   // dX[c][i] = sum_j dOut[c][j] * P[i][j]
+  gx.M = Cx; gx.N = K; gx.K = N; gx.sA = Cx * N; gx.sB = K * N; gx.sC = Cx * K; gx.C = dX;
+  GemmArgs ga = {};   // dP[i][j] = sum_c Xt[i][c] * dOt[j][c]
+  ga.M = K; ga.N = N; ga.K = Cx; ga.sA = K * Cx; ga.sB = N * Cx; ga.sC = K * N;
+  if (f32) {
+    hipLaunchKernelGGL((psa_prob<float, true>), pgrid, dim3(256), 0, st, (const float*)A, lse, K, N, w.P_hi, w.P_lo);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((psa_delta<float>), jgrid, dim3(256), 0, st, (const float*)out, (const float*)dout, Cx, N, w.delta);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(psa_split_k, dim3(egrid(B * Cx * N)), dim3(256), 0, st, (const float*)dout, B * Cx * N, w.D_hi, w.D_lo);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((psa_transpose<float, 0, true>), xgrid, dim3(256), 0, st, (const float*)X, (const float*)nullptr,
+                       Cx, K, w.X_hi, w.X_lo);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((psa_transpose<float, 0, true>), dgrid, dim3(256), 0, st, (const float*)dout,
+                       (const float*)nullptr, Cx, N, w.Dt_hi, w.Dt_lo);
+    TSG_CHECK_LAUNCH();
+    gx.A = w.D_hi; gx.B = w.P_hi; gx.accumulate = 0;
+    if ((e = launch_gemm<float, 0>(gx, B, st))) return e;
+    gx.accumulate = 1;
+    gx.A = w.D_hi; gx.B = w.P_lo;
+    if ((e = launch_gemm<float, 0>(gx, B, st))) return e;
+    gx.A = w.D_lo; gx.B = w.P_hi;
+    if ((e = launch_gemm<float, 0>(gx, B, st))) return e;
+    ga.C = w.dP;
+    ga.A = w.X_hi; ga.B = w.Dt_hi; ga.accumulate = 0;
+    if ((e = launch_gemm<float, 0>(ga, B, st))) return e;
+    ga.accumulate = 1;
+    ga.A = w.X_hi; ga.B = w.Dt_lo;
+    if ((e = launch_gemm<float, 0>(ga, B, st))) return e;
+    ga.A = w.X_lo; ga.B = w.Dt_hi;
+    if ((e = launch_gemm<float, 0>(ga, B, st))) return e;
+    hipLaunchKernelGGL(psa_da_f32, pgrid, dim3(256), 0, st, (const float*)A, lse, w.dP, w.delta, K, N, (float*)dA);
+    TSG_CHECK_LAUNCH();
+  } else {
+    hipLaunchKernelGGL((psa_prob<bf16_t, false>), pgrid, dim3(256), 0, st, (const bf16_t*)A, lse, K, N, w.P_hi,
+                       (bf16_t*)nullptr);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((psa_delta<bf16_t>), jgrid, dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((psa_transpose<bf16_t, 0, false>), xgrid, dim3(256), 0, st, (const bf16_t*)X,
+                       (const float*)nullptr, Cx, K, w.X_hi, (bf16_t*)nullptr);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((psa_transpose<bf16_t, 0, false>), dgrid, dim3(256), 0, st, (const bf16_t*)dout,
+                       (const float*)nullptr, Cx, N, w.Dt_hi, (bf16_t*)nullptr);
+    TSG_CHECK_LAUNCH();
+    gx.A = (const bf16_t*)dout; gx.B = w.P_hi; gx.accumulate = 0;
+    if ((e = launch_gemm<bf16_t, 0>(gx, B, st))) return e;
+    ga.C = dA; ga.A = w.X_hi; ga.B = w.Dt_hi; ga.P = w.P_hi; ga.delta = w.delta; ga.sP = K * N; ga.sD = N;
+    if ((e = launch_gemm<bf16_t, 1>(ga, B, st))) return e;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@ enters bf16 autocast (BASELINE config 2; the reference has no AMP), keeps the
 model in channels_last where MIOpen is faster on MI355X, and installs the aten
 upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_DTYPE=bf16|fp32   (default bf16 on GPU)    TSG_CHANNELS_LAST=1|0 (default 1 on GPU)
+  TSG_FUSE_PSA=1|0      (default: on when the model has a PointwiseSpatialAttention block)
 """
 import os
 
@@ -222,9 +223,12 @@ class DistributedDataParallel(nn.Module):
         self.channels_last = bool(channels_last)
         if self.channels_last:
             apply_channels_last(self.module)
+        self.fuse_psa = False
         if self.on_gpu:
             from .upsample import install_aten_overrides
             install_aten_overrides()
+            from .psa import model_has_psa
+            self.fuse_psa = _env_flag("TSG_FUSE_PSA", model_has_psa(module))
 
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None
@@ -235,7 +239,11 @@ class DistributedDataParallel(nn.Module):
                                    gradient_average, gradient_predivide_factor)
 
     def forward(self, *inputs, **kwargs):
-        if self.on_gpu and self.compute_dtype != torch.float32:
-            with torch.autocast("cuda", dtype=self.compute_dtype):
-                return self.module(*inputs, **kwargs)
-        return self.module(*inputs, **kwargs)
+        import contextlib
+        with contextlib.ExitStack() as stack:
+            if self.on_gpu and self.compute_dtype != torch.float32:
+                stack.enter_context(torch.autocast("cuda", dtype=self.compute_dtype))
+            if self.fuse_psa:
+                from .psa import FusePsaMode
+                stack.enter_context(FusePsaMode())
+            return self.module(*inputs, **kwargs)

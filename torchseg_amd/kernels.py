@@ -65,53 +65,64 @@ class HipKernels:
         L.check(self.lib.tsg_bn_collapse(partial.data_ptr(), S, Cc, out.data_ptr(),
                                          L.stream_ptr(partial)), "tsg_bn_collapse")
 
-    def bn_finalize(self, partial, S, Cc, count, count_dev, eps, momentum,
+    def bn_finalize(self, partial, S, Cc, count, count_dev, eps, momentum, gamma, beta,
                     running_mean, running_var, nbt):
-        mean = torch.empty(Cc, dtype=torch.float32, device=partial.device)
-        invstd = torch.empty(Cc, dtype=torch.float32, device=partial.device)
+        """-> (mean[C], invstd[C], fwd_pack[3,C])"""
+        dev = partial.device
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+        fp = torch.empty((3, Cc), dtype=torch.float32, device=dev)
         L.check(self.lib.tsg_bn_finalize(partial.data_ptr(), S, Cc, float(count), L.ptr(count_dev),
-                                         eps, momentum, L.ptr(running_mean), L.ptr(running_var),
-                                         L.ptr(nbt), mean.data_ptr(), invstd.data_ptr(),
-                                         L.stream_ptr(partial)), "tsg_bn_finalize")
-        return mean, invstd
+                                         eps, momentum, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                                         L.ptr(running_var), L.ptr(nbt), mean.data_ptr(),
+                                         invstd.data_ptr(), fp.data_ptr(), L.stream_ptr(partial)),
+                "tsg_bn_finalize")
+        return mean, invstd, fp
 
-    def bn_apply_fwd(self, x, residual, layout, N, Cc, HW, mean, invstd, gamma, beta, relu, out=None):
+    def bn_affine(self, mean, invstd, gamma, beta):
+        Cc = mean.numel()
+        fp = torch.empty((3, Cc), dtype=torch.float32, device=mean.device)
+        L.check(self.lib.tsg_bn_affine(mean.data_ptr(), invstd.data_ptr(), L.ptr(gamma), L.ptr(beta), Cc,
+                                       fp.data_ptr(), L.stream_ptr(mean)), "tsg_bn_affine")
+        return fp
+
+    def bn_apply_fwd(self, x, residual, layout, N, Cc, HW, fp, relu, out=None):
         y = torch.empty_like(x) if out is None else out
         L.check(self.lib.tsg_bn_apply_fwd(x.data_ptr(), L.ptr(residual), y.data_ptr(),
-                                          L.dtype_code(x), layout, N, Cc, HW, mean.data_ptr(),
-                                          invstd.data_ptr(), L.ptr(gamma), L.ptr(beta),
+                                          L.dtype_code(x), layout, N, Cc, HW, fp.data_ptr(),
                                           int(relu), L.stream_ptr(x)), "tsg_bn_apply_fwd")
         return y
 
-    def bn_bwd_reduce(self, dy, x, y, layout, N, Cc, HW, mean, invstd, gamma, beta, relu):
+    def bn_bwd_reduce(self, dy, x, y, layout, N, Cc, HW, fp, relu):
+        """-> (partial fp32 [S,2,C] = {sum dy', sum dy'(x-mean)}, S)"""
         lib = self.lib
         smax = lib.tsg_bn_num_partials(layout, N, Cc, HW)
         partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
         rows = C.c_int(0)
         L.check(lib.tsg_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), L.ptr(y), L.dtype_code(x),
-                                      layout, N, Cc, HW, mean.data_ptr(), invstd.data_ptr(),
-                                      L.ptr(gamma), L.ptr(beta), int(relu), partial.data_ptr(),
+                                      layout, N, Cc, HW, fp.data_ptr(), int(relu), partial.data_ptr(),
                                       C.byref(rows), L.stream_ptr(x)), "tsg_bn_bwd_reduce")
         return partial, rows.value
 
-    def bn_bwd_coeffs(self, partial, S, Cc, count, count_dev, want_param_grads, want_k):
+    def bn_bwd_coeffs(self, partial, S, Cc, count, count_dev, batch_stats, invstd, fp,
+                      want_param_grads, want_pack):
+        """-> (dgamma, dbeta, bwd_pack[5,C]) (None where not requested)"""
         dev = partial.device
         dgamma = torch.empty(Cc, dtype=torch.float32, device=dev) if want_param_grads else None
         dbeta = torch.empty(Cc, dtype=torch.float32, device=dev) if want_param_grads else None
-        k = torch.empty((2, Cc), dtype=torch.float32, device=dev) if want_k else None
+        bp = torch.empty((5, Cc), dtype=torch.float32, device=dev) if want_pack else None
         L.check(self.lib.tsg_bn_bwd_coeffs(partial.data_ptr(), S, Cc, float(count), L.ptr(count_dev),
-                                           L.ptr(dgamma), L.ptr(dbeta), L.ptr(k),
-                                           L.stream_ptr(partial)), "tsg_bn_bwd_coeffs")
-        return dgamma, dbeta, k
+                                           int(batch_stats), invstd.data_ptr(), L.ptr(fp), L.ptr(dgamma),
+                                           L.ptr(dbeta), L.ptr(bp), L.stream_ptr(partial)),
+                "tsg_bn_bwd_coeffs")
+        return dgamma, dbeta, bp
 
-    def bn_bwd_apply(self, dy, x, y, layout, N, Cc, HW, mean, invstd, gamma, beta, k, relu, want_dres):
+    def bn_bwd_apply(self, dy, x, y, layout, N, Cc, HW, bp, relu, want_dres):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         L.check(self.lib.tsg_bn_bwd_apply(dy.data_ptr(), x.data_ptr(), L.ptr(y), dx.data_ptr(),
                                           L.ptr(dres), L.dtype_code(x), layout, N, Cc, HW,
-                                          mean.data_ptr(), invstd.data_ptr(), L.ptr(gamma),
-                                          L.ptr(beta), k.data_ptr(), int(relu),
-                                          L.stream_ptr(x)), "tsg_bn_bwd_apply")
+                                          bp.data_ptr(), int(relu), L.stream_ptr(x)), "tsg_bn_bwd_apply")
         return dx, dres
 
     # ---- OHEM / focal / upsample ------------------------------------------
@@ -201,6 +212,39 @@ class HipKernels:
         return y
 
 
+    # ---- PSA attention -------------------------------------------------------
+    def psa_fwd(self, X, A):
+        """X [B,Cx,K], A [B,K,N] contiguous, same dtype -> (out [B,Cx,N], lse fp32 [B,N])"""
+        B, Cx, Kd = X.shape
+        N = A.shape[2]
+        dt = L.dtype_code(X)
+        wsb = self.lib.tsg_psa_ws_bytes(dt, 0, B, Cx, Kd, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=X.device)
+        out = torch.empty((B, Cx, N), dtype=X.dtype, device=X.device)
+        lse = torch.empty((B, N), dtype=torch.float32, device=X.device)
+        L.check(self.lib.tsg_psa_fwd(X.data_ptr(), A.data_ptr(), out.data_ptr(), lse.data_ptr(), dt, B, Cx,
+                                     Kd, N, ws.data_ptr(), wsb, L.stream_ptr(X)), "tsg_psa_fwd")
+        return out, lse
+
+    def psa_bwd(self, X, A, out, dout, lse):
+        B, Cx, Kd = X.shape
+        N = A.shape[2]
+        dt = L.dtype_code(X)
+        wsb = self.lib.tsg_psa_ws_bytes(dt, 1, B, Cx, Kd, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=X.device)
+        dX = torch.empty_like(X)
+        dA = torch.empty_like(A)
+        L.check(self.lib.tsg_psa_bwd(X.data_ptr(), A.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                     lse.data_ptr(), dX.data_ptr(), dA.data_ptr(), dt, B, Cx, Kd, N,
+                                     ws.data_ptr(), wsb, L.stream_ptr(X)), "tsg_psa_bwd")
+        return dX, dA
+
+    def sgd_step(self, param, grad, buf, lr, momentum, weight_decay, grad_scale, first):
+        L.check(self.lib.tsg_sgd_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(),
+                                      float(lr), float(momentum), float(weight_decay), float(grad_scale),
+                                      int(first), L.stream_ptr(param)), "tsg_sgd_step")
+
+
 _provider = None
 
 
@@ -230,7 +274,7 @@ _ALGO_BYTES = {
     "bn_stats": lambda a, r: _nbytes(a[0]),
     "bn_apply_fwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]),
     "bn_bwd_reduce": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[2]),
-    "bn_bwd_apply": lambda a, r: 3 * _nbytes(a[0]) + _nbytes(a[2]) + (_nbytes(a[0]) if a[13] else 0),
+    "bn_bwd_apply": lambda a, r: 3 * _nbytes(a[0]) + _nbytes(a[2]) + (_nbytes(a[0]) if a[9] else 0),
     "ohem_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "ohem_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "upsample_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),

@@ -6,7 +6,7 @@ mean, biased var for normalisation, unbiased var for the running estimate) and
 syncbn_kernel.cu:92-138,160-174 for the backward.  Exchange steps (one per
 direction, as §8(e) of SURVEY.md lists):
   forward : all-reduce(SUM) of [sum x | sum x^2 | count_hi | count_lo]  (2C+2 fp32)
-  backward: all-reduce(SUM) of [sum dy' | sum dy' xhat]                 (2C fp32)
+  backward: all-reduce(SUM) of [sum dy' | sum dy' (x - mean)]           (2C fp32)
 With world_size 1 both collectives are skipped.
 
 Extension over the reference surface (used by our furnace/seg_opr and
@@ -72,6 +72,8 @@ class _SyncBNFn(torch.autograd.Function):
         world = _world(group) if use_batch_stats else 1
         count_dev = None
         n_local = N * HW
+        gamma = weight.float() if weight is not None else None
+        beta = bias.float() if bias is not None else None
         if use_batch_stats:
             if world == 1 and n_local <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size {}"
@@ -87,39 +89,39 @@ class _SyncBNFn(torch.autograd.Function):
                 msg[2 * C:].copy_(_count_words(n_local, x.device))
                 dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
                 count_dev = msg[2 * C:]
-                mean, invstd = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum, rm, rv, nbt)
+                mean, invstd, fp = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum,
+                                                  gamma, beta, rm, rv, nbt)
             else:
-                mean, invstd = kp.bn_finalize(partial, S, C, float(n_local), None, float(mod.eps),
-                                              momentum, rm, rv, nbt)
+                mean, invstd, fp = kp.bn_finalize(partial, S, C, float(n_local), None, float(mod.eps),
+                                                  momentum, gamma, beta, rm, rv, nbt)
         else:
             mean = mod.running_mean.float()
             invstd = torch.rsqrt(mod.running_var.float() + mod.eps)
-        y = kp.bn_apply_fwd(x, residual, layout, N, C, HW, mean, invstd, weight, bias, relu)
+            fp = kp.bn_affine(mean, invstd, gamma, beta)
+        y = kp.bn_apply_fwd(x, residual, layout, N, C, HW, fp, relu)
         need_y = relu and residual is not None
-        ctx.save_for_backward(x, y if need_y else None, weight, bias, mean, invstd, count_dev)
+        ctx.save_for_backward(x, y if need_y else None, weight, bias, invstd, fp, count_dev)
         ctx.cfg = (layout, N, C, HW, relu, use_batch_stats, group, world, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         kp = K.provider()
-        x, y, weight, bias, mean, invstd, count_dev = ctx.saved_tensors
+        x, y, weight, bias, invstd, fp, count_dev = ctx.saved_tensors
         layout, N, C, HW, relu, use_batch_stats, group, world, has_res = ctx.cfg
         dy = _like(dy, x)
-        partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, mean, invstd, weight, bias, relu)
+        partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, fp, relu)
         want_pg = weight is not None
-        if not use_batch_stats:
-            dgamma, dbeta, _ = kp.bn_bwd_coeffs(partial, S, C, 1.0, None, True, False)
-            k = torch.zeros((2, C), dtype=torch.float32, device=x.device)
-        elif world > 1:
+        if use_batch_stats and world > 1:
             sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
             kp.bn_collapse(partial, S, C, sums)
-            dgamma, dbeta, _ = kp.bn_bwd_coeffs(sums, 1, C, 1.0, None, True, False)
+            dgamma, dbeta, _ = kp.bn_bwd_coeffs(sums, 1, C, 1.0, None, True, invstd, fp, True, False)
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-            _, _, k = kp.bn_bwd_coeffs(sums, 1, C, 0.0, count_dev, False, True)
+            _, _, bp = kp.bn_bwd_coeffs(sums, 1, C, 0.0, count_dev, True, invstd, fp, False, True)
         else:
-            dgamma, dbeta, k = kp.bn_bwd_coeffs(partial, S, C, float(N * HW), None, True, True)
-        dx, dres = kp.bn_bwd_apply(dy, x, y, layout, N, C, HW, mean, invstd, weight, bias, k, relu, has_res)
+            dgamma, dbeta, bp = kp.bn_bwd_coeffs(partial, S, C, float(N * HW), None, use_batch_stats,
+                                                 invstd, fp, True, True)
+        dx, dres = kp.bn_bwd_apply(dy, x, y, layout, N, C, HW, bp, relu, has_res)
         if not want_pg:
             dgamma = dbeta = None
         else:
