@@ -134,6 +134,38 @@ int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y,
                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
                      const float* bwd_pack, int relu, void* stream);
 
+/* Mixed-layout passes for conv stems: x (conv output) / dx are NCHW [N, C, HW]
+ * while y / dy are NHWC [N*HW, C]; a [C x 64-pixel] tile is transposed through
+ * LDS inside the BN pass, so no separate layout-conversion copy is needed
+ * between a C_in=3 stem (fastest in NCHW under MIOpen) and the NHWC network.
+ * Supported when C % 8 == 0, C <= 128 and HW % (16 / elem_size) == 0; the ReLU
+ * mask is recomputed from x (no fused residual). */
+int tsg_bn_mixed_supported(int dtype, int64_t C, int64_t HW);
+int tsg_bn_mixed_num_partials(int64_t N, int64_t C, int64_t HW);
+int tsg_bn_apply_fwd_mixed(const void* x_nchw, void* y_nhwc, int dtype,
+                           int64_t N, int64_t C, int64_t HW,
+                           const float* fwd_pack, int relu, void* stream);
+int tsg_bn_bwd_reduce_mixed(const void* dy_nhwc, const void* x_nchw, int dtype,
+                            int64_t N, int64_t C, int64_t HW,
+                            const float* fwd_pack, int relu,
+                            float* partial, int* rows, void* stream);
+int tsg_bn_bwd_apply_mixed(const void* dy_nhwc, const void* x_nchw, void* dx_nchw,
+                           int dtype, int64_t N, int64_t C, int64_t HW,
+                           const float* bwd_pack, int relu, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Global average pooling [N,C,H,W] -> [N,C] — replaces nn.AdaptiveAvgPool2d(1)
+ * inside AttentionRefinement / FeatureFusion (furnace/seg_opr/seg_oprs.py:200,
+ * 224) and GlobalAvgPool2d (seg_oprs.py:97-107).  x is [N, C, HW] (TSG_NCHW)
+ * or [N, HW, C] (TSG_NHWC); out / dout are [N, C] in the activation dtype.
+ * ---------------------------------------------------------------------- */
+size_t tsg_gap_ws_bytes(int layout, int64_t N, int64_t C, int64_t HW);
+int tsg_gap_fwd(const void* x, void* out, int dtype, int layout,
+                int64_t N, int64_t C, int64_t HW,
+                void* ws, size_t ws_bytes, void* stream);
+int tsg_gap_bwd(const void* dout, void* dx, int dtype, int layout,
+                int64_t N, int64_t C, int64_t HW, void* stream);
+
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
  * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.
@@ -211,6 +243,14 @@ int tsg_upsample_bilinear_ac_fwd(const void* x, const void* add, void* y,
 int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype,
                                  int64_t NC, int IH, int IW, int OH, int OW,
                                  void* stream);
+/* channels_last variants for feature maps: x [N, IH, IW, C] -> y [N, OH, OW, C],
+ * C % (16 / elem_size) == 0 (a thread owns one 16-byte channel vector). */
+int tsg_upsample_bilinear_ac_nhwc_fwd(const void* x, const void* add, void* y,
+                                      int dtype, int64_t N, int C, int IH, int IW,
+                                      int OH, int OW, void* stream);
+int tsg_upsample_bilinear_ac_nhwc_bwd(const void* dy, void* dx, int dtype,
+                                      int64_t N, int C, int IH, int IW,
+                                      int OH, int OW, void* stream);
 /* nearest (floor(dst*in/out)) variant used for label maps. */
 int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes,
                              int64_t NC, int IH, int IW, int OH, int OW,

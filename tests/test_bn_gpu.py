@@ -101,3 +101,40 @@ def test_bn_eval_and_errors(cuda):
         bn(torch.randn(1, 16, 1, 1, device=cuda))
     with pytest.raises(Exception):
         bn(torch.randn(4, 16, 3, 3))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (3, 64, 40, 24), (2, 128, 16, 16), (2, 8, 8, 12), (4, 64, 128, 128)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_mixed_layout_stem(cuda, shape, dtype, relu):
+    """NCHW conv output -> BN(+ReLU) -> channels_last output (and NHWC dy -> NCHW dx)
+    must equal the plain NCHW path bit-for-bit in fp32 and the oracle within tolerance."""
+    from torchseg_amd import syncbn
+    from torchseg_amd.syncbn import SyncBatchNorm
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(shape, generator=g) * 1.3 + 0.2).to(dtype)
+    dy = torch.randn(shape, generator=g).to(dtype)
+    outs = []
+    for prefer in (False, True):
+        syncbn.PREFER_CHANNELS_LAST_OUTPUT = prefer
+        try:
+            bn = SyncBatchNorm(C).to(cuda)
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            xd = x.to(cuda).requires_grad_(True)
+            y = bn(xd, relu=relu)
+            y.backward(dy.to(cuda).contiguous(memory_format=torch.channels_last if prefer else torch.contiguous_format))
+            outs.append((y.detach().float().cpu(), xd.grad.float().cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(),
+                         y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous()))
+        finally:
+            syncbn.PREFER_CHANNELS_LAST_OUTPUT = False
+    (y0, dx0, dg0, db0, cl0), (y1, dx1, dg1, db1, cl1) = outs
+    assert cl1 and not cl0
+    assert xd.grad.is_contiguous()
+    torch.testing.assert_close(y1, y0, rtol=0, atol=0)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dx1, dx0, **tol)
+    n = N * H * W
+    torch.testing.assert_close(dg1, dg0, rtol=1e-4, atol=1e-4 * n ** 0.5)
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-4 * n ** 0.5)

@@ -110,8 +110,11 @@ def test_ohem_vs_oracle_fp32(cuda, case):
     assert dev["branch"] == info["branch"], (dev, info["branch"])
     assert abs(loss - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
     kept = (grad.abs().sum(1) > 0).numpy()
-    mp = info["mask_prob"].view(B, H, W).numpy()
-    near = np.abs(mp - info["threshold"]) <= 4e-7 * max(info["threshold"], 1e-30)  # within ~2 ulp of the threshold
+    if info["mask_prob"] is None:      # min_kept > num_valid: no selection happened (loss_opr.py:78-79)
+        near = np.zeros((B, H, W), dtype=bool)
+    else:
+        mp = info["mask_prob"].view(B, H, W).numpy()
+        near = np.abs(mp - info["threshold"]) <= 4e-7 * max(info["threshold"], 1e-30)  # within ~2 ulp of the threshold
     np.testing.assert_array_equal(kept[~near], info["kept"].numpy()[~near])
     assert abs(dev["n_kept"] - info["n_kept"]) <= int(near.sum())
     if dev["branch"] == 1:   # threshold is the k-th value: equal up to softmax rounding

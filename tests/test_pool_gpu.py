@@ -1,0 +1,28 @@
+"""GPU parity: global average pool kernels (both layouts, fwd + bwd) vs torch CPU mean."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 7, 5), (4, 128, 32, 32), (16, 256, 128, 128), (3, 19, 9, 9), (2, 4096, 3, 3),
+                                   (2, 512, 1, 1)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_global_avg_pool(cuda, shape, layout, dtype):
+    from torchseg_amd.pool import GlobalAvgPool
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(shape, generator=g).to(dtype)
+    dy = torch.randn(shape[0], shape[1], 1, 1, generator=g).to(dtype)
+    fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+    xd = x.to(cuda).contiguous(memory_format=fmt).requires_grad_(True)
+    y = GlobalAvgPool(1)(xd)
+    assert y.shape == (shape[0], shape[1], 1, 1)
+    y.backward(dy.to(cuda))
+    xr = x.double().requires_grad_(True)
+    yr = xr.mean((2, 3), keepdim=True)
+    yr.backward(dy.double())
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
+    assert xd.grad.stride() == xd.stride()

@@ -97,3 +97,26 @@ def test_aten_override_used_by_interpolate(cuda):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         yb = F.interpolate(x.bfloat16(), size=(20, 20), mode="bilinear", align_corners=True)
     assert yb.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("c,ih,iw,oh,ow", [(128, 1, 1, 32, 32), (128, 32, 32, 64, 64), (128, 64, 64, 128, 128),
+                                           (8, 7, 5, 13, 9), (16, 9, 9, 4, 3), (256, 6, 6, 60, 60)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bilinear_channels_last(cuda, c, ih, iw, oh, ow, dtype):
+    from torchseg_amd.upsample import upsample_bilinear_ac
+    g = torch.Generator().manual_seed(c + oh)
+    x = torch.randn(2, c, ih, iw, generator=g).to(dtype)
+    dy = torch.randn(2, c, oh, ow, generator=g).to(dtype)
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = upsample_bilinear_ac(xd, size=(oh, ow))
+    if ih * iw > 1:
+        assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy.to(cuda).contiguous(memory_format=torch.channels_last))
+    y_ref = R.upsample_bilinear_ac(x.float().numpy(), oh, ow)
+    dx_ref = R.upsample_bilinear_ac_backward(dy.float().numpy(), ih, iw)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), dx_ref, rtol=1e-4, atol=1e-4 * max(1.0, oh / ih))
+    else:
+        np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref, rtol=8e-3, atol=8e-3)
+        np.testing.assert_allclose(xd.grad.float().cpu().numpy(), dx_ref, rtol=1e-2, atol=1e-2 * np.abs(dx_ref).max())

@@ -45,9 +45,17 @@ _PROTOS = {
     "tsg_bn_bwd_reduce": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p, _ip, _p]),
     "tsg_bn_bwd_coeffs": (_i, [_p, _i, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p]),
     "tsg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p]),
+    "tsg_bn_mixed_supported": (_i, [_i, _i64, _i64]),
+    "tsg_bn_mixed_num_partials": (_i, [_i64, _i64, _i64]),
+    "tsg_bn_apply_fwd_mixed": (_i, [_p, _p, _i, _i64, _i64, _i64, _p, _i, _p]),
+    "tsg_bn_bwd_reduce_mixed": (_i, [_p, _p, _i, _i64, _i64, _i64, _p, _i, _p, _ip, _p]),
+    "tsg_bn_bwd_apply_mixed": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _p, _i, _p]),
+    "tsg_gap_ws_bytes": (_sz, [_i, _i64, _i64, _i64]),
+    "tsg_gap_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_gap_bwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),
     "tsg_ohem_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _f, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
-    "tsg_ohem_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "tsg_ohem_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tsg_kth_ws_bytes": (_sz, [_i64]),
     "tsg_kth_value": (_i, [_p, _i64, _i64, _p, _p, _sz, _p]),
     "tsg_focal_ws_bytes": (_sz, [_i64]),
@@ -55,6 +63,8 @@ _PROTOS = {
     "tsg_focal_bwd": (_i, [_p, _i, _p, _i, _i64, _i64, _f, _f, _p, _p, _p]),
     "tsg_upsample_bilinear_ac_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_upsample_bilinear_ac_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "tsg_upsample_bilinear_ac_nhwc_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
+    "tsg_upsample_bilinear_ac_nhwc_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
     "tsg_upsample_nearest_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_psa_ws_bytes": (_sz, [_i, _i, _i64, _i64, _i64, _i64]),
     "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),

@@ -414,6 +414,163 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
 }
 
 // =========================================================================
+// mixed-layout passes for conv stems: x (the conv output) is NCHW because MIOpen's
+// NHWC kernels lose badly at C_in = 3, while everything downstream is NHWC.
+// These kernels read/write x-side tensors as [N, C, HW] and y-side tensors
+// (y, dy) as [N*HW, C], transposing a [C x TP] tile through LDS, so no separate
+// layout-conversion copy (a ~0.6 TB/s strided copy in eager PyTorch) is needed.
+// Block = one image n, TP = 64 consecutive pixels, all C channels (C % 8 == 0, C <= 128).
+// =========================================================================
+constexpr int kTP = 64;
+
+template <typename T, bool RELU>
+__global__ __launch_bounds__(kThreads) void bn_fwd_mixed(
+    const T* __restrict__ x, T* __restrict__ y, int64_t C, int64_t HW, int tiles_per_img,
+    const float* __restrict__ fp) {
+  constexpr int V = Pack<T, (sizeof(T) == 2 ? 8 : 4)>::N;
+  extern __shared__ __attribute__((aligned(16))) float tile[];     // [kTP][C + 1]
+  const int ldt = (int)C + 1;
+  const int64_t n = blockIdx.x / tiles_per_img;
+  const int64_t p0 = (int64_t)(blockIdx.x % tiles_per_img) * kTP;
+  const int npx = (HW - p0) < kTP ? (int)(HW - p0) : kTP;
+  const int tid = threadIdx.x;
+  // phase 1: NCHW rows -> LDS[p][c]
+  const int vpr = kTP / V;                       // vectors per channel row
+  for (int it = tid; it < (int)C * vpr; it += kThreads) {
+    const int c = it / vpr, v = it - c * vpr;
+    const int p = v * V;
+    if (p < npx) {
+      Pack<T, V> px;
+      px.load(x + (n * C + c) * HW + p0 + p);   // HW % V == 0 (host check) => full vector in range
+      const float a = fp[c], b = fp[C + c];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float t = fmaf(px.v[j], a, b);
+        if (RELU) t = t > 0.f ? t : 0.f;
+        tile[(p + j) * ldt + c] = t;
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: LDS[p][c-vector] -> NHWC
+  const int gpr = (int)C / V;                    // channel groups per pixel
+  for (int it = tid; it < npx * gpr; it += kThreads) {
+    const int p = it / gpr, g = it - p * gpr;
+    Pack<T, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = tile[p * ldt + g * V + j];
+    o.store(y + ((n * HW + p0 + p) * C) + g * V);
+  }
+}
+
+// Backward reduction: dy is NHWC, x is NCHW; the ReLU mask is recomputed from x
+// (stems have no fused residual).  A block walks tiles blockIdx.x, +gridDim.x, ...
+// keeping per-(channel, pixel-vector) sums in registers, then folds them once.
+constexpr int kMixedItems = 8;   // >= C * (kTP / V) / kThreads for C <= 128
+
+template <typename T, bool RELU>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_mixed(
+    const T* __restrict__ dy, const T* __restrict__ x, int64_t C, int64_t HW, int tiles_per_img,
+    int64_t total_tiles, const float* __restrict__ pk, float* __restrict__ partial) {
+  constexpr int V = Pack<T, (sizeof(T) == 2 ? 8 : 4)>::N;
+  extern __shared__ __attribute__((aligned(16))) float tile[];     // [kTP][C + 1] + [2][C][vpr]
+  const int ldt = (int)C + 1;
+  const int tid = threadIdx.x;
+  const int gpr = (int)C / V, vpr = kTP / V;
+  const int items = (int)C * vpr;
+  float s1[kMixedItems], s2[kMixedItems];
+#pragma unroll
+  for (int k = 0; k < kMixedItems; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  for (int64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    const int64_t n = t / tiles_per_img;
+    const int64_t p0 = (t % tiles_per_img) * kTP;
+    const int npx = (HW - p0) < kTP ? (int)(HW - p0) : kTP;
+    __syncthreads();                                            // previous tile fully consumed
+    for (int it = tid; it < npx * gpr; it += kThreads) {
+      const int p = it / gpr, g = it - p * gpr;
+      Pack<T, V> pd;
+      pd.load(dy + ((n * HW + p0 + p) * C) + g * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) tile[p * ldt + g * V + j] = pd.v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kMixedItems; ++k) {
+      const int it = tid + k * kThreads;
+      if (it < items) {
+        const int c = it / vpr, v = it - c * vpr;
+        const int p = v * V;
+        if (p < npx) {
+          Pack<T, V> px;
+          px.load(x + (n * C + c) * HW + p0 + p);
+          const float a = pk[c], b = pk[C + c], mu = pk[2 * C + c];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            float d = tile[(p + j) * ldt + c];
+            if (RELU) d = fmaf(px.v[j], a, b) > 0.f ? d : 0.f;
+            s1[k] += d;
+            s2[k] = fmaf(d, px.v[j] - mu, s2[k]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* red = tile;                                            // reuse: [2][C][vpr]
+#pragma unroll
+  for (int k = 0; k < kMixedItems; ++k) {
+    const int it = tid + k * kThreads;
+    if (it < items) { red[it] = s1[k]; red[items + it] = s2[k]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < (int)C; c += kThreads) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int v = 0; v < vpr; ++v) { t1 += red[c * vpr + v]; t2 += red[items + c * vpr + v]; }
+    partial[((int64_t)blockIdx.x * 2 + 0) * C + c] = t1;
+    partial[((int64_t)blockIdx.x * 2 + 1) * C + c] = t2;
+  }
+}
+
+// dx (NCHW) = a*dy' + Bc*(x-mean) + C2 with dy NHWC
+template <typename T, bool RELU>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_mixed(
+    const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int64_t C, int64_t HW,
+    int tiles_per_img, const float* __restrict__ pk) {
+  constexpr int V = Pack<T, (sizeof(T) == 2 ? 8 : 4)>::N;
+  extern __shared__ __attribute__((aligned(16))) float tile[];     // [kTP][C + 1]
+  const int ldt = (int)C + 1;
+  const int64_t n = blockIdx.x / tiles_per_img;
+  const int64_t p0 = (int64_t)(blockIdx.x % tiles_per_img) * kTP;
+  const int npx = (HW - p0) < kTP ? (int)(HW - p0) : kTP;
+  const int tid = threadIdx.x;
+  const int gpr = (int)C / V, vpr = kTP / V;
+  for (int it = tid; it < npx * gpr; it += kThreads) {
+    const int p = it / gpr, g = it - p * gpr;
+    Pack<T, V> pd;
+    pd.load(dy + ((n * HW + p0 + p) * C) + g * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) tile[p * ldt + g * V + j] = pd.v[j];
+  }
+  __syncthreads();
+  for (int it = tid; it < (int)C * vpr; it += kThreads) {
+    const int c = it / vpr, v = it - c * vpr;
+    const int p = v * V;
+    if (p < npx) {
+      Pack<T, V> px;
+      px.load(x + (n * C + c) * HW + p0 + p);
+      const float a = pk[c], b = pk[C + c], mu = pk[2 * C + c], bc = pk[3 * C + c], c2 = pk[4 * C + c];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float d = tile[(p + j) * ldt + c];
+        if (RELU) d = fmaf(px.v[j], a, b) > 0.f ? d : 0.f;
+        px.v[j] = fmaf(a, d, fmaf(bc, px.v[j] - mu, c2));
+      }
+      px.store(dx + (n * C + c) * HW + p0 + p);
+    }
+  }
+}
+
+// =========================================================================
 // per-channel tail kernels: block = 32 channels x 8 slice-lanes, fp64, fixed order
 // =========================================================================
 constexpr int kTc = 32, kTs = 8;
@@ -757,6 +914,86 @@ int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, voi
   if (dtype == TSG_F32) return V == 4 ? GO(float, 4) : GO(float, 1);
   return V == 8 ? GO(bf16_t, 8) : GO(bf16_t, 1);
 #undef GO
+}
+
+
+// ---- mixed layout (x NCHW, y/dy NHWC) --------------------------------------------
+static int mixed_ok(int dtype, int64_t C, int64_t HW) {
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  return (dtype == TSG_F32 || dtype == TSG_BF16) && C % 8 == 0 && C <= 128 && HW % V == 0;
+}
+
+int tsg_bn_mixed_supported(int dtype, int64_t C, int64_t HW) { return mixed_ok(dtype, C, HW); }
+
+static int mixed_blocks(int64_t N, int64_t HW) {
+  int64_t t = N * ((HW + kTP - 1) / kTP);
+  if (t > kTargetBlocksNhwc) t = kTargetBlocksNhwc;
+  return (int)(t < 1 ? 1 : t);
+}
+
+int tsg_bn_mixed_num_partials(int64_t N, int64_t C, int64_t HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  return mixed_blocks(N, HW);
+}
+
+int tsg_bn_apply_fwd_mixed(const void* x_nchw, void* y_nhwc, int dtype, int64_t N, int64_t C,
+                           int64_t HW, const float* fwd_pack, int relu, void* stream) {
+  if (!x_nchw || !y_nhwc || !fwd_pack) return TSG_E_NULL;
+  if (N <= 0 || !mixed_ok(dtype, C, HW)) return TSG_E_SHAPE;
+  if (!aligned16(x_nchw) || !aligned16(y_nhwc)) return TSG_E_ALIGN;
+  const int tpi = (int)((HW + kTP - 1) / kTP);
+  const size_t sh = (size_t)kTP * (C + 1) * sizeof(float);
+  dim3 grid((unsigned)(N * tpi));
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T, R) hipLaunchKernelGGL((bn_fwd_mixed<T, R>), grid, dim3(kThreads), sh, st, (const T*)x_nchw, \
+                                    (T*)y_nhwc, C, HW, tpi, fwd_pack)
+  if (dtype == TSG_F32) { if (relu) GO(float, true); else GO(float, false); }
+  else { if (relu) GO(bf16_t, true); else GO(bf16_t, false); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_bn_bwd_reduce_mixed(const void* dy_nhwc, const void* x_nchw, int dtype, int64_t N, int64_t C,
+                            int64_t HW, const float* fwd_pack, int relu, float* partial, int* rows,
+                            void* stream) {
+  if (!dy_nhwc || !x_nchw || !fwd_pack || !partial) return TSG_E_NULL;
+  if (N <= 0 || !mixed_ok(dtype, C, HW)) return TSG_E_SHAPE;
+  if (!aligned16(x_nchw) || !aligned16(dy_nhwc)) return TSG_E_ALIGN;
+  const int tpi = (int)((HW + kTP - 1) / kTP);
+  const int64_t total = N * tpi;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  size_t sh = (size_t)kTP * (C + 1) * sizeof(float);
+  const size_t red = (size_t)2 * C * (kTP / V) * sizeof(float);
+  if (red > sh) sh = red;
+  const int blocks = mixed_blocks(N, HW);
+  if (rows) *rows = blocks;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T, R) hipLaunchKernelGGL((bn_bwd_reduce_mixed<T, R>), dim3(blocks), dim3(kThreads), sh, st, \
+                                    (const T*)dy_nhwc, (const T*)x_nchw, C, HW, tpi, total, fwd_pack, partial)
+  if (dtype == TSG_F32) { if (relu) GO(float, true); else GO(float, false); }
+  else { if (relu) GO(bf16_t, true); else GO(bf16_t, false); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_bn_bwd_apply_mixed(const void* dy_nhwc, const void* x_nchw, void* dx_nchw, int dtype, int64_t N,
+                           int64_t C, int64_t HW, const float* bwd_pack, int relu, void* stream) {
+  if (!dy_nhwc || !x_nchw || !dx_nchw || !bwd_pack) return TSG_E_NULL;
+  if (N <= 0 || !mixed_ok(dtype, C, HW)) return TSG_E_SHAPE;
+  if (!aligned16(x_nchw) || !aligned16(dy_nhwc) || !aligned16(dx_nchw)) return TSG_E_ALIGN;
+  const int tpi = (int)((HW + kTP - 1) / kTP);
+  const size_t sh = (size_t)kTP * (C + 1) * sizeof(float);
+  dim3 grid((unsigned)(N * tpi));
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T, R) hipLaunchKernelGGL((bn_bwd_apply_mixed<T, R>), grid, dim3(kThreads), sh, st, \
+                                    (const T*)dy_nhwc, (const T*)x_nchw, (T*)dx_nchw, C, HW, tpi, bwd_pack)
+  if (dtype == TSG_F32) { if (relu) GO(float, true); else GO(float, false); }
+  else { if (relu) GO(bf16_t, true); else GO(bf16_t, false); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,238 @@
+// Global average pooling ([N,C,H,W] -> [N,C,1,1]) for gfx950.
+//
+// The reference reaches it through nn.AdaptiveAvgPool2d(1) inside
+// AttentionRefinement / FeatureFusion (furnace/seg_opr/seg_oprs.py:200,224) and
+// GlobalAvgPool2d (seg_oprs.py:97-107).  On channels_last activations eager
+// PyTorch runs it as a strided reduce_kernel at ~0.2 TB/s (318 us for the
+// 16x256x128x128 FFM map, profiles/r01); here it is a streaming column reduce
+// with 16-byte loads and fixed-order partials (deterministic), HBM-bound:
+// algorithmic bytes = E*s forward, E*s backward (broadcast write).
+#include "tsg_common.h"
+
+namespace tsg {
+constexpr int kT = 256;
+constexpr int kU = 4;
+
+template <typename T, int V> struct PV;
+template <> struct PV<float, 4> : Vec<float> {};
+template <> struct PV<bf16_t, 8> : Vec<bf16_t> {};
+template <typename T> struct PV<T, 1> {
+  float v[1];
+  __device__ __forceinline__ void load(const T* p) { v[0] = ld1<T>(p); }
+  __device__ __forceinline__ void store(T* p) const { st1<T>(p, v[0]); }
+};
+
+// NHWC: x [N, HW, C]; block (s, n): rows [s*rpb, ...) of image n -> partial[n][s][c]
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void gap_partial_nhwc(const T* __restrict__ x, int64_t HW, int64_t C, int GT,
+                                                       int R, int64_t rpb, int S, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [R][C]
+  const int tid = threadIdx.x, gl = tid % GT, r = tid / GT;
+  const int64_t n = blockIdx.y;
+  const int64_t row0 = (int64_t)blockIdx.x * rpb;
+  int64_t row1 = row0 + rpb;
+  if (row1 > HW) row1 = HW;
+  const int G = (int)(C / V);
+  for (int gb = 0; gb < G; gb += GT) {                         // channel tiles when C/V > 256
+    const int g = gb + gl;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (r < R && g < G) {
+      const T* b = x + n * HW * C + (int64_t)g * V;
+      for (int64_t row = row0 + r; row < row1; row += (int64_t)kU * R) {
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+          const int64_t rr = row + (int64_t)k * R;
+          if (rr < row1) {
+            PV<T, V> p;
+            p.load(b + rr * C);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += p.v[j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (r < R && g < G) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) sm[r * (GT * V) + gl * V + j] = acc[j];
+    }
+    __syncthreads();
+    for (int t = tid; t < GT * V; t += kT) {
+      const int64_t c = (int64_t)gb * V + t;
+      if (c < C) {
+        float s = 0.f;
+        for (int q = 0; q < R; ++q) s += sm[q * (GT * V) + t];
+        partial[(n * S + blockIdx.x) * C + c] = s;
+      }
+    }
+  }
+}
+
+// NCHW: one block per (n, c) plane
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void gap_plane_nchw(const T* __restrict__ x, int64_t HW, float inv,
+                                                     T* __restrict__ out) {
+  __shared__ float sm[2 * (kT / 64)];
+  const T* b = x + (int64_t)blockIdx.x * HW;
+  float acc = 0.f, dummy = 0.f;
+  for (int64_t i = (int64_t)threadIdx.x * V; i < HW; i += (int64_t)kT * V) {
+    PV<T, V> p;
+    p.load(b + i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc += p.v[j];
+  }
+  block_sum2(acc, dummy, sm);
+  if (threadIdx.x == 0) st1<T>(out + blockIdx.x, acc * inv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kT) void gap_finish(const float* __restrict__ partial, int S, int64_t NC, int64_t C,
+                                                 float inv, T* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;   // i = n*C + c
+  if (i >= NC) return;
+  const int64_t n = i / C, c = i - n * C;
+  float s = 0.f;
+  for (int q = 0; q < S; ++q) s += partial[(n * S + q) * C + c];
+  st1<T>(out + i, s * inv);
+}
+
+// backward: dx[n, p, c] = dout[n, c] * inv   (NHWC)   /   dx[n, c, p] (NCHW)
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void gap_bwd_nhwc(const T* __restrict__ dout, int64_t HW, int64_t C, float inv,
+                                                   T* __restrict__ dx) {
+  const int64_t G = C / V;
+  const int64_t n = blockIdx.y;
+  const int64_t total = HW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int64_t g = i % G;
+    PV<T, V> p;
+    p.load(dout + n * C + g * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) p.v[j] *= inv;
+    p.store(dx + (n * HW) * C + i * V);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void gap_bwd_nchw(const T* __restrict__ dout, int64_t HW, float inv,
+                                                   T* __restrict__ dx) {
+  const float v = ld1<T>(dout + blockIdx.x) * inv;
+  PV<T, V> p;
+#pragma unroll
+  for (int j = 0; j < V; ++j) p.v[j] = v;
+  T* b = dx + (int64_t)blockIdx.x * HW;
+  for (int64_t i = (int64_t)threadIdx.x * V; i < HW; i += (int64_t)kT * V) p.store(b + i);
+}
+
+struct GapGeom { int gt, R, S; int64_t rpb; };
+static GapGeom gap_geom(int64_t N, int64_t C, int64_t HW, int V) {
+  GapGeom g;
+  int64_t G = C / V;
+  g.gt = (int)(G < kT ? G : kT);
+  g.R = kT / g.gt;
+  int64_t s = (1024 + N - 1) / N;
+  int64_t min_rows = (int64_t)g.R * kU * 2;
+  int64_t max_s = (HW + min_rows - 1) / min_rows;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  g.rpb = (HW + s - 1) / s;
+  g.rpb = (g.rpb + g.R - 1) / g.R * g.R;
+  g.S = (int)((HW + g.rpb - 1) / g.rpb);
+  return g;
+}
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" {
+
+size_t tsg_gap_ws_bytes(int layout, int64_t N, int64_t C, int64_t HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  if (layout == TSG_NCHW) return 16;
+  int smax = 1;
+  const int vs[3] = {1, 4, 8};
+  for (int i = 0; i < 3; ++i) if (C % vs[i] == 0) { int s = gap_geom(N, C, HW, vs[i]).S; if (s > smax) smax = s; }
+  return (size_t)N * smax * C * sizeof(float);
+}
+
+int tsg_gap_fwd(const void* x, void* out, int dtype, int layout, int64_t N, int64_t C, int64_t HW, void* ws,
+                size_t ws_bytes, void* stream) {
+  if (!x || !out || !ws) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_gap_ws_bytes(layout, N, C, HW)) return TSG_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  const int native = dtype == TSG_BF16 ? 8 : 4;
+  const float inv = 1.f / (float)HW;
+  if (layout == TSG_NCHW) {
+    const bool vec = HW % native == 0 && aligned16(x);
+    if (N * C > 0x7fffffffLL) return TSG_E_SHAPE;
+    dim3 grid((unsigned)(N * C));
+    if (dtype == TSG_F32) {
+      if (vec) hipLaunchKernelGGL((gap_plane_nchw<float, 4>), grid, dim3(kT), 0, st, (const float*)x, HW, inv, (float*)out);
+      else hipLaunchKernelGGL((gap_plane_nchw<float, 1>), grid, dim3(kT), 0, st, (const float*)x, HW, inv, (float*)out);
+    } else {
+      if (vec) hipLaunchKernelGGL((gap_plane_nchw<bf16_t, 8>), grid, dim3(kT), 0, st, (const bf16_t*)x, HW, inv, (bf16_t*)out);
+      else hipLaunchKernelGGL((gap_plane_nchw<bf16_t, 1>), grid, dim3(kT), 0, st, (const bf16_t*)x, HW, inv, (bf16_t*)out);
+    }
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (layout != TSG_NHWC) return TSG_E_LAYOUT;
+  const int V = (C % native == 0 && aligned16(x)) ? native : 1;
+  GapGeom g = gap_geom(N, C, HW, V);
+  dim3 grid((unsigned)g.S, (unsigned)N);
+  const size_t sh = (size_t)g.R * g.gt * V * sizeof(float);
+#define GO(T, VV) hipLaunchKernelGGL((gap_partial_nhwc<T, VV>), grid, dim3(kT), sh, st, (const T*)x, HW, C, g.gt, \
+                                     g.R, g.rpb, g.S, (float*)ws)
+  if (dtype == TSG_F32) { if (V == 4) GO(float, 4); else GO(float, 1); }
+  else { if (V == 8) GO(bf16_t, 8); else GO(bf16_t, 1); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  const int64_t NC = N * C;
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((gap_finish<float>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, inv, (float*)out);
+  else
+    hipLaunchKernelGGL((gap_finish<bf16_t>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, inv, (bf16_t*)out);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_gap_bwd(const void* dout, void* dx, int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                void* stream) {
+  if (!dout || !dx) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int native = dtype == TSG_BF16 ? 8 : 4;
+  const float inv = 1.f / (float)HW;
+  if (layout == TSG_NCHW) {
+    const bool vec = HW % native == 0 && aligned16(dx);
+    dim3 grid((unsigned)(N * C));
+    if (dtype == TSG_F32) {
+      if (vec) hipLaunchKernelGGL((gap_bwd_nchw<float, 4>), grid, dim3(kT), 0, st, (const float*)dout, HW, inv, (float*)dx);
+      else hipLaunchKernelGGL((gap_bwd_nchw<float, 1>), grid, dim3(kT), 0, st, (const float*)dout, HW, inv, (float*)dx);
+    } else {
+      if (vec) hipLaunchKernelGGL((gap_bwd_nchw<bf16_t, 8>), grid, dim3(kT), 0, st, (const bf16_t*)dout, HW, inv, (bf16_t*)dx);
+      else hipLaunchKernelGGL((gap_bwd_nchw<bf16_t, 1>), grid, dim3(kT), 0, st, (const bf16_t*)dout, HW, inv, (bf16_t*)dx);
+    }
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (layout != TSG_NHWC) return TSG_E_LAYOUT;
+  const int V = (C % native == 0 && aligned16(dx) && aligned16(dout)) ? native : 1;
+  int64_t gx = (HW * (C / V) + kT - 1) / kT;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, (unsigned)N);
+#define GO(T, VV) hipLaunchKernelGGL((gap_bwd_nhwc<T, VV>), grid, dim3(kT), 0, st, (const T*)dout, HW, C, inv, (T*)dx)
+  if (dtype == TSG_F32) { if (V == 4) GO(float, 4); else GO(float, 1); }
+  else { if (V == 8) GO(bf16_t, 8); else GO(bf16_t, 1); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

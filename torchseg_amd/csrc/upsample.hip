@@ -41,37 +41,70 @@ template <typename T> struct OutVec<T, 1> {
   __device__ __forceinline__ void store(T* p) const { st1<T>(p, v[0]); }
 };
 
-template <typename T, int V, bool ADD>
+// Forward, separable form.  One thread owns V consecutive output columns and a
+// band of RB output rows.  H0/H1 hold the horizontally interpolated source rows
+// y0 / y1 for its columns; they are refreshed only when y0 advances (every
+// ~1/scale output rows), so the per-output work is 2 FMAs + the 16-B store:
+//   top = hx*x[y0][x0] + lx*x[y0][x1] ; bot = (same on y1) ; y = hy*top + ly*bot
+// (identical operations and order to the 4-tap formula above).
+template <typename T, int V, bool ADD, int RB>
 __global__ __launch_bounds__(kT) void up_fwd(const T* __restrict__ x, const T* __restrict__ add,
                                              T* __restrict__ y, int64_t NC, int IH, int IW, int OH,
                                              int OW, float sy, float sx) {
-  const int vpr = OW / V;  // vectors per output row
-  const int64_t total = NC * OH * (int64_t)vpr;
+  const int vpr = OW / V;                      // column groups per row
+  const int bands = (OH + RB - 1) / RB;
+  const int64_t total = NC * bands * (int64_t)vpr;
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
     const int vx = (int)(i % vpr);
-    const int64_t row = i / vpr;
-    const int oy = (int)(row % OH);
-    const int64_t nc = row / OH;
-    int y0, y1; float ly;
-    src_index(sy, oy, IH, y0, y1, ly);
-    const float hy = 1.f - ly;
-    const T* r0 = x + (nc * IH + y0) * IW;
-    const T* r1 = x + (nc * IH + y1) * IW;
-    OutVec<T, V> o, a;
-    const int64_t ooff = row * OW + (int64_t)vx * V;
-    if (ADD) a.load(add + ooff);
+    const int64_t t = i / vpr;
+    const int band = (int)(t % bands);
+    const int64_t nc = t / bands;
+    int x0[V], x1[V];
+    float lx[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      int x0, x1; float lx;
-      src_index(sx, vx * V + j, IW, x0, x1, lx);
-      const float hx = 1.f - lx;
-      const float top = hx * ld1<T>(r0 + x0) + lx * ld1<T>(r0 + x1);
-      const float bot = hx * ld1<T>(r1 + x0) + lx * ld1<T>(r1 + x1);
-      float v = hy * top + ly * bot;
-      if (ADD) v += a.v[j];
-      o.v[j] = v;
+    for (int j = 0; j < V; ++j) src_index(sx, vx * V + j, IW, x0[j], x1[j], lx[j]);
+    const T* src = x + nc * IH * (int64_t)IW;
+    float h0[V], h1[V];
+    int cy0 = -1, cy1 = -1;
+    const int oy_end = (band + 1) * RB < OH ? (band + 1) * RB : OH;
+    for (int oy = band * RB; oy < oy_end; ++oy) {
+      int y0, y1; float ly;
+      src_index(sy, oy, IH, y0, y1, ly);
+      if (y0 != cy0) {
+        if (y0 == cy1) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) h0[j] = h1[j];
+        } else {
+          const T* r = src + (int64_t)y0 * IW;
+#pragma unroll
+          for (int j = 0; j < V; ++j) h0[j] = (1.f - lx[j]) * ld1<T>(r + x0[j]) + lx[j] * ld1<T>(r + x1[j]);
+        }
+        cy0 = y0;
+        cy1 = -1;
+      }
+      if (y1 != cy1) {
+        if (y1 == cy0) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) h1[j] = h0[j];
+        } else {
+          const T* r = src + (int64_t)y1 * IW;
+#pragma unroll
+          for (int j = 0; j < V; ++j) h1[j] = (1.f - lx[j]) * ld1<T>(r + x0[j]) + lx[j] * ld1<T>(r + x1[j]);
+        }
+        cy1 = y1;
+      }
+      const float hy = 1.f - ly;
+      const int64_t ooff = (nc * OH + oy) * (int64_t)OW + (int64_t)vx * V;
+      OutVec<T, V> o, a;
+      if (ADD) a.load(add + ooff);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float v = hy * h0[j] + ly * h1[j];
+        if (ADD) v += a.v[j];
+        o.v[j] = v;
+      }
+      o.store(y + ooff);
     }
-    o.store(y + ooff);
   }
 }
 
@@ -141,6 +174,183 @@ __global__ __launch_bounds__(kT) void up_bwd(const T* __restrict__ dy, T* __rest
   }
 }
 
+// Backward, fused separable form (the fast path for up-sampling).  A block owns
+// RB consecutive source rows of one (n,c) plane and the full row width:
+//   1. vertical: every thread streams V output columns over the output rows whose
+//      taps touch the owned source rows (16-B coalesced reads of dy, each read
+//      once plus a one-row halo), keeping running sums for source rows y0 / y0+1
+//      and flushing a finished row into LDS;
+//   2. horizontal: thread ix gathers its x-footprint from the LDS rows with the
+//      forward's exact tap weights and writes dx.
+// No atomics; every source pixel is produced by exactly one thread in a fixed order.
+template <typename T, int V, int MAXF>
+__global__ void up_bwd_tiled(const T* __restrict__ dy, T* __restrict__ dx, int IH, int IW, int OH,
+                             int OW, int RB, float sy, float sx) {
+  extern __shared__ __attribute__((aligned(16))) float vrow[];    // [RB][OW]
+  const int nthreads = blockDim.x;
+  const int tid = threadIdx.x;
+  const int vpr = OW / V;
+  const int bands = (IH + RB - 1) / RB;
+  const int band = blockIdx.x % bands;
+  const int64_t nc = blockIdx.x / bands;
+  const int r0 = band * RB;
+  const int r1 = (r0 + RB < IH) ? r0 + RB : IH;
+  const T* src = dy + nc * OH * (int64_t)OW;
+  for (int i = tid; i < (r1 - r0) * OW; i += nthreads) vrow[i] = 0.f;
+  __syncthreads();
+  // output rows with y0 in [r0-1, r1-1]
+  int oy_lo = 0, oy_hi = OH - 1;
+  if (sy > 0.f) {
+    const float inv = 1.f / sy;
+    int l = (int)ceilf((float)(r0 - 1) * inv) - 1;
+    int h = (int)floorf((float)r1 * inv) + 1;
+    oy_lo = l < 0 ? 0 : l;
+    oy_hi = h > OH - 1 ? OH - 1 : h;
+  }
+  if (tid < vpr) {
+    float accA[V], accB[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+    int cur = -2;                                  // source row accA belongs to
+    auto flush = [&](int row, const float (&acc)[V]) {
+      if (row >= r0 && row < r1) {
+        float* d = vrow + (row - r0) * OW + tid * V;
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = acc[j];
+      }
+    };
+    auto absorb = [&](int oy, const OutVec<T, V>& g) {
+      int y0, y1; float ly;
+      src_index(sy, oy, IH, y0, y1, ly);
+      if (y0 < r0 - 1 || y0 > r1 - 1) return;      // halo rows of the conservative range
+      if (y0 != cur) {
+        if (cur >= 0) {
+          flush(cur, accA);
+          if (y0 == cur + 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { accA[j] = accB[j]; accB[j] = 0.f; }
+          } else {                                 // down-sampling jump: both rows are finished
+            flush(cur + 1, accB);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+          }
+        }
+        cur = y0;
+      }
+      const float hy = 1.f - ly;
+      if (y1 == y0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) accA[j] += hy * g.v[j] + ly * g.v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { accA[j] += hy * g.v[j]; accB[j] += ly * g.v[j]; }
+      }
+    };
+    constexpr int U = 4;                           // rows in flight per thread
+    for (int oy = oy_lo; oy <= oy_hi; oy += U) {
+      OutVec<T, V> g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (oy + u <= oy_hi) g[u].load(src + (int64_t)(oy + u) * OW + tid * V);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (oy + u <= oy_hi) absorb(oy + u, g[u]);
+    }
+    if (cur >= 0) { flush(cur, accA); flush(cur + 1, accB); }
+  }
+  __syncthreads();
+  for (int ix = tid; ix < IW; ix += nthreads) {
+    int xlo, xhi;
+    footprint(sx, ix, OW, xlo, xhi);
+    float wx[MAXF];
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j) wx[j] = (xlo + j <= xhi) ? tap_weight(sx, xlo + j, IW, ix) : 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const float* v = vrow + (r - r0) * OW + xlo;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXF; ++j)
+        if (xlo + j <= xhi) acc += wx[j] * v[j];
+      st1<T>(dx + (nc * IH + r) * (int64_t)IW + ix, acc);
+    }
+  }
+}
+
+// ---- channels_last (NHWC) variants for feature maps (C % V == 0) ---------------
+// A thread owns V adjacent channels of one pixel: every tap is one 16-byte load,
+// so neither direction needs LDS.  x [N, IH, IW, C] -> y [N, OH, OW, C].
+template <typename T, int V, bool ADD>
+__global__ __launch_bounds__(kT) void up_fwd_nhwc(const T* __restrict__ x, const T* __restrict__ add,
+                                                  T* __restrict__ y, int64_t N, int C, int IH, int IW,
+                                                  int OH, int OW, float sy, float sx) {
+  const int G = C / V;
+  const int64_t total = N * OH * (int64_t)OW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int g = (int)(i % G);
+    int64_t t = i / G;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int64_t n = t / OH;
+    int y0, y1, x0, x1; float ly, lx;
+    src_index(sy, oy, IH, y0, y1, ly);
+    src_index(sx, ox, IW, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* b = x + n * IH * (int64_t)IW * C + g * V;
+    OutVec<T, V> p00, p01, p10, p11, o, a;
+    p00.load(b + ((int64_t)y0 * IW + x0) * C);
+    p01.load(b + ((int64_t)y0 * IW + x1) * C);
+    p10.load(b + ((int64_t)y1 * IW + x0) * C);
+    p11.load(b + ((int64_t)y1 * IW + x1) * C);
+    if (ADD) a.load(add + i * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float v = hy * (hx * p00.v[j] + lx * p01.v[j]) + ly * (hx * p10.v[j] + lx * p11.v[j]);
+      if (ADD) v += a.v[j];
+      o.v[j] = v;
+    }
+    o.store(y + i * V);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void up_bwd_nhwc(const T* __restrict__ dy, T* __restrict__ dx,
+                                                  int64_t N, int C, int IH, int IW, int OH, int OW,
+                                                  float sy, float sx) {
+  const int G = C / V;
+  const int64_t total = N * IH * (int64_t)IW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int g = (int)(i % G);
+    int64_t t = i / G;
+    const int ix = (int)(t % IW); t /= IW;
+    const int iy = (int)(t % IH);
+    const int64_t n = t / IH;
+    int xlo, xhi, ylo, yhi;
+    footprint(sx, ix, OW, xlo, xhi);
+    footprint(sy, iy, OH, ylo, yhi);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    const T* b = dy + n * OH * (int64_t)OW * C + g * V;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = tap_weight(sy, oy, IH, iy);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float w = wy * tap_weight(sx, ox, IW, ix);
+        if (w != 0.f) {
+          OutVec<T, V> p;
+          p.load(b + ((int64_t)oy * OW + ox) * C);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += w * p.v[j];
+        }
+      }
+    }
+    OutVec<T, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = acc[j];
+    o.store(dx + i * V);
+  }
+}
+
 template <int EB>
 __global__ __launch_bounds__(kT) void nearest_fwd(const void* __restrict__ x, void* __restrict__ y,
                                                   int64_t NC, int IH, int IW, int OH, int OW,
@@ -183,8 +393,8 @@ int tsg_upsample_bilinear_ac_fwd(const void* x, const void* add, void* y, int dt
   const int native = dtype == TSG_BF16 ? 8 : 4;
   const bool vec = (OW % native == 0) && aligned16(y) && (!add || aligned16(add));
   const int V = vec ? native : 1;
-  const int grid = grid_for(NC * OH * (int64_t)(OW / V));
-#define GO(T, VV, A) hipLaunchKernelGGL((up_fwd<T, VV, A>), dim3(grid), dim3(kT), 0, st, (const T*)x, \
+  const int grid = grid_for(NC * ((OH + 15) / 16) * (int64_t)(OW / V));
+#define GO(T, VV, A) hipLaunchKernelGGL((up_fwd<T, VV, A, 16>), dim3(grid), dim3(kT), 0, st, (const T*)x, \
                                         (const T*)add, (T*)y, NC, IH, IW, OH, OW, sy, sx)
   if (dtype == TSG_F32) {
     if (vec) { if (add) GO(float, 4, true); else GO(float, 4, false); }
@@ -207,6 +417,31 @@ int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype, int64_t NC
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
   // widest x-footprint: floor(2/sx) + 4 candidates (see footprint())
   int need = sx > 0.f ? (int)floorf(2.f / sx) + 4 : OW;
+  // fast path: up-sampling with a vectorisable row that one block can span
+  const int native = dtype == TSG_BF16 ? 8 : 4;
+  if (need <= 37 && OW % native == 0 && OW / native <= 1024 && OW >= IW && aligned16(dy)) {
+    int threads = ((OW / native + 63) / 64) * 64;
+    if (threads < 128) threads = 128;
+    int RB = 8;
+    while (RB > 1 && (size_t)RB * OW * sizeof(float) > 48 * 1024) RB >>= 1;
+    if ((size_t)RB * OW * sizeof(float) <= 64 * 1024) {
+      const int bands = (IH + RB - 1) / RB;
+      const int64_t blocks = NC * bands;
+      if (blocks <= 0x7fffffffLL) {
+        const size_t sh = (size_t)RB * OW * sizeof(float);
+#define GT_(T, VV, F) hipLaunchKernelGGL((up_bwd_tiled<T, VV, F>), dim3((unsigned)blocks), dim3(threads), sh, st, \
+                                         (const T*)dy, (T*)dx, IH, IW, OH, OW, RB, sy, sx)
+        if (dtype == TSG_F32) {
+          if (need <= 9) GT_(float, 4, 9); else if (need <= 21) GT_(float, 4, 21); else GT_(float, 4, 37);
+        } else {
+          if (need <= 9) GT_(bf16_t, 8, 9); else if (need <= 21) GT_(bf16_t, 8, 21); else GT_(bf16_t, 8, 37);
+        }
+#undef GT_
+        TSG_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+  }
   const int grid = grid_for(NC * IH * (int64_t)IW);
 #define GO(T, F) hipLaunchKernelGGL((up_bwd<T, F>), dim3(grid), dim3(kT), 0, st, (const T*)dy, (T*)dx, \
                                     NC, IH, IW, OH, OW, sy, sx)
@@ -216,6 +451,45 @@ int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype, int64_t NC
     if (need <= 9) GO(bf16_t, 9); else if (need <= 21) GO(bf16_t, 21); else if (need <= 37) GO(bf16_t, 37); else GO(bf16_t, 0);
   }
 #undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_upsample_bilinear_ac_nhwc_fwd(const void* x, const void* add, void* y, int dtype, int64_t N,
+                                      int C, int IH, int IW, int OH, int OW, void* stream) {
+  if (!x || !y) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return TSG_E_SHAPE;
+  if (!aligned16(x) || !aligned16(y) || (add && !aligned16(add))) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
+  const int grid = grid_for(N * OH * (int64_t)OW * (C / V));
+#define GO(T, VV, A) hipLaunchKernelGGL((up_fwd_nhwc<T, VV, A>), dim3(grid), dim3(kT), 0, st, (const T*)x, \
+                                        (const T*)add, (T*)y, N, C, IH, IW, OH, OW, sy, sx)
+  if (dtype == TSG_F32) { if (add) GO(float, 4, true); else GO(float, 4, false); }
+  else { if (add) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_upsample_bilinear_ac_nhwc_bwd(const void* dy, void* dx, int dtype, int64_t N, int C, int IH,
+                                      int IW, int OH, int OW, void* stream) {
+  if (!dy || !dx) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return TSG_E_SHAPE;
+  if (!aligned16(dy) || !aligned16(dx)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
+  const int grid = grid_for(N * IH * (int64_t)IW * (C / V));
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((up_bwd_nhwc<float, 4>), dim3(grid), dim3(kT), 0, st, (const float*)dy, (float*)dx, N, C,
+                       IH, IW, OH, OW, sy, sx);
+  else
+    hipLaunchKernelGGL((up_bwd_nhwc<bf16_t, 8>), dim3(grid), dim3(kT), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, C,
+                       IH, IW, OH, OW, sy, sx);
   TSG_CHECK_LAUNCH();
   return 0;
 }

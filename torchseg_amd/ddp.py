@@ -223,6 +223,8 @@ class DistributedDataParallel(nn.Module):
         self.channels_last = bool(channels_last)
         if self.channels_last:
             apply_channels_last(self.module)
+            from . import syncbn
+            syncbn.PREFER_CHANNELS_LAST_OUTPUT = True
         self.fuse_psa = False
         if self.on_gpu:
             from .upsample import install_aten_overrides

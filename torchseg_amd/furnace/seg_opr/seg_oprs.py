@@ -10,6 +10,7 @@ nn.BatchNorm2d for the CPU plumbing config) takes the plain module sequence.
 import torch
 import torch.nn as nn
 
+from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool
 from torchseg_amd.syncbn import SyncBatchNorm as _FusedBN
 
 
@@ -89,6 +90,9 @@ class GlobalAvgPool2d(nn.Module):
     """[B,C,H,W] -> [B,C,1,1] mean (seg_oprs.py:97-107)."""
 
     def forward(self, inputs):
+        if inputs.is_cuda and inputs.dim() == 4:
+            from torchseg_amd.pool import global_avg_pool
+            return global_avg_pool(inputs)
         b, c = inputs.size(0), inputs.size(1)
         return inputs.reshape(b, c, -1).mean(dim=2).view(b, c, 1, 1)
 
@@ -96,7 +100,7 @@ class GlobalAvgPool2d(nn.Module):
 class SELayer(nn.Module):
     def __init__(self, in_planes, out_planes, reduction=16):
         super(SELayer, self).__init__()
-        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.avg_pool = _GlobalAvgPool(1)
         self.fc = nn.Sequential(nn.Linear(in_planes, out_planes // reduction), nn.ReLU(inplace=True),
                                 nn.Linear(out_planes // reduction, out_planes), nn.Sigmoid())
         self.out_planes = out_planes
@@ -166,7 +170,7 @@ class AttentionRefinement(nn.Module):
         self.conv_3x3 = ConvBnRelu(in_planes, out_planes, 3, 1, 1, has_bn=True, norm_layer=norm_layer,
                                    has_relu=True, has_bias=False)
         self.channel_attention = nn.Sequential(
-            nn.AdaptiveAvgPool2d(1),
+            _GlobalAvgPool(1),
             ConvBnRelu(out_planes, out_planes, 1, 1, 0, has_bn=True, norm_layer=norm_layer,
                        has_relu=False, has_bias=False),
             nn.Sigmoid())
@@ -184,7 +188,7 @@ class FeatureFusion(nn.Module):
         self.conv_1x1 = ConvBnRelu(in_planes, out_planes, 1, 1, 0, has_bn=True, norm_layer=norm_layer,
                                    has_relu=True, has_bias=False)
         self.channel_attention = nn.Sequential(
-            nn.AdaptiveAvgPool2d(1),
+            _GlobalAvgPool(1),
             ConvBnRelu(out_planes, out_planes // reduction, 1, 1, 0, has_bn=False, norm_layer=norm_layer,
                        has_relu=True, has_bias=False),
             ConvBnRelu(out_planes // reduction, out_planes, 1, 1, 0, has_bn=False, norm_layer=norm_layer,

@@ -12,6 +12,9 @@ import torch
 from . import _lib as L
 
 
+# re-exported so host modules can name layout codes as K.L.NCHW / K.L.NHWC
+
+
 def bn_layout(x):
     """(layout, N, C, HW) of a dense activation, or None if it must be copied.
 
@@ -125,6 +128,51 @@ class HipKernels:
                                           bp.data_ptr(), int(relu), L.stream_ptr(x)), "tsg_bn_bwd_apply")
         return dx, dres
 
+    # ---- SyncBN, mixed layout (x NCHW, y/dy channels_last) -------------------
+    def bn_mixed_supported(self, x):
+        """4-D NCHW-contiguous activation that the stem kernels can take."""
+        if x.dim() != 4 or not x.is_contiguous():
+            return False
+        return bool(self.lib.tsg_bn_mixed_supported(L.dtype_code(x), x.shape[1], x.shape[2] * x.shape[3]))
+
+    def bn_apply_fwd_mixed(self, x, N, Cc, HW, fp, relu):
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_bn_apply_fwd_mixed(x.data_ptr(), y.data_ptr(), L.dtype_code(x), N, Cc, HW,
+                                                fp.data_ptr(), int(relu), L.stream_ptr(x)),
+                "tsg_bn_apply_fwd_mixed")
+        return y
+
+    def bn_bwd_reduce_mixed(self, dy, x, N, Cc, HW, fp, relu):
+        smax = self.lib.tsg_bn_mixed_num_partials(N, Cc, HW)
+        partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
+        rows = C.c_int(0)
+        L.check(self.lib.tsg_bn_bwd_reduce_mixed(dy.data_ptr(), x.data_ptr(), L.dtype_code(x), N, Cc, HW,
+                                                 fp.data_ptr(), int(relu), partial.data_ptr(),
+                                                 C.byref(rows), L.stream_ptr(x)), "tsg_bn_bwd_reduce_mixed")
+        return partial, rows.value
+
+    def bn_bwd_apply_mixed(self, dy, x, N, Cc, HW, bp, relu):
+        dx = torch.empty_like(x)
+        L.check(self.lib.tsg_bn_bwd_apply_mixed(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), L.dtype_code(x),
+                                                N, Cc, HW, bp.data_ptr(), int(relu), L.stream_ptr(x)),
+                "tsg_bn_bwd_apply_mixed")
+        return dx
+
+    # ---- global average pool -------------------------------------------------
+    def gap_fwd(self, x, layout, N, Cc, HW):
+        wsb = self.lib.tsg_gap_ws_bytes(layout, N, Cc, HW)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+        out = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
+        L.check(self.lib.tsg_gap_fwd(x.data_ptr(), out.data_ptr(), L.dtype_code(x), layout, N, Cc, HW,
+                                     ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_gap_fwd")
+        return out
+
+    def gap_bwd(self, dout, like, layout, N, Cc, HW):
+        dx = torch.empty_like(like)
+        L.check(self.lib.tsg_gap_bwd(dout.data_ptr(), dx.data_ptr(), L.dtype_code(dout), layout, N, Cc, HW,
+                                     L.stream_ptr(dout)), "tsg_gap_bwd")
+        return dx
+
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
@@ -199,6 +247,23 @@ class HipKernels:
         L.check(self.lib.tsg_upsample_bilinear_ac_bwd(dy.data_ptr(), dx.data_ptr(), L.dtype_code(dy),
                                                       N * Cc, IH, IW, OH, OW, L.stream_ptr(dy)),
                 "tsg_upsample_bilinear_ac_bwd")
+        return dx
+
+    def upsample_fwd_nhwc(self, x, add, OH, OW):
+        """x [N,C,IH,IW] channels_last-dense -> [N,C,OH,OW] channels_last"""
+        N, Cc, IH, IW = x.shape
+        y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_upsample_bilinear_ac_nhwc_fwd(x.data_ptr(), L.ptr(add), y.data_ptr(),
+                                                           L.dtype_code(x), N, Cc, IH, IW, OH, OW,
+                                                           L.stream_ptr(x)), "tsg_upsample_bilinear_ac_nhwc_fwd")
+        return y
+
+    def upsample_bwd_nhwc(self, dy, IH, IW):
+        N, Cc, OH, OW = dy.shape
+        dx = torch.empty((N, Cc, IH, IW), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_upsample_bilinear_ac_nhwc_bwd(dy.data_ptr(), dx.data_ptr(), L.dtype_code(dy),
+                                                           N, Cc, IH, IW, OH, OW, L.stream_ptr(dy)),
+                "tsg_upsample_bilinear_ac_nhwc_bwd")
         return dx
 
     def upsample_nearest(self, x, OH, OW):
@@ -279,6 +344,13 @@ _ALGO_BYTES = {
     "ohem_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "upsample_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "upsample_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "upsample_fwd_nhwc": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
+    "upsample_bwd_nhwc": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "bn_apply_fwd_mixed": lambda a, r: 2 * _nbytes(a[0]),
+    "bn_bwd_reduce_mixed": lambda a, r: 2 * _nbytes(a[0]),
+    "bn_bwd_apply_mixed": lambda a, r: 3 * _nbytes(a[0]),
+    "gap_fwd": lambda a, r: _nbytes(a[0]),
+    "gap_bwd": lambda a, r: _nbytes(r),
 }
 
 

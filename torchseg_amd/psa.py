@@ -57,7 +57,8 @@ class _DeferredColSoftmax(object):
 
     def materialize(self):
         if self._value is None:
-            self._value = torch.softmax(self.a, dim=1)
+            # aten-level entry point: not one of _SOFTMAX_FUNCS, so an active FusePsaMode lets it through
+            self._value = torch._softmax(self.a, 1, False)
         return self._value
 
     @classmethod

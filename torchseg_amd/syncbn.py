@@ -22,6 +22,11 @@ from . import kernels as K
 
 _count_cache = {}
 
+# Set by the DDP wrapper when the model runs channels_last: an NCHW activation
+# (only conv stems produce one) then leaves the BN already converted to
+# channels_last through the mixed-layout kernels.
+PREFER_CHANNELS_LAST_OUTPUT = False
+
 
 def _count_words(n, device):
     """Device tensor [n // 4096, n % 4096] (fp32): an exactly summable count."""
@@ -62,6 +67,43 @@ def _like(t, ref):
     return t
 
 
+def _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world):
+    """stats -> (all-reduce) -> finalize.  Returns (invstd, fwd_pack, count_dev)."""
+    n_local = N * HW
+    if world == 1 and n_local <= 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size {}"
+                         .format(tuple(x.shape)))
+    partial, S = kp.bn_stats(x, layout, N, C, HW)
+    rm = mod.running_mean if mod.track_running_stats else None
+    rv = mod.running_var if mod.track_running_stats else None
+    nbt = mod.num_batches_tracked if mod.track_running_stats else None
+    momentum = 0.0 if mod.momentum is None else float(mod.momentum)
+    if world > 1:
+        msg = torch.empty(2 * C + 2, dtype=torch.float32, device=x.device)
+        kp.bn_collapse(partial, S, C, msg)
+        msg[2 * C:].copy_(_count_words(n_local, x.device))
+        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+        count_dev = msg[2 * C:]
+        _, invstd, fp = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum,
+                                       gamma, beta, rm, rv, nbt)
+        return invstd, fp, count_dev
+    _, invstd, fp = kp.bn_finalize(partial, S, C, float(n_local), None, float(mod.eps), momentum,
+                                   gamma, beta, rm, rv, nbt)
+    return invstd, fp, None
+
+
+def _backward_pack(kp, partial, S, C, n_local, invstd, fp, count_dev, use_batch_stats, group, world, device):
+    """(all-reduce of the backward sums) -> dgamma, dbeta (local) and the bwd pack (global)."""
+    if use_batch_stats and world > 1:
+        sums = torch.empty(2 * C, dtype=torch.float32, device=device)
+        kp.bn_collapse(partial, S, C, sums)
+        dgamma, dbeta, _ = kp.bn_bwd_coeffs(sums, 1, C, 1.0, None, True, invstd, fp, True, False)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        _, _, bp = kp.bn_bwd_coeffs(sums, 1, C, 0.0, count_dev, True, invstd, fp, False, True)
+        return dgamma, dbeta, bp
+    return kp.bn_bwd_coeffs(partial, S, C, float(n_local), None, use_batch_stats, invstd, fp, True, True)
+
+
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, mod, relu, use_batch_stats, group):
@@ -71,58 +113,45 @@ class _SyncBNFn(torch.autograd.Function):
             residual = _like(residual, x)
         world = _world(group) if use_batch_stats else 1
         count_dev = None
-        n_local = N * HW
         gamma = weight.float() if weight is not None else None
         beta = bias.float() if bias is not None else None
         if use_batch_stats:
-            if world == 1 and n_local <= 1:
-                raise ValueError("Expected more than 1 value per channel when training, got input size {}"
-                                 .format(tuple(x.shape)))
-            partial, S = kp.bn_stats(x, layout, N, C, HW)
-            rm = mod.running_mean if mod.track_running_stats else None
-            rv = mod.running_var if mod.track_running_stats else None
-            nbt = mod.num_batches_tracked if mod.track_running_stats else None
-            momentum = 0.0 if mod.momentum is None else float(mod.momentum)
-            if world > 1:
-                msg = torch.empty(2 * C + 2, dtype=torch.float32, device=x.device)
-                kp.bn_collapse(partial, S, C, msg)
-                msg[2 * C:].copy_(_count_words(n_local, x.device))
-                dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
-                count_dev = msg[2 * C:]
-                mean, invstd, fp = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum,
-                                                  gamma, beta, rm, rv, nbt)
-            else:
-                mean, invstd, fp = kp.bn_finalize(partial, S, C, float(n_local), None, float(mod.eps),
-                                                  momentum, gamma, beta, rm, rv, nbt)
+            invstd, fp, count_dev = _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world)
         else:
             mean = mod.running_mean.float()
             invstd = torch.rsqrt(mod.running_var.float() + mod.eps)
             fp = kp.bn_affine(mean, invstd, gamma, beta)
-        y = kp.bn_apply_fwd(x, residual, layout, N, C, HW, fp, relu)
+        mixed = (PREFER_CHANNELS_LAST_OUTPUT and residual is None and layout == K.L.NCHW
+                 and kp.bn_mixed_supported(x))
+        if mixed:
+            y = kp.bn_apply_fwd_mixed(x, N, C, HW, fp, relu)
+        else:
+            y = kp.bn_apply_fwd(x, residual, layout, N, C, HW, fp, relu)
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, weight, bias, invstd, fp, count_dev)
-        ctx.cfg = (layout, N, C, HW, relu, use_batch_stats, group, world, residual is not None)
+        ctx.cfg = (layout, N, C, HW, relu, use_batch_stats, group, world, residual is not None, mixed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         kp = K.provider()
         x, y, weight, bias, invstd, fp, count_dev = ctx.saved_tensors
-        layout, N, C, HW, relu, use_batch_stats, group, world, has_res = ctx.cfg
-        dy = _like(dy, x)
-        partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, fp, relu)
-        want_pg = weight is not None
-        if use_batch_stats and world > 1:
-            sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
-            kp.bn_collapse(partial, S, C, sums)
-            dgamma, dbeta, _ = kp.bn_bwd_coeffs(sums, 1, C, 1.0, None, True, invstd, fp, True, False)
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-            _, _, bp = kp.bn_bwd_coeffs(sums, 1, C, 0.0, count_dev, True, invstd, fp, False, True)
+        layout, N, C, HW, relu, use_batch_stats, group, world, has_res, mixed = ctx.cfg
+        if mixed:
+            if dy.dtype != x.dtype:
+                dy = dy.to(x.dtype)
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            partial, S = kp.bn_bwd_reduce_mixed(dy, x, N, C, HW, fp, relu)
         else:
-            dgamma, dbeta, bp = kp.bn_bwd_coeffs(partial, S, C, float(N * HW), None, use_batch_stats,
-                                                 invstd, fp, True, True)
-        dx, dres = kp.bn_bwd_apply(dy, x, y, layout, N, C, HW, bp, relu, has_res)
-        if not want_pg:
+            dy = _like(dy, x)
+            partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, fp, relu)
+        dgamma, dbeta, bp = _backward_pack(kp, partial, S, C, N * HW, invstd, fp, count_dev,
+                                           use_batch_stats, group, world, x.device)
+        if mixed:
+            dx, dres = kp.bn_bwd_apply_mixed(dy, x, N, C, HW, bp, relu), None
+        else:
+            dx, dres = kp.bn_bwd_apply(dy, x, y, layout, N, C, HW, bp, relu, has_res)
+        if weight is None:
             dgamma = dbeta = None
         else:
             dgamma = dgamma.to(weight.dtype)

@@ -15,22 +15,46 @@ import torch
 from . import kernels as K
 
 
+def _is_cl_dense(x):
+    """channels_last-dense 4-D tensor that is not also plain-contiguous."""
+    return (x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _vec_ok(x):
+    return x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+
+
+def _forward_any_layout(x, add, OH, OW):
+    """Pick the kernel by layout: channels_last feature maps stay channels_last
+    (no conversion copies around the convs); everything else is NCHW planar, which
+    is also what the OHEM kernels want for the C=19 logits."""
+    kp = K.provider()
+    if _is_cl_dense(x) and _vec_ok(x):
+        if add is not None:
+            add = add.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        return kp.upsample_fwd_nhwc(x, add, OH, OW)
+    if add is not None:
+        add = add.to(x.dtype).contiguous()
+    return kp.upsample_fwd(x.contiguous(), add, OH, OW)
+
+
+def _backward_any_layout(dy, IH, IW):
+    kp = K.provider()
+    if _is_cl_dense(dy) and _vec_ok(dy):
+        return kp.upsample_bwd_nhwc(dy, IH, IW)
+    return kp.upsample_bwd(dy.contiguous(), IH, IW)
+
+
 class _UpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, add, OH, OW):
-        kp = K.provider()
-        x = x.contiguous()
-        if add is not None:
-            add = add.to(x.dtype).contiguous()
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.has_add = add is not None
-        return kp.upsample_fwd(x, add, OH, OW)
+        return _forward_any_layout(x, add, OH, OW)
 
     @staticmethod
     def backward(ctx, dy):
-        kp = K.provider()
-        dy = dy.contiguous()
-        dx = kp.upsample_bwd(dy, *ctx.in_hw)
+        dx = _backward_any_layout(dy, *ctx.in_hw)
         return dx, (dy if ctx.has_add else None), None, None
 
 
@@ -71,15 +95,25 @@ def install_aten_overrides():
     def fwd(x, output_size, align_corners, scales_h=None, scales_w=None):
         if not align_corners:
             raise NotImplementedError("torchseg_amd overrides upsample_bilinear2d for align_corners=True only")
-        return K.provider().upsample_fwd(x.contiguous(), None, int(output_size[0]), int(output_size[1]))
+        return _forward_any_layout(x, None, int(output_size[0]), int(output_size[1]))
 
     def bwd(grad_output, output_size, input_size, align_corners, scales_h=None, scales_w=None):
         if not align_corners:
             raise NotImplementedError("torchseg_amd overrides upsample_bilinear2d for align_corners=True only")
-        return K.provider().upsample_bwd(grad_output.contiguous(), int(input_size[2]), int(input_size[3]))
+        return _backward_any_layout(grad_output, int(input_size[2]), int(input_size[3]))
+
+    # torch's autocast up-casts upsample inputs to fp32; BASELINE config 2 keeps
+    # activations (and therefore the full-resolution logits) in bf16, so the
+    # autocast layer is told to pass the input dtype through to our kernel.
+    autocast_key = torch._C.DispatchKeySet(torch._C.DispatchKey.AutocastCUDA)
+
+    def fwd_autocast(x, output_size, align_corners, scales_h=None, scales_w=None):
+        with torch._C._ExcludeDispatchKeyGuard(autocast_key):
+            return torch.ops.aten.upsample_bilinear2d.default(x, output_size, align_corners, scales_h, scales_w)
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         lib.impl("upsample_bilinear2d", fwd, "CUDA")
         lib.impl("upsample_bilinear2d_backward", bwd, "CUDA")
+        lib.impl("upsample_bilinear2d", fwd_autocast, "AutocastCUDA")
     _lib_handle = lib
