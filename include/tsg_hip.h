@@ -166,6 +166,17 @@ int tsg_gap_fwd(const void* x, void* out, int dtype, int layout,
 int tsg_gap_bwd(const void* dout, void* dx, int dtype, int layout,
                 int64_t N, int64_t C, int64_t HW, void* stream);
 
+/* Channel gate y = x * s[n,c] (+ x when add_identity): the squeeze-excite
+ * multiply of AttentionRefinement (`fm * fm_se`, seg_oprs.py:209-210) and
+ * FeatureFusion (`fm + fm * fm_se`, seg_oprs.py:236-237).  s / ds are [N, C] in
+ * the activation dtype.  Backward in one pass: dx = dy*s (+dy), ds = sum_p dy*x.
+ * ws as for tsg_gap_fwd (tsg_gap_ws_bytes). */
+int tsg_chanscale_fwd(const void* x, const void* s, void* y, int dtype, int layout,
+                      int64_t N, int64_t C, int64_t HW, int add_identity, void* stream);
+int tsg_chanscale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds,
+                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                      int add_identity, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
  * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.

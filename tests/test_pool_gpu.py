@@ -26,3 +26,32 @@ def test_global_avg_pool(cuda, shape, layout, dtype):
     torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
     torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
     assert xd.grad.stride() == xd.stride()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 7, 5), (4, 128, 32, 32), (16, 256, 128, 128), (3, 19, 9, 9), (2, 4096, 3, 3)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ident", [False, True])
+def test_channel_scale(cuda, shape, layout, dtype, ident):
+    from torchseg_amd.pool import channel_scale
+    g = torch.Generator().manual_seed(shape[1] + 1)
+    x = torch.randn(shape, generator=g).to(dtype)
+    s = torch.sigmoid(torch.randn(shape[0], shape[1], 1, 1, generator=g)).to(dtype)
+    dy = torch.randn(shape, generator=g).to(dtype)
+    fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+    xd = x.to(cuda).contiguous(memory_format=fmt).requires_grad_(True)
+    sd = s.to(cuda).requires_grad_(True)
+    y = channel_scale(xd, sd, ident)
+    y.backward(dy.to(cuda).contiguous(memory_format=fmt))
+    xr, sr = x.double().requires_grad_(True), s.double().requires_grad_(True)
+    yr = xr + xr * sr if ident else xr * sr
+    yr.backward(dy.double())
+    n = shape[2] * shape[3]
+    if dtype == torch.float32:
+        torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sd.grad.cpu().double(), sr.grad, rtol=1e-4, atol=1e-4 * n ** 0.5)
+    else:
+        torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(sd.grad.cpu().double(), sr.grad, rtol=2e-2, atol=2e-2 * n ** 0.5)

@@ -571,9 +571,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_mixed(
 }
 
 // =========================================================================
-// per-channel tail kernels: block = 32 channels x 8 slice-lanes, fp64, fixed order
+// per-channel tail kernels: block = 32 channels x 32 slice-lanes, fp64, fixed order
 // =========================================================================
-constexpr int kTc = 32, kTs = 8;
+constexpr int kTc = 32, kTs = 32;
 
 __device__ __forceinline__ void tail_sums(const float* __restrict__ partial, int S, int64_t C,
                                           double& t1, double& t2, bool& owner, int64_t& c) {

@@ -126,6 +126,120 @@ __global__ __launch_bounds__(kT) void gap_bwd_nchw(const T* __restrict__ dout, i
   for (int64_t i = (int64_t)threadIdx.x * V; i < HW; i += (int64_t)kT * V) p.store(b + i);
 }
 
+// ---- channel gate: y = x * s[n,c] (+ x)  -------------------------------------------
+// The squeeze-excite multiply of AttentionRefinement (`fm * fm_se`, seg_oprs.py:209-210)
+// and FeatureFusion (`fm + fm * fm_se`, seg_oprs.py:236-237).  Eager PyTorch runs the
+// backward as 3 element-wise kernels plus a strided reduce (520 us for the FFM map);
+// here backward is ONE pass: dx = dy*s (+dy) written while ds[n,c] = sum_p dy*x is
+// accumulated (fixed-order partials).
+template <typename T, int V, bool IDENT>
+__global__ __launch_bounds__(kT) void cs_fwd_nhwc(const T* __restrict__ x, const T* __restrict__ s,
+                                                  T* __restrict__ y, int64_t HW, int64_t C) {
+  const int64_t G = C / V, n = blockIdx.y, total = HW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int64_t g = i % G;
+    PV<T, V> px, ps;
+    px.load(x + n * HW * C + i * V);
+    ps.load(s + n * C + g * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) px.v[j] = IDENT ? fmaf(px.v[j], ps.v[j], px.v[j]) : px.v[j] * ps.v[j];
+    px.store(y + n * HW * C + i * V);
+  }
+}
+
+template <typename T, int V, bool IDENT>
+__global__ __launch_bounds__(kT) void cs_fwd_nchw(const T* __restrict__ x, const T* __restrict__ s,
+                                                  T* __restrict__ y, int64_t HW) {
+  const float g = ld1<T>(s + blockIdx.x);
+  const int64_t off = (int64_t)blockIdx.x * HW;
+  for (int64_t i = (int64_t)threadIdx.x * V; i < HW; i += (int64_t)kT * V) {
+    PV<T, V> px;
+    px.load(x + off + i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) px.v[j] = IDENT ? fmaf(px.v[j], g, px.v[j]) : px.v[j] * g;
+    px.store(y + off + i);
+  }
+}
+
+template <typename T, int V, bool IDENT>
+__global__ __launch_bounds__(kT) void cs_bwd_nhwc(const T* __restrict__ dy, const T* __restrict__ x,
+                                                  const T* __restrict__ s, T* __restrict__ dx, int64_t HW,
+                                                  int64_t C, int GT, int R, int64_t rpb, int S,
+                                                  float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [R][GT*V]
+  const int tid = threadIdx.x, gl = tid % GT, r = tid / GT;
+  const int64_t n = blockIdx.y;
+  const int64_t row0 = (int64_t)blockIdx.x * rpb;
+  int64_t row1 = row0 + rpb;
+  if (row1 > HW) row1 = HW;
+  const int G = (int)(C / V);
+  for (int gb = 0; gb < G; gb += GT) {
+    const int g = gb + gl;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (r < R && g < G) {
+      PV<T, V> ps;
+      ps.load(s + n * C + (int64_t)g * V);
+      const int64_t base = n * HW * C + (int64_t)g * V;
+      for (int64_t row = row0 + r; row < row1; row += (int64_t)kU * R) {
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+          const int64_t rr = row + (int64_t)k * R;
+          if (rr < row1) {
+            PV<T, V> pd, px;
+            pd.load(dy + base + rr * C);
+            px.load(x + base + rr * C);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              acc[j] = fmaf(pd.v[j], px.v[j], acc[j]);
+              px.v[j] = IDENT ? fmaf(pd.v[j], ps.v[j], pd.v[j]) : pd.v[j] * ps.v[j];
+            }
+            px.store(dx + base + rr * C);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (r < R && g < G) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) sm[r * (GT * V) + gl * V + j] = acc[j];
+    }
+    __syncthreads();
+    for (int t = tid; t < GT * V; t += kT) {
+      const int64_t c = (int64_t)gb * V + t;
+      if (c < C) {
+        float a = 0.f;
+        for (int q = 0; q < R; ++q) a += sm[q * (GT * V) + t];
+        partial[(n * S + blockIdx.x) * C + c] = a;
+      }
+    }
+  }
+}
+
+template <typename T, int V, bool IDENT>
+__global__ __launch_bounds__(kT) void cs_bwd_nchw(const T* __restrict__ dy, const T* __restrict__ x,
+                                                  const T* __restrict__ s, T* __restrict__ dx,
+                                                  T* __restrict__ ds, int64_t HW) {
+  __shared__ float sm[2 * (kT / 64)];
+  const float g = ld1<T>(s + blockIdx.x);
+  const int64_t off = (int64_t)blockIdx.x * HW;
+  float acc = 0.f, dummy = 0.f;
+  for (int64_t i = (int64_t)threadIdx.x * V; i < HW; i += (int64_t)kT * V) {
+    PV<T, V> pd, px;
+    pd.load(dy + off + i);
+    px.load(x + off + i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      acc = fmaf(pd.v[j], px.v[j], acc);
+      px.v[j] = IDENT ? fmaf(pd.v[j], g, pd.v[j]) : pd.v[j] * g;
+    }
+    px.store(dx + off + i);
+  }
+  block_sum2(acc, dummy, sm);
+  if (threadIdx.x == 0) st1<T>(ds + blockIdx.x, acc);
+}
+
 struct GapGeom { int gt, R, S; int64_t rpb; };
 static GapGeom gap_geom(int64_t N, int64_t C, int64_t HW, int V) {
   GapGeom g;
@@ -231,6 +345,78 @@ int tsg_gap_bwd(const void* dout, void* dx, int dtype, int layout, int64_t N, in
   if (dtype == TSG_F32) { if (V == 4) GO(float, 4); else GO(float, 1); }
   else { if (V == 8) GO(bf16_t, 8); else GO(bf16_t, 1); }
 #undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+
+int tsg_chanscale_fwd(const void* x, const void* s, void* y, int dtype, int layout, int64_t N, int64_t C,
+                      int64_t HW, int add_identity, void* stream) {
+  if (!x || !s || !y) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int native = dtype == TSG_BF16 ? 8 : 4;
+  if (layout == TSG_NCHW) {
+    const bool vec = HW % native == 0 && aligned16(x) && aligned16(y);
+    dim3 grid((unsigned)(N * C));
+#define GO(T, VV, I) hipLaunchKernelGGL((cs_fwd_nchw<T, VV, I>), grid, dim3(kT), 0, st, (const T*)x, (const T*)s, (T*)y, HW)
+    if (dtype == TSG_F32) { if (vec) { if (add_identity) GO(float, 4, true); else GO(float, 4, false); } else { if (add_identity) GO(float, 1, true); else GO(float, 1, false); } }
+    else { if (vec) { if (add_identity) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); } else { if (add_identity) GO(bf16_t, 1, true); else GO(bf16_t, 1, false); } }
+#undef GO
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (layout != TSG_NHWC) return TSG_E_LAYOUT;
+  const bool vec = C % native == 0 && aligned16(x) && aligned16(y) && aligned16(s);
+  const int V = vec ? native : 1;
+  int64_t gx = (HW * (C / V) + kT - 1) / kT;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, (unsigned)N);
+#define GO(T, VV, I) hipLaunchKernelGGL((cs_fwd_nhwc<T, VV, I>), grid, dim3(kT), 0, st, (const T*)x, (const T*)s, (T*)y, HW, C)
+  if (dtype == TSG_F32) { if (vec) { if (add_identity) GO(float, 4, true); else GO(float, 4, false); } else { if (add_identity) GO(float, 1, true); else GO(float, 1, false); } }
+  else { if (vec) { if (add_identity) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); } else { if (add_identity) GO(bf16_t, 1, true); else GO(bf16_t, 1, false); } }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_chanscale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int dtype, int layout,
+                      int64_t N, int64_t C, int64_t HW, int add_identity, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!dy || !x || !s || !dx || !ds || !ws) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_gap_ws_bytes(layout, N, C, HW)) return TSG_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  const int native = dtype == TSG_BF16 ? 8 : 4;
+  if (layout == TSG_NCHW) {
+    const bool vec = HW % native == 0 && aligned16(x) && aligned16(dy) && aligned16(dx);
+    dim3 grid((unsigned)(N * C));
+#define GO(T, VV, I) hipLaunchKernelGGL((cs_bwd_nchw<T, VV, I>), grid, dim3(kT), 0, st, (const T*)dy, (const T*)x, (const T*)s, (T*)dx, (T*)ds, HW)
+    if (dtype == TSG_F32) { if (vec) { if (add_identity) GO(float, 4, true); else GO(float, 4, false); } else { if (add_identity) GO(float, 1, true); else GO(float, 1, false); } }
+    else { if (vec) { if (add_identity) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); } else { if (add_identity) GO(bf16_t, 1, true); else GO(bf16_t, 1, false); } }
+#undef GO
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (layout != TSG_NHWC) return TSG_E_LAYOUT;
+  const bool vec = C % native == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(s);
+  const int V = vec ? native : 1;
+  GapGeom g = gap_geom(N, C, HW, V);
+  dim3 grid((unsigned)g.S, (unsigned)N);
+  const size_t sh = (size_t)g.R * g.gt * V * sizeof(float);
+#define GO(T, VV, I) hipLaunchKernelGGL((cs_bwd_nhwc<T, VV, I>), grid, dim3(kT), sh, st, (const T*)dy, (const T*)x, (const T*)s, \
+                                        (T*)dx, HW, C, g.gt, g.R, g.rpb, g.S, (float*)ws)
+  if (dtype == TSG_F32) { if (vec) { if (add_identity) GO(float, 4, true); else GO(float, 4, false); } else { if (add_identity) GO(float, 1, true); else GO(float, 1, false); } }
+  else { if (vec) { if (add_identity) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); } else { if (add_identity) GO(bf16_t, 1, true); else GO(bf16_t, 1, false); } }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  const int64_t NC = N * C;
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((gap_finish<float>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, 1.f, (float*)ds);
+  else
+    hipLaunchKernelGGL((gap_finish<bf16_t>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, 1.f, (bf16_t*)ds);
   TSG_CHECK_LAUNCH();
   return 0;
 }

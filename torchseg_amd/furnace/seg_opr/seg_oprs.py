@@ -10,7 +10,7 @@ nn.BatchNorm2d for the CPU plumbing config) takes the plain module sequence.
 import torch
 import torch.nn as nn
 
-from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool
+from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool, channel_scale
 from torchseg_amd.syncbn import SyncBatchNorm as _FusedBN
 
 
@@ -177,7 +177,7 @@ class AttentionRefinement(nn.Module):
 
     def forward(self, x):
         fm = self.conv_3x3(x)
-        return fm * self.channel_attention(fm)
+        return channel_scale(fm, self.channel_attention(fm))
 
 
 class FeatureFusion(nn.Module):
@@ -197,4 +197,4 @@ class FeatureFusion(nn.Module):
 
     def forward(self, x1, x2):
         fm = self.conv_1x1(torch.cat([x1, x2], dim=1))
-        return fm + fm * self.channel_attention(fm)
+        return channel_scale(fm, self.channel_attention(fm), add_identity=True)

@@ -173,6 +173,22 @@ class HipKernels:
                                      L.stream_ptr(dout)), "tsg_gap_bwd")
         return dx
 
+    def chanscale_fwd(self, x, s, layout, N, Cc, HW, add_identity):
+        y = torch.empty_like(x)
+        L.check(self.lib.tsg_chanscale_fwd(x.data_ptr(), s.data_ptr(), y.data_ptr(), L.dtype_code(x), layout,
+                                           N, Cc, HW, int(add_identity), L.stream_ptr(x)), "tsg_chanscale_fwd")
+        return y
+
+    def chanscale_bwd(self, dy, x, s, layout, N, Cc, HW, add_identity):
+        wsb = self.lib.tsg_gap_ws_bytes(layout, N, Cc, HW)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        ds = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
+        L.check(self.lib.tsg_chanscale_bwd(dy.data_ptr(), x.data_ptr(), s.data_ptr(), dx.data_ptr(), ds.data_ptr(),
+                                           L.dtype_code(x), layout, N, Cc, HW, int(add_identity), ws.data_ptr(),
+                                           ws.numel(), L.stream_ptr(x)), "tsg_chanscale_bwd")
+        return dx, ds
+
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
@@ -349,6 +365,8 @@ _ALGO_BYTES = {
     "bn_apply_fwd_mixed": lambda a, r: 2 * _nbytes(a[0]),
     "bn_bwd_reduce_mixed": lambda a, r: 2 * _nbytes(a[0]),
     "bn_bwd_apply_mixed": lambda a, r: 3 * _nbytes(a[0]),
+    "chanscale_fwd": lambda a, r: 2 * _nbytes(a[0]),
+    "chanscale_bwd": lambda a, r: 3 * _nbytes(a[0]),
     "gap_fwd": lambda a, r: _nbytes(a[0]),
     "gap_bwd": lambda a, r: _nbytes(r),
 }

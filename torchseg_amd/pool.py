@@ -48,3 +48,39 @@ class GlobalAvgPool(nn.AdaptiveAvgPool2d):
         if x.is_cuda and x.dim() == 4 and one and x.dtype in (torch.float32, torch.bfloat16):
             return global_avg_pool(x)
         return super().forward(x)
+
+
+class _ChanScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, add_identity):
+        kp = K.provider()
+        lay = K.bn_layout(x)
+        if lay is None:
+            x = x.contiguous()
+            lay = K.bn_layout(x)
+        layout, N, C, HW = lay
+        s2 = s.reshape(N, C).to(x.dtype).contiguous()
+        ctx.save_for_backward(x, s2)
+        ctx.cfg = (layout, N, C, HW, bool(add_identity), s.shape, s.dtype)
+        return kp.chanscale_fwd(x, s2, layout, N, C, HW, add_identity)
+
+    @staticmethod
+    def backward(ctx, dy):
+        kp = K.provider()
+        x, s2 = ctx.saved_tensors
+        layout, N, C, HW, add_identity, s_shape, s_dtype = ctx.cfg
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy.stride() != x.stride():
+            t = torch.empty_like(x)
+            t.copy_(dy)
+            dy = t
+        dx, ds = kp.chanscale_bwd(dy, x, s2, layout, N, C, HW, add_identity)
+        return dx, ds.to(s_dtype).reshape(s_shape), None
+
+
+def channel_scale(x, s, add_identity=False):
+    """x [N,C,H,W] * s [N,C,1,1] (+ x): the squeeze-excite gate of ARM / FFM."""
+    if x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16):
+        return _ChanScaleFn.apply(x, s, add_identity)
+    return x + x * s if add_identity else x * s

@@ -40,6 +40,14 @@ def _forward_any_layout(x, add, OH, OW):
 
 def _backward_any_layout(dy, IH, IW):
     kp = K.provider()
+    if IH == 1 and IW == 1 and dy.shape[2] * dy.shape[3] > 1:
+        # a 1x1 source is broadcast to every output pixel: its gradient is the plain sum
+        lay = K.bn_layout(dy)
+        if lay is None:
+            dy = dy.contiguous()
+            lay = K.bn_layout(dy)
+        layout, N, C, HW = lay
+        return (kp.gap_fwd(dy, layout, N, C, HW).float() * float(HW)).to(dy.dtype).view(N, C, 1, 1)
     if _is_cl_dense(dy) and _vec_ok(dy):
         return kp.upsample_bwd_nhwc(dy, IH, IW)
     return kp.upsample_bwd(dy.contiguous(), IH, IW)
