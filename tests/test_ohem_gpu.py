@@ -131,7 +131,7 @@ def test_ohem_selection_bit_exact_given_device_probs(cuda):
     pred, t = _make(B, C, H, W, "confident", seed=5)
     k = B * H * W // 2
     kp = K.provider()
-    loss, nll, lse, sel = kp.ohem_fwd(pred.to(cuda), t.to(cuda), 255, 0.7, k, None)
+    loss, nll, lse, sel = kp.ohem_fwd(pred.to(cuda).contiguous(), t.to(cuda), 255, 0.7, k, None)   # NCHW planar
     p_dev = torch.exp(-nll.cpu())          # same expression the kernels use, evaluated on the CPU...
     sel = sel.cpu()
     thr = sel[0:1].view(torch.float32).item()

@@ -55,3 +55,23 @@ def test_channel_scale(cuda, shape, layout, dtype, ident):
         torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=1e-2, atol=1e-2)
         torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-2, atol=1e-2)
         torch.testing.assert_close(sd.grad.cpu().double(), sr.grad, rtol=2e-2, atol=2e-2 * n ** 0.5)
+
+
+def test_bias_split_conv_matches_plain_conv(cuda):
+    import torch.nn as nn
+    from torchseg_amd.convbias import split_conv_bias
+    torch.manual_seed(0)
+    a = nn.Conv2d(32, 19, 1).to(cuda)
+    b = nn.Conv2d(32, 19, 1).to(cuda)
+    b.load_state_dict(a.state_dict())
+    assert split_conv_bias(b) == 1
+    x = torch.randn(4, 32, 24, 40, device=cuda).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(4, 19, 24, 40, device=cuda)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a(xa), b(xb)
+    ya.backward(g); yb.backward(g)
+    torch.testing.assert_close(yb, ya, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xb.grad, xa.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(b.weight.grad, a.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-4, atol=1e-3)
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())

@@ -466,9 +466,8 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_mixed(
 // Backward reduction: dy is NHWC, x is NCHW; the ReLU mask is recomputed from x
 // (stems have no fused residual).  A block walks tiles blockIdx.x, +gridDim.x, ...
 // keeping per-(channel, pixel-vector) sums in registers, then folds them once.
-constexpr int kMixedItems = 8;   // >= C * (kTP / V) / kThreads for C <= 128
-
-template <typename T, bool RELU>
+// ITEMS = ceil(C * (kTP / V) / kThreads): (channel, pixel-vector) pairs per thread
+template <typename T, bool RELU, int ITEMS>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_mixed(
     const T* __restrict__ dy, const T* __restrict__ x, int64_t C, int64_t HW, int tiles_per_img,
     int64_t total_tiles, const float* __restrict__ pk, float* __restrict__ partial) {
@@ -478,9 +477,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_mixed(
   const int tid = threadIdx.x;
   const int gpr = (int)C / V, vpr = kTP / V;
   const int items = (int)C * vpr;
-  float s1[kMixedItems], s2[kMixedItems];
+  float s1[ITEMS], s2[ITEMS];
 #pragma unroll
-  for (int k = 0; k < kMixedItems; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  for (int k = 0; k < ITEMS; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   for (int64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
     const int64_t n = t / tiles_per_img;
     const int64_t p0 = (t % tiles_per_img) * kTP;
@@ -495,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_mixed(
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kMixedItems; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
       const int it = tid + k * kThreads;
       if (it < items) {
         const int c = it / vpr, v = it - c * vpr;
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_mixed(
   __syncthreads();
   float* red = tile;                                            // reuse: [2][C][vpr]
 #pragma unroll
-  for (int k = 0; k < kMixedItems; ++k) {
+  for (int k = 0; k < ITEMS; ++k) {
     const int it = tid + k * kThreads;
     if (it < items) { red[it] = s1[k]; red[items + it] = s2[k]; }
   }
@@ -969,10 +968,14 @@ int tsg_bn_bwd_reduce_mixed(const void* dy_nhwc, const void* x_nchw, int dtype, 
   const int blocks = mixed_blocks(N, HW);
   if (rows) *rows = blocks;
   hipStream_t st = (hipStream_t)stream;
-#define GO(T, R) hipLaunchKernelGGL((bn_bwd_reduce_mixed<T, R>), dim3(blocks), dim3(kThreads), sh, st, \
-                                    (const T*)dy_nhwc, (const T*)x_nchw, C, HW, tpi, total, fwd_pack, partial)
-  if (dtype == TSG_F32) { if (relu) GO(float, true); else GO(float, false); }
-  else { if (relu) GO(bf16_t, true); else GO(bf16_t, false); }
+  const int items = (int)((C * (kTP / V) + kThreads - 1) / kThreads);   // 1..8 for C <= 128
+#define GO(T, R, I) hipLaunchKernelGGL((bn_bwd_reduce_mixed<T, R, I>), dim3(blocks), dim3(kThreads), sh, st, \
+                                       (const T*)dy_nhwc, (const T*)x_nchw, C, HW, tpi, total, fwd_pack, partial)
+#define GI(T, R) do { if (items <= 1) GO(T, R, 1); else if (items <= 2) GO(T, R, 2); else if (items <= 4) GO(T, R, 4); \
+                      else GO(T, R, 8); } while (0)
+  if (dtype == TSG_F32) { if (relu) GI(float, true); else GI(float, false); }
+  else { if (relu) GI(bf16_t, true); else GI(bf16_t, false); }
+#undef GI
 #undef GO
   TSG_CHECK_LAUNCH();
   return 0;

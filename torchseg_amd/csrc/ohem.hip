@@ -141,13 +141,13 @@ __global__ __launch_bounds__(kT) void ohem_pass_a(
     const int64_t b = p0 / HW;
     const int64_t q = p0 - b * HW;
     const T* base = logits + (b * C) * HW + q;
-    int64_t t[V];
+    int t[V];
     bool valid[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int64_t lab = Lab<LT>::get(labels, p0 + j);
       valid[j] = lab != ignore_label;
-      t[j] = valid[j] ? lab : 0;  // loss_opr.py:72
+      t[j] = valid[j] ? (int)lab : 0;  // loss_opr.py:72
     }
     float m[V], s[V], xt[V];
     {
@@ -424,13 +424,13 @@ __global__ __launch_bounds__(kT) void ohem_bwd_k(
     const int64_t q = p0 - b * HW;
     const int64_t boff = (b * C) * HW + q;
     float coef[V], ls[V];
-    int64_t t[V];
+    int t[V];
     bool any = false;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int64_t lab = Lab<LT>::get(labels, p0 + j);
       const bool valid = lab != ignore_label;
-      t[j] = valid ? lab : -1;
+      t[j] = valid ? (int)lab : -1;
       bool kept = valid;
       if (valid && branch != 2) kept = prob_of_nll(nll[p0 + j]) <= thr;
       const float w = (weight && valid) ? weight[lab] : 1.f;

@@ -246,15 +246,19 @@ __global__ void up_bwd_tiled(const T* __restrict__ dy, T* __restrict__ dx, int I
         for (int j = 0; j < V; ++j) { accA[j] += hy * g.v[j]; accB[j] += ly * g.v[j]; }
       }
     };
-    constexpr int U = 4;                           // rows in flight per thread
-    for (int oy = oy_lo; oy <= oy_hi; oy += U) {
+    constexpr int U = 8;                           // rows in flight per thread
+    int oy = oy_lo;
+    for (; oy + U - 1 <= oy_hi; oy += U) {         // full batches: U independent 16-B loads, then the math
       OutVec<T, V> g[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (oy + u <= oy_hi) g[u].load(src + (int64_t)(oy + u) * OW + tid * V);
+      for (int u = 0; u < U; ++u) g[u].load(src + (int64_t)(oy + u) * OW + tid * V);
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (oy + u <= oy_hi) absorb(oy + u, g[u]);
+      for (int u = 0; u < U; ++u) absorb(oy + u, g[u]);
+    }
+    for (; oy <= oy_hi; ++oy) {
+      OutVec<T, V> g;
+      g.load(src + (int64_t)oy * OW + tid * V);
+      absorb(oy, g);
     }
     if (cur >= 0) { flush(cur, accA); flush(cur + 1, accB); }
   }

@@ -36,6 +36,13 @@ def bn_layout(x):
     return None
 
 
+def _require_contiguous(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_contiguous():
+            raise L.TsgError("kernel wrapper needs a contiguous tensor, got strides %s for shape %s"
+                             % (tuple(t.stride()), tuple(t.shape)))
+
+
 def _label_code(t):
     if t.dtype == torch.int64:
         return L.I64
@@ -192,6 +199,7 @@ class HipKernels:
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
+        _require_contiguous(logits, labels, weight)
         B, Cc = logits.shape[0], logits.shape[1]
         HW = logits.numel() // (B * Cc)
         P = B * HW
@@ -211,6 +219,7 @@ class HipKernels:
         return loss, nll, lse, sel
 
     def ohem_bwd(self, logits, labels, ignore_label, weight, nll, lse, sel, gscale):
+        _require_contiguous(logits, labels, weight)
         B, Cc = logits.shape[0], logits.shape[1]
         HW = logits.numel() // (B * Cc)
         dlogits = torch.empty_like(logits)
@@ -230,6 +239,7 @@ class HipKernels:
         return out
 
     def focal_fwd(self, pred, target, ignore_label, gamma, alpha):
+        _require_contiguous(pred, target)
         P = pred.numel()
         wsb = self.lib.tsg_focal_ws_bytes(P)
         ws = torch.empty(wsb, dtype=torch.uint8, device=pred.device)
@@ -250,6 +260,7 @@ class HipKernels:
 
     def upsample_fwd(self, x, add, OH, OW):
         """x [N,C,IH,IW] contiguous -> [N,C,OH,OW]"""
+        _require_contiguous(x, add)
         N, Cc, IH, IW = x.shape
         y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device)
         L.check(self.lib.tsg_upsample_bilinear_ac_fwd(x.data_ptr(), L.ptr(add), y.data_ptr(),
@@ -258,6 +269,7 @@ class HipKernels:
         return y
 
     def upsample_bwd(self, dy, IH, IW):
+        _require_contiguous(dy)
         N, Cc, OH, OW = dy.shape
         dx = torch.empty((N, Cc, IH, IW), dtype=dy.dtype, device=dy.device)
         L.check(self.lib.tsg_upsample_bilinear_ac_bwd(dy.data_ptr(), dx.data_ptr(), L.dtype_code(dy),
@@ -296,6 +308,7 @@ class HipKernels:
     # ---- PSA attention -------------------------------------------------------
     def psa_fwd(self, X, A):
         """X [B,Cx,K], A [B,K,N] contiguous, same dtype -> (out [B,Cx,N], lse fp32 [B,N])"""
+        _require_contiguous(X, A)
         B, Cx, Kd = X.shape
         N = A.shape[2]
         dt = L.dtype_code(X)
@@ -308,6 +321,7 @@ class HipKernels:
         return out, lse
 
     def psa_bwd(self, X, A, out, dout, lse):
+        _require_contiguous(X, A, out, dout)
         B, Cx, Kd = X.shape
         N = A.shape[2]
         dt = L.dtype_code(X)
