@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "0")))
+    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "1")),
+                    help="torch.backends.cudnn.benchmark, as the reference sets it (train.py:35)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +119,8 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["TSG_DTYPE"] = args.dtype
+    from torchseg_amd.tuning import use_shipped_miopen_db
+    use_shipped_miopen_db(rank=rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an AMD GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)

@@ -77,6 +77,8 @@ class Engine(object):
             use_gpu = torch.cuda.is_available()
             if use_gpu:
                 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+                from torchseg_amd.tuning import use_shipped_miopen_db
+                use_shipped_miopen_db(rank=self.local_rank)
                 torch.cuda.set_device(self.local_rank)
             if not dist.is_initialized():
                 dist.init_process_group(backend="nccl" if use_gpu else "gloo", init_method='env://')
