@@ -150,10 +150,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Per-kernel timing brackets every launch with HIP events, which costs host time
+    # (~600 event records per step); it must not distort `value`.  So: the warm-up
+    # steps run fully instrumented to learn which of our kernels dominates, and the
+    # timed region instruments ONLY that kernel (~35 launches per step).
+    timer = None
+    dominant = None
     for it in range(args.warmup):
+        probe = None
+        if not args.no_kernel_timing and it == args.warmup - 1:
+            probe = K.KernelTimer(K.provider())
         loss = train_step(model, opt, imgs, gts, pol, it, world)
+        if probe is not None:
+            probe.stop()
+            dominant = probe.dominant()
+            all_kernels = probe.summary()
     sync()
-    timer = None if args.no_kernel_timing else K.KernelTimer(K.provider())
+    if dominant is not None:
+        timer = K.KernelTimer(K.provider(), names=[dominant])
     t0 = time.perf_counter()
     for it in range(args.steps):
         loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
@@ -183,7 +197,7 @@ def main():
         }
         if timer is not None:
             out["roofline"] = timer.roofline(HBM_PEAK_GBS, os.path.join(ROOT, "profiles"))
-            out["kernels"] = timer.summary()
+            out["kernels_last_warmup_step"] = all_kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

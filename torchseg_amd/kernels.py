@@ -435,8 +435,12 @@ class KernelTimer:
     def summary(self):
         return self.stats
 
+    def dominant(self):
+        """Name of the instrumented kernel with the largest total time (None if nothing ran)."""
+        return max(self.stats, key=lambda n: self.stats[n]["total_ms"]) if self.stats else None
+
     def roofline(self, peak_gbs, profiles_dir=None):
-        name = max(self.stats, key=lambda n: self.stats[n]["total_ms"])
+        name = self.dominant()
         st = self.stats[name]
         traffic = None
         if profiles_dir:
