@@ -448,7 +448,7 @@ class KernelTimer:
             import os
             f = os.path.join(profiles_dir, "traffic.json")
             if os.path.exists(f):
-                traffic = json.load(open(f)).get(name)
+                traffic = json.load(open(f)).get(name)   # PMC bytes per launch, profiles/r01_pmc_summary.txt
         return {"bound": "hbm", "kernel": name, "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
                 "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic,
                 "algo_bytes_per_launch": int(st["algo_MB_per_launch"] * 1e6), "avg_launch_us": st["avg_us"]}
