@@ -220,6 +220,27 @@ int tsg_ohem_bwd(const void* logits, int dtype, const void* labels, int ltype,
                  const float* nll, const float* lse, const int32_t* sel,
                  const float* gscale, void* dlogits, void* ws, void* stream);
 
+/* Fused head: the criterion applied to
+ *   F.interpolate(z, size=(OH,OW), mode='bilinear', align_corners=True)
+ * (bisenet network.py:104-106 with :164-166) WITHOUT materialising the
+ * full-resolution logits: z [B, C, IH, IW] is interpolated inside the OHEM
+ * kernels (forward: per-tile LDS window of z; backward: dz accumulated through
+ * the transposed taps, deterministically).  Outputs as tsg_ohem_fwd / dz [B,C,IH,IW].
+ * tsg_ohem_up_supported() != 0 when both kernels can take the shape (genuine
+ * up-sampling by >= 2 and <= 16 per axis, LDS windows fit). */
+int tsg_ohem_up_supported(int C, int IH, int IW, int OH, int OW, float thresh);
+int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype,
+                    int64_t B, int C, int IH, int IW, int OH, int OW,
+                    int64_t ignore_label, float thresh, int64_t min_kept,
+                    const float* weight,
+                    float* nll, float* lse, float* loss, int32_t* sel,
+                    void* ws, size_t ws_bytes, void* stream);
+int tsg_ohem_up_bwd(const void* z, int dtype, const void* labels, int ltype,
+                    int64_t B, int C, int IH, int IW, int OH, int OW,
+                    int64_t ignore_label, const float* weight,
+                    const float* nll, const float* lse, const int32_t* sel,
+                    const float* gscale, void* dz, void* stream);
+
 /* Exact k-th order statistic of non-negative floats by radix select on their
  * IEEE bit patterns — what torch.sort(mask_prob)[k-1] returns
  * (loss_opr.py:86-88).  out[0] receives the value.  k is 1-based. */

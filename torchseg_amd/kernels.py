@@ -229,6 +229,39 @@ class HipKernels:
                                       dlogits.data_ptr(), None, L.stream_ptr(logits)), "tsg_ohem_bwd")
         return dlogits
 
+    def ohem_up_supported(self, z, OH, OW, thresh):
+        return bool(self.lib.tsg_ohem_up_supported(z.shape[1], z.shape[2], z.shape[3], int(OH), int(OW), float(thresh)))
+
+    def ohem_up_fwd(self, z, labels, OH, OW, ignore_label, thresh, min_kept, weight):
+        """z [B,C,IH,IW] contiguous low-res logits, labels [B,OH,OW] -> as ohem_fwd"""
+        _require_contiguous(z, labels, weight)
+        B, Cc, IH, IW = z.shape
+        P = B * OH * OW
+        dev = z.device
+        plan = L.OhemPlan()
+        L.check(self.lib.tsg_ohem_make_plan(B, Cc, OH * OW, float(thresh), C.byref(plan)), "tsg_ohem_make_plan")
+        ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+        nll = torch.empty(P, dtype=torch.float32, device=dev)
+        lse = torch.empty(P, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        sel = torch.empty(8, dtype=torch.int32, device=dev)
+        L.check(self.lib.tsg_ohem_up_fwd(z.data_ptr(), L.dtype_code(z), labels.data_ptr(), _label_code(labels),
+                                         B, Cc, IH, IW, int(OH), int(OW), int(ignore_label), float(thresh),
+                                         int(min_kept), L.ptr(weight), nll.data_ptr(), lse.data_ptr(),
+                                         loss.data_ptr(), sel.data_ptr(), ws.data_ptr(), plan.ws_bytes,
+                                         L.stream_ptr(z)), "tsg_ohem_up_fwd")
+        return loss, nll, lse, sel
+
+    def ohem_up_bwd(self, z, labels, OH, OW, ignore_label, weight, nll, lse, sel, gscale):
+        _require_contiguous(z, labels, weight)
+        B, Cc, IH, IW = z.shape
+        dz = torch.empty_like(z)
+        L.check(self.lib.tsg_ohem_up_bwd(z.data_ptr(), L.dtype_code(z), labels.data_ptr(), _label_code(labels),
+                                         B, Cc, IH, IW, int(OH), int(OW), int(ignore_label), L.ptr(weight),
+                                         nll.data_ptr(), lse.data_ptr(), sel.data_ptr(), gscale.data_ptr(),
+                                         dz.data_ptr(), L.stream_ptr(z)), "tsg_ohem_up_bwd")
+        return dz
+
     def kth_value(self, v, k):
         n = v.numel()
         wsb = self.lib.tsg_kth_ws_bytes(n)
@@ -372,6 +405,8 @@ _ALGO_BYTES = {
     "bn_bwd_apply": lambda a, r: 3 * _nbytes(a[0]) + _nbytes(a[2]) + (_nbytes(a[0]) if a[9] else 0),
     "ohem_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "ohem_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
+    "ohem_up_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
+    "ohem_up_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "upsample_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "upsample_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "upsample_fwd_nhwc": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),

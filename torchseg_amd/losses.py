@@ -42,12 +42,45 @@ class _OhemCEFn(torch.autograd.Function):
         return dpred, None, None, None, None, None
 
 
+class _OhemUpCEFn(torch.autograd.Function):
+    """criterion(F.interpolate(z)) with the interpolation evaluated inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, z, target, OH, OW, ignore_label, thresh, min_kept, weight):
+        kp = K.provider()
+        z = z.contiguous()
+        target = target.contiguous()
+        loss, nll, lse, sel = kp.ohem_up_fwd(z, target, OH, OW, ignore_label, thresh, min_kept, weight)
+        ctx.save_for_backward(z, target, nll, lse, sel, weight)
+        ctx.cfg = (OH, OW, ignore_label)
+        ctx.mark_non_differentiable(sel)
+        return loss.reshape(()), sel
+
+    @staticmethod
+    def backward(ctx, gloss, _gsel):
+        kp = K.provider()
+        z, target, nll, lse, sel, weight = ctx.saved_tensors
+        OH, OW, ignore_label = ctx.cfg
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        dz = kp.ohem_up_bwd(z, target, OH, OW, ignore_label, weight, nll, lse, sel, g)
+        return dz, None, None, None, None, None, None, None
+
+
 def ohem_cross_entropy(pred, target, ignore_label=255, thresh=0.7, min_kept=0, weight=None,
                        return_selection=False):
     """Functional form.  pred [B,C,H,W] (f32/bf16), target [B,H,W] (int64/uint8).
 
     selection (int32[8], on device) = {thr bits, n_kept, num_valid, branch, denom bits, ...}.
     """
+    from .upsample import DeferredUpsample
+    if isinstance(pred, DeferredUpsample):
+        OH, OW = pred.out_hw
+        z = pred.z
+        if (target.dim() == 3 and tuple(target.shape) == (z.shape[0], OH, OW)
+                and K.provider().ohem_up_supported(z, OH, OW, thresh)):
+            loss, sel = _OhemUpCEFn.apply(z, target, OH, OW, int(ignore_label), float(thresh), int(min_kept), weight)
+            return (loss, sel) if return_selection else loss
+        pred = pred.materialize()
     if pred.dim() != 4 or target.dim() != 3:
         raise ValueError("expected pred [B,C,H,W] and target [B,H,W]")
     if pred.shape[0] != target.shape[0] or pred.shape[2:] != target.shape[1:]:

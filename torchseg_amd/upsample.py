@@ -125,3 +125,109 @@ def install_aten_overrides():
         lib.impl("upsample_bilinear2d_backward", bwd, "CUDA")
         lib.impl("upsample_bilinear2d", fwd_autocast, "AutocastCUDA")
     _lib_handle = lib
+
+
+class DeferredUpsample(object):
+    """`F.interpolate(z, ..., mode='bilinear', align_corners=True)` that has not been
+    evaluated yet.  Our criterion consumes it directly (fused upsample + OHEM, the
+    full-resolution logits never exist); ANY other use materialises it through
+    the normal differentiable kernel, so semantics are unchanged."""
+
+    def __init__(self, z, out_hw):
+        self.z = z
+        self.out_hw = (int(out_hw[0]), int(out_hw[1]))
+        self._value = None
+
+    def materialize(self):
+        if self._value is None:
+            self._value = _UpFn.apply(self.z, None, *self.out_hw)
+        return self._value
+
+    # cheap metadata without materialising
+    @property
+    def shape(self):
+        return torch.Size((self.z.shape[0], self.z.shape[1]) + self.out_hw)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 4
+
+    @property
+    def dtype(self):
+        return self.z.dtype
+
+    @property
+    def device(self):
+        return self.z.device
+
+    @property
+    def is_cuda(self):
+        return self.z.is_cuda
+
+    @property
+    def requires_grad(self):
+        return self.z.requires_grad
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(v):
+            if isinstance(v, cls):
+                return v.materialize()
+            if isinstance(v, (list, tuple)):
+                return type(v)(unwrap(u) for u in v)
+            return v
+        return func(*unwrap(tuple(args)), **{k: unwrap(v) for k, v in (kwargs or {}).items()})
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.z.shape[0]
+
+    def __repr__(self):
+        return "DeferredUpsample(z=%s -> %s)" % (tuple(self.z.shape), self.out_hw)
+
+
+def _binary(name):
+    def op(self, other):
+        other = other.materialize() if isinstance(other, DeferredUpsample) else other
+        return getattr(self.materialize(), name)(other)
+    return op
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__"):
+    setattr(DeferredUpsample, _n, _binary(_n))
+DeferredUpsample.__neg__ = lambda self: -self.materialize()
+
+_orig_interpolate = None
+
+
+def install_deferred_interpolate(min_scale=4):
+    """Wrap torch.nn.functional.interpolate (looked up at call time as `F.interpolate`
+    by the reference's network.py files) so that a bilinear align_corners=True
+    up-sampling by >= min_scale of a HIP tensor returns a DeferredUpsample.
+    Idempotent; everything else goes to the original function untouched."""
+    global _orig_interpolate
+    import torch.nn.functional as F
+    if _orig_interpolate is not None:
+        return
+    _orig_interpolate = F.interpolate
+
+    def interpolate(input, size=None, scale_factor=None, mode='nearest', align_corners=None,
+                    recompute_scale_factor=None, antialias=False):
+        if (mode == 'bilinear' and align_corners and not antialias and isinstance(input, torch.Tensor)
+                and input.is_cuda and input.dim() == 4 and input.dtype in (torch.float32, torch.bfloat16)):
+            OH, OW = _out_size(input, size, scale_factor)
+            if OH >= min_scale * input.shape[2] and OW >= min_scale * input.shape[3]:
+                return DeferredUpsample(input, (OH, OW))
+        return _orig_interpolate(input, size=size, scale_factor=scale_factor, mode=mode,
+                                 align_corners=align_corners, recompute_scale_factor=recompute_scale_factor,
+                                 antialias=antialias)
+
+    F.interpolate = interpolate
+    torch.nn.functional.interpolate = interpolate
