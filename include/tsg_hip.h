@@ -226,9 +226,12 @@ int tsg_ohem_bwd(const void* logits, int dtype, const void* labels, int ltype,
  * full-resolution logits: z [B, C, IH, IW] is interpolated inside the OHEM
  * kernels (forward: per-tile LDS window of z; backward: dz accumulated through
  * the transposed taps, deterministically).  Outputs as tsg_ohem_fwd / dz [B,C,IH,IW].
- * tsg_ohem_up_supported() != 0 when both kernels can take the shape (genuine
- * up-sampling by >= 2 and <= 16 per axis, LDS windows fit). */
+ * tsg_ohem_up_supported() != 0 when the kernels can take the shape (C <= 32,
+ * genuine up-sampling by >= 2 and <= ~16 per axis).  The backward needs a
+ * workspace of tsg_ohem_up_bwd_ws_bytes() (the vertically reduced gradient
+ * V[B,C,IH,OW] in fp32). */
 int tsg_ohem_up_supported(int C, int IH, int IW, int OH, int OW, float thresh);
+size_t tsg_ohem_up_bwd_ws_bytes(int64_t B, int C, int IH, int OW);
 int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype,
                     int64_t B, int C, int IH, int IW, int OH, int OW,
                     int64_t ignore_label, float thresh, int64_t min_kept,
@@ -239,7 +242,8 @@ int tsg_ohem_up_bwd(const void* z, int dtype, const void* labels, int ltype,
                     int64_t B, int C, int IH, int IW, int OH, int OW,
                     int64_t ignore_label, const float* weight,
                     const float* nll, const float* lse, const int32_t* sel,
-                    const float* gscale, void* dz, void* stream);
+                    const float* gscale, void* dz,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* Exact k-th order statistic of non-negative floats by radix select on their
  * IEEE bit patterns — what torch.sort(mask_prob)[k-1] returns

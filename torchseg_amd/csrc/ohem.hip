@@ -481,301 +481,241 @@ __global__ __launch_bounds__(kT) void ohem_bwd_k(
 // evaluated INSIDE the OHEM kernels, so the full-resolution logits (59.8 M
 // elements per image for BiSeNet's three heads) are never written or re-read
 // (SURVEY.md §8f-1).  z is [B, C, IH, IW]; the virtual logits are [B, C, OH, OW].
+//
+// Both directions are "column walkers": a thread owns ONE output column ox and
+// walks down a band of output rows.  For its column it keeps, per class, the two
+// horizontally interpolated source rows H0[c] / H1[c] (rows y0 / y1) in registers;
+// they change only when y0 advances (every ~scale output rows), so per pixel and
+// class the logit costs 2 FMAs:  v_c = (1-ly)*H0[c] + ly*H1[c]   — the same
+// operations, in the same order, as the 4-tap formula of aten::upsample_bilinear2d.
+// z itself is tiny (L2-resident) and read with wave-broadcast loads.
+//   forward : per pixel max / sum-exp over the C register values (1 exp per class),
+//             then the shared pass-A accounting.  HBM: label read + nll/lse write.
+//   backward: g_c = coef*(softmax_c - [c==t]) is folded straight into the vertical
+//             transposed taps (accA/accB per class, flushed when a source row is
+//             complete) -> V[B,C,IH,OW] fp32; a small second kernel applies the
+//             horizontal transposed taps.  No atomics, fixed order => deterministic.
 // =============================================================================
-constexpr int kFTX = 64, kFTY = 16;          // forward tile: 64 x 16 full-resolution pixels
+constexpr int kFwdBand = 32;                 // output rows per forward band
+constexpr int kBwdCH = 8;                    // source rows owned by a backward block
 
-// forward: per block-tile, stage the touched low-res window of every class in LDS
-// ([C][RH][RW] floats), then every thread interpolates its 4 pixels class by class
-// (4 LDS reads + 3 lerps) feeding the same online softmax / accounting as pass A.
-template <typename T, int LT>
+template <typename T, int CMAX>
+__device__ __forceinline__ void load_hrow(const T* __restrict__ zb, int C, int64_t plane, int IW, int y,
+                                          int x0, int x1, float lx, float (&H)[CMAX]) {
+  const float hx = 1.f - lx;
+  const T* r = zb + (int64_t)y * IW;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) H[c] = hx * ld1<T>(r + c * plane + x0) + lx * ld1<T>(r + c * plane + x1);
+}
+
+template <typename T, int LT, int CMAX>
 __global__ __launch_bounds__(kT) void ohem_up_pass_a(
     const T* __restrict__ z, const void* __restrict__ labels, int64_t B, int C, int IH, int IW,
-    int OH, int OW, float sy, float sx, int RH, int RW, int64_t ignore_label, float thresh,
-    int64_t tb, int shift0, int bins0, const float* __restrict__ weight,
-    float* __restrict__ nll_out, float* __restrict__ lse_out, uint32_t* __restrict__ hist0,
-    BlkPart* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lh[];   // [bins0] then zt
-  float* zt = reinterpret_cast<float*>(lh + ((bins0 + 3) & ~3));
+    int OH, int OW, float sy, float sx, int64_t ignore_label, float thresh, int64_t tb, int shift0,
+    int bins0, const float* __restrict__ weight, float* __restrict__ nll_out,
+    float* __restrict__ lse_out, uint32_t* __restrict__ hist0, BlkPart* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
   const int tid = threadIdx.x;
   for (int i = tid; i < bins0; i += kT) lh[i] = 0;
+  __syncthreads();
   PassAcc acc;
-  const int tiles_x = (OW + kFTX - 1) / kFTX, tiles_y = (OH + kFTY - 1) / kFTY;
-  const int64_t total = B * tiles_y * (int64_t)tiles_x;
-  const int prow = tid / (kFTX / 4), pxg = tid % (kFTX / 4);     // 16 rows x 16 groups of 4 pixels
-  const int plane = RH * RW;
+  const int xblocks = (OW + kT - 1) / kT, bands = (OH + kFwdBand - 1) / kFwdBand;
+  const int64_t total = B * bands * (int64_t)xblocks;
+  const int64_t plane = (int64_t)IH * IW;
   for (int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
-    const int tx = (int)(tile % tiles_x);
-    const int ty = (int)((tile / tiles_x) % tiles_y);
-    const int64_t b = tile / ((int64_t)tiles_x * tiles_y);
-    const int oy_first = ty * kFTY, ox_first = tx * kFTX;
-    int Y0, X0, dum; float fd;
-    src_index(sy, oy_first, IH, Y0, dum, fd);
-    src_index(sx, ox_first, IW, X0, dum, fd);
-    __syncthreads();                                             // previous tile done with zt / lh init visible
-    for (int i = tid; i < C * plane; i += kT) {
-      const int c = i / plane, r = i - c * plane;
-      const int ry = r / RW, rx = r - ry * RW;
-      int yy = Y0 + ry; yy = yy > IH - 1 ? IH - 1 : yy;
-      int xx = X0 + rx; xx = xx > IW - 1 ? IW - 1 : xx;
-      zt[i] = ld1<T>(z + ((b * C + c) * IH + yy) * (int64_t)IW + xx);
-    }
-    __syncthreads();
-    const int oy = oy_first + prow;
-    const int ox0 = ox_first + pxg * 4;
-    if (oy < OH && ox0 < OW) {
+    const int xb = (int)(tile % xblocks);
+    const int band = (int)((tile / xblocks) % bands);
+    const int64_t b = tile / ((int64_t)xblocks * bands);
+    const int ox = xb * kT + tid;
+    if (ox >= OW) continue;
+    int x0, x1; float lx;
+    src_index(sx, ox, IW, x0, x1, lx);
+    const T* zb = z + b * C * plane;
+    float H0[CMAX], H1[CMAX];
+    int cy0 = -1, cy1 = -1;
+    const int oy_end = (band + 1) * kFwdBand < OH ? (band + 1) * kFwdBand : OH;
+    for (int oy = band * kFwdBand; oy < oy_end; ++oy) {
       int y0, y1; float ly;
       src_index(sy, oy, IH, y0, y1, ly);
+      if (y0 != cy0) {
+        if (y0 == cy1) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) H0[c] = H1[c];
+        } else {
+          load_hrow<T, CMAX>(zb, C, plane, IW, y0, x0, x1, lx, H0);
+        }
+        cy0 = y0; cy1 = -1;
+      }
+      if (y1 != cy1) {
+        if (y1 == cy0) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) H1[c] = H0[c];
+        } else {
+          load_hrow<T, CMAX>(zb, C, plane, IW, y1, x0, x1, lx, H1);
+        }
+        cy1 = y1;
+      }
+      const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
+      const int64_t lab = Lab<LT>::get(labels, gp);
+      const bool valid = lab != ignore_label;
+      const int t = valid ? (int)lab : 0;
       const float hy = 1.f - ly;
-      const int r0 = (y0 - Y0) * RW, r1 = (y1 - Y0) * RW;
-      int o00[4], o01[4], t[4];
-      float lx[4];
-      bool inb[4], valid[4];
-      const int64_t p0 = (b * OH + oy) * (int64_t)OW + ox0;
+      float v[CMAX];
+      float m = -INFINITY, xt = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        inb[j] = ox0 + j < OW;
-        int x0, x1;
-        src_index(sx, inb[j] ? ox0 + j : OW - 1, IW, x0, x1, lx[j]);
-        o00[j] = x0 - X0; o01[j] = x1 - X0;
-        const int64_t lab = inb[j] ? Lab<LT>::get(labels, p0 + j) : ignore_label;
-        valid[j] = lab != ignore_label;
-        t[j] = valid[j] ? (int)lab : 0;
-      }
-      float m[4], sacc[4], xt[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { m[j] = -INFINITY; sacc[j] = 0.f; xt[j] = 0.f; }
-      for (int c = 0; c < C; ++c) {
-        const float* pz = zt + c * plane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float hx = 1.f - lx[j];
-          const float top = hx * pz[r0 + o00[j]] + lx[j] * pz[r0 + o01[j]];
-          const float bot = hx * pz[r1 + o00[j]] + lx[j] * pz[r1 + o01[j]];
-          const float x = hy * top + ly * bot;
-          if (t[j] == c) xt[j] = x;
-          const float mn = fmaxf(m[j], x);
-          sacc[j] = sacc[j] * __expf(m[j] - mn) + __expf(x - mn);
-          m[j] = mn;
+      for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+          v[c] = hy * H0[c] + ly * H1[c];
+          m = fmaxf(m, v[c]);
+          if (c == t) xt = v[c];
         }
       }
+      float ssum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (inb[j]) {
-          const float ls = m[j] + logf(sacc[j]);
-          float nl = ls - xt[j];
-          nl = nl < 0.f ? 0.f : nl;
-          nl = valid[j] ? nl : 0.f;
-          nll_out[p0 + j] = nl;
-          lse_out[p0 + j] = ls;
-          const float w = (weight && valid[j]) ? weight[t[j]] : 1.f;
-          account(acc, valid[j], nl, w, thresh, tb, shift0, bins0, lh);
-        }
-      }
+      for (int c = 0; c < CMAX; ++c)
+        if (c < C) ssum += __expf(v[c] - m);
+      const float ls = m + logf(ssum);
+      float nl = ls - xt;
+      nl = nl < 0.f ? 0.f : nl;
+      nl = valid ? nl : 0.f;
+      nll_out[gp] = nl;
+      lse_out[gp] = ls;
+      const float w = (weight && valid) ? weight[t] : 1.f;
+      account(acc, valid, nl, w, thresh, tb, shift0, bins0, lh);
     }
   }
   fold_block(acc, lh, bins0, hist0, part);
 }
 
-// backward: a block owns CH x CW low-res cells of one image and produces dz for all
-// C classes of them.  Classes are processed CHUNK at a time:
-//   phase 1  every thread evaluates g_c = coef * (softmax_c - [c == t]) for its (<= KP)
-//            full-res pixels of the block's footprint region (interpolating the logit
-//            from the LDS copy of z) -> gbuf[CHUNK][region]
-//   phase 2a horizontal taps:  hsum[c][row][ix] = sum_ox wx(ox, ix) * g[c][row][ox]
-//   phase 2b vertical taps:    dz[c][iy][ix]    = sum_row wy(row, iy) * hsum[c][row][ix]
-// Tap weights come from tap_weight() (bit-identical to the forward) via small LDS
-// tables; no atomics, fixed summation order => deterministic.
-constexpr int kKP = 12;        // region pixels per thread (region <= 3072)
-constexpr int kChunk = 4;
-constexpr int kMaxFoot = 40;   // taps per source index along one axis (scale factor <= 16)
-
-struct UpBwdGeom { int CH, CW, RHf, RWf, FY, FX; };
-
-template <typename T, int LT>
-__global__ __launch_bounds__(kT) void ohem_up_bwd_k(
+// backward, vertical part.  grid = (x-blocks, source-row bands, B); V[b][c][iy][ox] fp32.
+template <typename T, int LT, int CMAX>
+__global__ __launch_bounds__(kT) void ohem_up_bwd_v(
     const T* __restrict__ z, const void* __restrict__ labels, int C, int IH, int IW, int OH, int OW,
-    float sy, float sx, UpBwdGeom gm, int64_t ignore_label, const float* __restrict__ weight,
+    float sy, float sx, int64_t ignore_label, const float* __restrict__ weight,
     const float* __restrict__ nll, const float* __restrict__ lse, const int32_t* __restrict__ sel,
-    const float* __restrict__ gscale, T* __restrict__ dz) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int CH = gm.CH, CW = gm.CW, RHf = gm.RHf, RWf = gm.RWf;
-  const int ZH = CH + 2, ZW = CW + 2, zplane = ZH * ZW;
-  float* zt = sm;                                   // [C][ZH][ZW]
-  float* gbuf = zt + C * zplane;                    // [kChunk][RHf*RWf]
-  float* hsum = gbuf + kChunk * RHf * RWf;          // [kChunk][RHf][CW]
-  float* wyt = hsum + kChunk * RHf * CW;            // [CH][FY]
-  float* wxt = wyt + CH * gm.FY;                    // [CW][FX]
-  int* lo_y = reinterpret_cast<int*>(wxt + CW * gm.FX);   // [CH]
-  int* lo_x = lo_y + CH;                            // [CW]
-  const int tid = threadIdx.x;
-  const int tiles_x = (IW + CW - 1) / CW, tiles_y = (IH + CH - 1) / CH;
-  const int txi = blockIdx.x % tiles_x, tyi = (blockIdx.x / tiles_x) % tiles_y;
-  const int64_t b = blockIdx.x / (tiles_x * tiles_y);
-  const int r0 = tyi * CH, r1 = (r0 + CH < IH) ? r0 + CH : IH;
-  const int c0 = txi * CW, c1 = (c0 + CW < IW) ? c0 + CW : IW;
-  // footprint region of the owned cells in full-res coordinates
-  int oy_lo, oy_hi, ox_lo, ox_hi, d0, d1;
-  footprint(sy, r0, OH, oy_lo, d1); footprint(sy, r1 - 1, OH, d0, oy_hi);
-  footprint(sx, c0, OW, ox_lo, d1); footprint(sx, c1 - 1, OW, d0, ox_hi);
-  const int nrows = oy_hi - oy_lo + 1, ncols = ox_hi - ox_lo + 1, NP = nrows * ncols;
-  // stage z window [r0-1, r1] x [c0-1, c1] (clamped) and the tap-weight tables
-  for (int i = tid; i < C * zplane; i += kT) {
-    const int c = i / zplane, r = i - c * zplane;
-    int yy = r0 - 1 + r / ZW, xx = c0 - 1 + r % ZW;
-    yy = yy < 0 ? 0 : (yy > IH - 1 ? IH - 1 : yy);
-    xx = xx < 0 ? 0 : (xx > IW - 1 ? IW - 1 : xx);
-    zt[i] = ld1<T>(z + ((b * C + c) * IH + yy) * (int64_t)IW + xx);
-  }
-  for (int i = tid; i < CH * gm.FY; i += kT) {
-    const int iyl = i / gm.FY, j = i - iyl * gm.FY;
-    float w = 0.f;
-    if (r0 + iyl < r1) {
-      int lo, hi;
-      footprint(sy, r0 + iyl, OH, lo, hi);
-      if (j == 0) lo_y[iyl] = lo;
-      if (lo + j <= hi) w = tap_weight(sy, lo + j, IH, r0 + iyl);
-    } else if (j == 0) lo_y[iyl] = 0;
-    wyt[i] = w;
-  }
-  for (int i = tid; i < CW * gm.FX; i += kT) {
-    const int ixl = i / gm.FX, j = i - ixl * gm.FX;
-    float w = 0.f;
-    if (c0 + ixl < c1) {
-      int lo, hi;
-      footprint(sx, c0 + ixl, OW, lo, hi);
-      if (j == 0) lo_x[ixl] = lo;
-      if (lo + j <= hi) w = tap_weight(sx, lo + j, IW, c0 + ixl);
-    } else if (j == 0) lo_x[ixl] = 0;
-    wxt[i] = w;
-  }
-  // per-thread pixel state, kept in registers across the class chunks
+    const float* __restrict__ gscale, float* __restrict__ V) {
+  const int ox = blockIdx.x * kT + threadIdx.x;
+  if (ox >= OW) return;
+  const int r0 = blockIdx.y * kBwdCH;
+  const int r1 = (r0 + kBwdCH < IH) ? r0 + kBwdCH : IH;
+  const int64_t b = blockIdx.z;
   const float thr = __uint_as_float((uint32_t)sel[0]);
   const int branch = sel[3];
   const float g = gscale[0] / reinterpret_cast<const float*>(sel)[4];
-  float coef[kKP], lsv[kKP];
-  int tt[kKP];
-#pragma unroll
-  for (int k = 0; k < kKP; ++k) {
-    const int p = tid + k * kT;
-    coef[k] = 0.f; lsv[k] = 0.f; tt[k] = -1;
-    if (p < NP) {
-      const int oy = oy_lo + p / ncols, ox = ox_lo + p % ncols;
-      int y0, y1, x0, x1; float ly, lx;
-      src_index(sy, oy, IH, y0, y1, ly);
-      src_index(sx, ox, IW, x0, x1, lx);
-      const bool touches = !(y1 < r0 || y0 > r1 - 1 || x1 < c0 || x0 > c1 - 1);
-      if (touches) {
-        const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
-        const int64_t lab = Lab<LT>::get(labels, gp);
-        const bool valid = lab != ignore_label;
-        bool kept = valid;
-        if (valid && branch != 2) kept = prob_of_nll(nll[gp]) <= thr;
-        if (kept) {
-          coef[k] = g * (weight ? weight[lab] : 1.f);
-          lsv[k] = lse[gp];
-          tt[k] = (int)lab;
-        }
-      }
-    }
+  const int64_t plane = (int64_t)IH * IW;
+  const T* zb = z + b * C * plane;
+  float* Vb = V + b * C * (int64_t)IH * OW;
+  int x0, x1; float lx;
+  src_index(sx, ox, IW, x0, x1, lx);
+  // output rows whose y0 lies in [r0-1, r1-1]
+  int oy_lo = 0, oy_hi = OH - 1;
+  if (sy > 0.f) {
+    const float inv = 1.f / sy;
+    int l = (int)ceilf((float)(r0 - 1) * inv) - 1;
+    int h = (int)floorf((float)r1 * inv) + 1;
+    oy_lo = l < 0 ? 0 : l;
+    oy_hi = h > OH - 1 ? OH - 1 : h;
   }
-  __syncthreads();
-  for (int cb = 0; cb < C; cb += kChunk) {
-    const int nc = (C - cb < kChunk) ? C - cb : kChunk;
-    // phase 1
+  float H0[CMAX], H1[CMAX], accA[CMAX], accB[CMAX];
 #pragma unroll
-    for (int k = 0; k < kKP; ++k) {
-      const int p = tid + k * kT;
-      if (p < NP) {
-        if (coef[k] != 0.f) {
-          const int oy = oy_lo + p / ncols, ox = ox_lo + p % ncols;
-          int y0, y1, x0, x1; float ly, lx;
-          src_index(sy, oy, IH, y0, y1, ly);
-          src_index(sx, ox, IW, x0, x1, lx);
-          const float hy = 1.f - ly, hx = 1.f - lx;
-          const int a0 = (y0 - (r0 - 1)) * ZW, a1 = (y1 - (r0 - 1)) * ZW;
-          const int b0 = x0 - (c0 - 1), b1 = x1 - (c0 - 1);
-          for (int cl = 0; cl < nc; ++cl) {
-            const float* pz = zt + (cb + cl) * zplane;
-            const float v = hy * (hx * pz[a0 + b0] + lx * pz[a0 + b1]) + ly * (hx * pz[a1 + b0] + lx * pz[a1 + b1]);
-            const float smx = __expf(v - lsv[k]);
-            gbuf[cl * NP + p] = coef[k] * (smx - (tt[k] == cb + cl ? 1.f : 0.f));
-          }
+  for (int c = 0; c < CMAX; ++c) { accA[c] = 0.f; accB[c] = 0.f; H0[c] = 0.f; H1[c] = 0.f; }
+  int cy0 = -1, cy1 = -1;
+  int cur = -2;                                      // source row accA belongs to
+  auto flush = [&](int row, const float (&a)[CMAX]) {
+    if (row >= r0 && row < r1) {
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < C) Vb[((int64_t)c * IH + row) * OW + ox] = a[c];
+    }
+  };
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    int y0, y1; float ly;
+    src_index(sy, oy, IH, y0, y1, ly);
+    if (y0 < r0 - 1) continue;
+    if (y0 > r1 - 1) break;
+    if (y0 != cur) {
+      if (cur >= 0) {
+        flush(cur, accA);
+        if (y0 == cur + 1) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) { accA[c] = accB[c]; accB[c] = 0.f; }
         } else {
-          for (int cl = 0; cl < nc; ++cl) gbuf[cl * NP + p] = 0.f;
+          flush(cur + 1, accB);
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) { accA[c] = 0.f; accB[c] = 0.f; }
+        }
+      }
+      cur = y0;
+    }
+    if (y0 != cy0) {
+      if (y0 == cy1) {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) H0[c] = H1[c];
+      } else {
+        load_hrow<T, CMAX>(zb, C, plane, IW, y0, x0, x1, lx, H0);
+      }
+      cy0 = y0; cy1 = -1;
+    }
+    if (y1 != cy1) {
+      if (y1 == cy0) {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) H1[c] = H0[c];
+      } else {
+        load_hrow<T, CMAX>(zb, C, plane, IW, y1, x0, x1, lx, H1);
+      }
+      cy1 = y1;
+    }
+    const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
+    const int64_t lab = Lab<LT>::get(labels, gp);
+    const bool valid = lab != ignore_label;
+    bool kept = valid;
+    if (valid && branch != 2) kept = prob_of_nll(nll[gp]) <= thr;
+    if (kept) {
+      const float coef = g * (weight ? weight[lab] : 1.f);
+      const float ls = lse[gp];
+      const float hy = 1.f - ly;
+      const int t = (int)lab;
+      const bool same = (y1 == y0);
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+          const float v = hy * H0[c] + ly * H1[c];
+          const float gc = coef * (__expf(v - ls) - (c == t ? 1.f : 0.f));
+          if (same) accA[c] += hy * gc + ly * gc;
+          else { accA[c] += hy * gc; accB[c] += ly * gc; }
         }
       }
     }
-    __syncthreads();
-    // phase 2a: horizontal
-    const int ncw = c1 - c0;
-    for (int i = tid; i < nc * nrows * ncw; i += kT) {
-      const int ixl = i % ncw;
-      const int row = (i / ncw) % nrows;
-      const int cl = i / (ncw * nrows);
-      const int xs = lo_x[ixl] - ox_lo;            // first tap relative to the region
-      const float* gr = gbuf + cl * NP + row * ncols;
-      const float* w = wxt + ixl * gm.FX;
-      float acc = 0.f;
-      for (int j = 0; j < gm.FX; ++j) {
-        const int xo = xs + j;
-        if (xo >= 0 && xo < ncols) acc += w[j] * gr[xo];
-      }
-      hsum[(cl * RHf + row) * CW + ixl] = acc;
-    }
-    __syncthreads();
-    // phase 2b: vertical + store
-    const int nch = r1 - r0;
-    for (int i = tid; i < nc * nch * ncw; i += kT) {
-      const int ixl = i % ncw;
-      const int iyl = (i / ncw) % nch;
-      const int cl = i / (ncw * nch);
-      const int ys = lo_y[iyl] - oy_lo;
-      const float* w = wyt + iyl * gm.FY;
-      float acc = 0.f;
-      for (int j = 0; j < gm.FY; ++j) {
-        const int yo = ys + j;
-        if (yo >= 0 && yo < nrows) acc += w[j] * hsum[(cl * RHf + yo) * CW + ixl];
-      }
-      st1<T>(dz + ((b * C + cb + cl) * IH + r0 + iyl) * (int64_t)IW + c0 + ixl, acc);
-    }
-    __syncthreads();
+  }
+  if (cur >= 0) { flush(cur, accA); flush(cur + 1, accB); }
+}
+
+// backward, horizontal part: dz[b,c,iy,ix] = sum_ox wx(ox, ix) * V[b,c,iy,ox]
+template <typename T, int MAXF>
+__global__ __launch_bounds__(kT) void ohem_up_bwd_h(const float* __restrict__ V, T* __restrict__ dz,
+                                                    int64_t rows, int IW, int OW, float sx) {
+  const int64_t total = rows * IW;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int ix = (int)(i % IW);
+    const int64_t row = i / IW;
+    int xlo, xhi;
+    footprint(sx, ix, OW, xlo, xhi);
+    const float* v = V + row * OW + xlo;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j)
+      if (xlo + j <= xhi) acc += tap_weight(sx, xlo + j, IW, ix) * v[j];
+    st1<T>(dz + i, acc);
   }
 }
 
-// host-side geometry of the fused kernels -------------------------------------
-static bool up_fwd_geom(int C, int IH, int IW, int OH, int OW, int bins0, int* RH, int* RW, size_t* sh) {
+static bool up_fused_ok(int C, int IH, int IW, int OH, int OW) {
+  if (C > 32 || C < 1) return false;
   if (OH < 2 * IH || OW < 2 * IW) return false;             // only genuine up-sampling is fused
-  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
-  *RH = (int)floorf((kFTY - 1) * sy) + 3;
-  *RW = (int)floorf((kFTX - 1) * sx) + 3;
-  *sh = ((size_t)((bins0 + 3) & ~3) + (size_t)C * *RH * *RW) * sizeof(float);
-  return *sh <= 60 * 1024;
-}
-
-static size_t up_bwd_lds(int C, const UpBwdGeom& g) {
-  return ((size_t)C * (g.CH + 2) * (g.CW + 2) + (size_t)kChunk * g.RHf * g.RWf + (size_t)kChunk * g.RHf * g.CW +
-          (size_t)g.CH * g.FY + (size_t)g.CW * g.FX + g.CH + g.CW) * sizeof(float);
-}
-
-static bool up_bwd_geom(int C, int IH, int IW, int OH, int OW, UpBwdGeom* out) {
-  if (OH < 2 * IH || OW < 2 * IW) return false;
-  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
-  if (sy <= 0.f || sx <= 0.f) return false;
-  const int FY = (int)floorf(2.f / sy) + 4, FX = (int)floorf(2.f / sx) + 4;
-  if (FY > kMaxFoot || FX > kMaxFoot) return false;
-  const int cand[8][2] = {{4, 8}, {4, 6}, {2, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
-  for (int i = 0; i < 8; ++i) {
-    UpBwdGeom g;
-    g.CH = cand[i][0] < IH ? cand[i][0] : IH;
-    g.CW = cand[i][1] < IW ? cand[i][1] : IW;
-    g.FY = FY; g.FX = FX;
-    g.RHf = (int)ceilf((g.CH + 1) / sy) + 4;
-    g.RWf = (int)ceilf((g.CW + 1) / sx) + 4;
-    if (g.RHf > OH) g.RHf = OH;
-    if (g.RWf > OW) g.RWf = OW;
-    if ((int64_t)g.RHf * g.RWf <= (int64_t)kKP * kT && up_bwd_lds(C, g) <= 62 * 1024) { *out = g; return true; }
-  }
-  return false;
+  const float sx = ac_scale(IW, OW), sy = ac_scale(IH, OH);
+  if (sx <= 0.f || sy <= 0.f) return false;
+  return (int)floorf(2.f / sx) + 4 <= 37;                    // horizontal footprint the gather unrolls
 }
 
 static int pixel_grid(int64_t nvec) {
@@ -910,12 +850,13 @@ int tsg_ohem_bwd(const void* logits, int dtype, const void* labels, int ltype, i
 
 // ---- fused upsample + OHEM ------------------------------------------------------
 int tsg_ohem_up_supported(int C, int IH, int IW, int OH, int OW, float thresh) {
-  tsg_ohem_plan pl;
-  if (tsg_ohem_make_plan(1, C, (int64_t)OH * OW, thresh, &pl)) return 0;
-  int RH, RW; size_t sh;
-  UpBwdGeom g;
-  return up_fwd_geom(C, IH, IW, OH, OW, pl.levels > 0 ? pl.bins[0] : 0, &RH, &RW, &sh) &&
-         up_bwd_geom(C, IH, IW, OH, OW, &g);
+  (void)thresh;
+  return up_fused_ok(C, IH, IW, OH, OW) ? 1 : 0;
+}
+
+size_t tsg_ohem_up_bwd_ws_bytes(int64_t B, int C, int IH, int OW) {
+  if (B <= 0 || C <= 0 || IH <= 0 || OW <= 0) return 0;
+  return (size_t)B * C * IH * OW * sizeof(float);
 }
 
 int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype, int64_t B, int C, int IH,
@@ -925,30 +866,27 @@ int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype, int
   if (!z || !labels || !nll || !lse || !loss || !sel || !ws) return TSG_E_NULL;
   if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
   if (ltype != TSG_I64 && ltype != TSG_U8) return TSG_E_DTYPE;
-  if (IH <= 0 || IW <= 0) return TSG_E_SHAPE;
+  if (IH <= 0 || IW <= 0 || !up_fused_ok(C, IH, IW, OH, OW)) return TSG_E_SHAPE;
   tsg_ohem_plan pl;
   int e = tsg_ohem_make_plan(B, C, (int64_t)OH * OW, thresh, &pl);
   if (e) return e;
   if (ws_bytes < pl.ws_bytes) return TSG_E_WS;
   if (!aligned16(ws)) return TSG_E_ALIGN;
   const int bins0 = pl.levels > 0 ? pl.bins[0] : 0;
-  int RH, RW; size_t sh;
-  if (!up_fwd_geom(C, IH, IW, OH, OW, bins0, &RH, &RW, &sh)) return TSG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   OhemWs w = carve(ws, pl);
   TSG_HIP(hipMemsetAsync(ws, 0, w.zero_bytes, st));
   const int64_t tb = thresh_tb(thresh);
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
-#define PA(T, LTT)                                                                                    \
-  do {                                                                                                \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ohem_up_pass_a<T, LTT>),               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                \
-    hipLaunchKernelGGL((ohem_up_pass_a<T, LTT>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, C, \
-                       IH, IW, OH, OW, sy, sx, RH, RW, ignore_label, thresh, tb, pl.shift[0], bins0,  \
-                       weight, nll, lse, w.hist[0], w.part);                                          \
-  } while (0)
-  if (dtype == TSG_F32) { if (ltype == TSG_I64) PA(float, TSG_I64); else PA(float, TSG_U8); }
-  else { if (ltype == TSG_I64) PA(bf16_t, TSG_I64); else PA(bf16_t, TSG_U8); }
+  const size_t sh = (size_t)(bins0 > 0 ? bins0 : 1) * sizeof(uint32_t);
+#define PA(T, LTT, CM)                                                                                \
+  hipLaunchKernelGGL((ohem_up_pass_a<T, LTT, CM>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, C, \
+                     IH, IW, OH, OW, sy, sx, ignore_label, thresh, tb, pl.shift[0], bins0, weight, nll, \
+                     lse, w.hist[0], w.part)
+#define PC(T, LTT) do { if (C <= 20) PA(T, LTT, 20); else PA(T, LTT, 32); } while (0)
+  if (dtype == TSG_F32) { if (ltype == TSG_I64) PC(float, TSG_I64); else PC(float, TSG_U8); }
+  else { if (ltype == TSG_I64) PC(bf16_t, TSG_I64); else PC(bf16_t, TSG_U8); }
+#undef PC
 #undef PA
   TSG_CHECK_LAUNCH();
   return ohem_select_tail(pl, w, labels, ltype, ignore_label, thresh, min_kept, weight, nll, loss, sel, tb, st);
@@ -956,28 +894,34 @@ int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype, int
 
 int tsg_ohem_up_bwd(const void* z, int dtype, const void* labels, int ltype, int64_t B, int C, int IH,
                     int IW, int OH, int OW, int64_t ignore_label, const float* weight, const float* nll,
-                    const float* lse, const int32_t* sel, const float* gscale, void* dz, void* stream) {
-  if (!z || !labels || !nll || !lse || !sel || !gscale || !dz) return TSG_E_NULL;
+                    const float* lse, const int32_t* sel, const float* gscale, void* dz, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!z || !labels || !nll || !lse || !sel || !gscale || !dz || !ws) return TSG_E_NULL;
   if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
   if (ltype != TSG_I64 && ltype != TSG_U8) return TSG_E_DTYPE;
-  if (B <= 0 || C <= 0) return TSG_E_SHAPE;
-  UpBwdGeom g;
-  if (!up_bwd_geom(C, IH, IW, OH, OW, &g)) return TSG_E_SHAPE;
+  if (B <= 0 || !up_fused_ok(C, IH, IW, OH, OW)) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_ohem_up_bwd_ws_bytes(B, C, IH, OW)) return TSG_E_WS;
   hipStream_t st = (hipStream_t)stream;
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
-  const size_t sh = up_bwd_lds(C, g);
-  const int64_t blocks = B * ((IH + g.CH - 1) / g.CH) * (int64_t)((IW + g.CW - 1) / g.CW);
-  if (blocks > 0x7fffffffLL) return TSG_E_SHAPE;
-#define PB(T, LTT)                                                                                    \
-  do {                                                                                                \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ohem_up_bwd_k<T, LTT>),                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                \
-    hipLaunchKernelGGL((ohem_up_bwd_k<T, LTT>), dim3((unsigned)blocks), dim3(kT), sh, st, (const T*)z, labels, \
-                       C, IH, IW, OH, OW, sy, sx, g, ignore_label, weight, nll, lse, sel, gscale, (T*)dz); \
-  } while (0)
-  if (dtype == TSG_F32) { if (ltype == TSG_I64) PB(float, TSG_I64); else PB(float, TSG_U8); }
-  else { if (ltype == TSG_I64) PB(bf16_t, TSG_I64); else PB(bf16_t, TSG_U8); }
+  float* V = (float*)ws;
+  dim3 grid((unsigned)((OW + kT - 1) / kT), (unsigned)((IH + kBwdCH - 1) / kBwdCH), (unsigned)B);
+#define PB(T, LTT, CM)                                                                                \
+  hipLaunchKernelGGL((ohem_up_bwd_v<T, LTT, CM>), grid, dim3(kT), 0, st, (const T*)z, labels, C, IH, IW, OH, OW, \
+                     sy, sx, ignore_label, weight, nll, lse, sel, gscale, V)
+#define PC(T, LTT) do { if (C <= 20) PB(T, LTT, 20); else PB(T, LTT, 32); } while (0)
+  if (dtype == TSG_F32) { if (ltype == TSG_I64) PC(float, TSG_I64); else PC(float, TSG_U8); }
+  else { if (ltype == TSG_I64) PC(bf16_t, TSG_I64); else PC(bf16_t, TSG_U8); }
+#undef PC
 #undef PB
+  TSG_CHECK_LAUNCH();
+  const int64_t rows = B * C * IH;
+  const int need = (int)floorf(2.f / sx) + 4;
+  int64_t g2 = (rows * IW + kT - 1) / kT;
+  if (g2 > 8192) g2 = 8192;
+#define PH(T, F) hipLaunchKernelGGL((ohem_up_bwd_h<T, F>), dim3((unsigned)g2), dim3(kT), 0, st, V, (T*)dz, rows, IW, OW, sx)
+  if (dtype == TSG_F32) { if (need <= 9) PH(float, 9); else if (need <= 21) PH(float, 21); else PH(float, 37); }
+  else { if (need <= 9) PH(bf16_t, 9); else if (need <= 21) PH(bf16_t, 21); else PH(bf16_t, 37); }
+#undef PH
   TSG_CHECK_LAUNCH();
   return 0;
 }

@@ -256,10 +256,12 @@ class HipKernels:
         _require_contiguous(z, labels, weight)
         B, Cc, IH, IW = z.shape
         dz = torch.empty_like(z)
+        wsb = self.lib.tsg_ohem_up_bwd_ws_bytes(B, Cc, IH, int(OW))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=z.device)
         L.check(self.lib.tsg_ohem_up_bwd(z.data_ptr(), L.dtype_code(z), labels.data_ptr(), _label_code(labels),
                                          B, Cc, IH, IW, int(OH), int(OW), int(ignore_label), L.ptr(weight),
                                          nll.data_ptr(), lse.data_ptr(), sel.data_ptr(), gscale.data_ptr(),
-                                         dz.data_ptr(), L.stream_ptr(z)), "tsg_ohem_up_bwd")
+                                         dz.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(z)), "tsg_ohem_up_bwd")
         return dz
 
     def kth_value(self, v, k):
