@@ -516,6 +516,7 @@ __global__ __launch_bounds__(kT) void ohem_up_pass_a(
     int bins0, const float* __restrict__ weight, float* __restrict__ nll_out,
     float* __restrict__ lse_out, uint32_t* __restrict__ hist0, BlkPart* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
+  __shared__ uint8_t lab_s[kFwdBand * kT];          // labels of the current band (255 = ignored), C <= 32
   const int tid = threadIdx.x;
   for (int i = tid; i < bins0; i += kT) lh[i] = 0;
   __syncthreads();
@@ -535,6 +536,15 @@ __global__ __launch_bounds__(kT) void ohem_up_pass_a(
     float H0[CMAX], H1[CMAX];
     int cy0 = -1, cy1 = -1;
     const int oy_end = (band + 1) * kFwdBand < OH ? (band + 1) * kFwdBand : OH;
+    // side data of the whole band first (kFwdBand independent loads in flight per thread);
+    // each thread only ever reads back its own column, so no barrier is needed.
+#pragma unroll
+    for (int u = 0; u < kFwdBand; ++u) {
+      const int oy = band * kFwdBand + u;
+      int64_t lab = ignore_label;
+      if (oy < oy_end) lab = Lab<LT>::get(labels, (b * OH + oy) * (int64_t)OW + ox);
+      lab_s[u * kT + tid] = (lab != ignore_label) ? (uint8_t)lab : (uint8_t)255;
+    }
     for (int oy = band * kFwdBand; oy < oy_end; ++oy) {
       int y0, y1; float ly;
       src_index(sy, oy, IH, y0, y1, ly);
@@ -557,9 +567,9 @@ __global__ __launch_bounds__(kT) void ohem_up_pass_a(
         cy1 = y1;
       }
       const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
-      const int64_t lab = Lab<LT>::get(labels, gp);
-      const bool valid = lab != ignore_label;
-      const int t = valid ? (int)lab : 0;
+      const int lab = lab_s[(oy - band * kFwdBand) * kT + tid];
+      const bool valid = lab != 255;
+      const int t = valid ? lab : 0;
       const float hy = 1.f - ly;
       float v[CMAX];
       float m = -INFINITY, xt = 0.f;
@@ -595,8 +605,9 @@ __global__ __launch_bounds__(kT) void ohem_up_bwd_v(
     float sy, float sx, int64_t ignore_label, const float* __restrict__ weight,
     const float* __restrict__ nll, const float* __restrict__ lse, const int32_t* __restrict__ sel,
     const float* __restrict__ gscale, float* __restrict__ V) {
-  const int ox = blockIdx.x * kT + threadIdx.x;
-  if (ox >= OW) return;
+  int ox = blockIdx.x * kT + threadIdx.x;
+  const bool live = ox < OW;
+  if (!live) return;
   const int r0 = blockIdx.y * kBwdCH;
   const int r1 = (r0 + kBwdCH < IH) ? r0 + kBwdCH : IH;
   const int64_t b = blockIdx.z;
@@ -629,61 +640,78 @@ __global__ __launch_bounds__(kT) void ohem_up_bwd_v(
         if (c < C) Vb[((int64_t)c * IH + row) * OW + ox] = a[c];
     }
   };
-  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-    int y0, y1; float ly;
-    src_index(sy, oy, IH, y0, y1, ly);
-    if (y0 < r0 - 1) continue;
-    if (y0 > r1 - 1) break;
-    if (y0 != cur) {
-      if (cur >= 0) {
-        flush(cur, accA);
-        if (y0 == cur + 1) {
+  constexpr int G = 16;                                // rows whose side data are fetched together
+  __shared__ float coef_s[G * kT];                     // g * w_t for kept pixels, 0 otherwise
+  __shared__ float lse_s[G * kT];
+  __shared__ uint8_t lab_s[G * kT];
+  const int tid = threadIdx.x;
+  for (int oyg = oy_lo; oyg <= oy_hi; oyg += G) {
+    // independent loads first; a thread only reads back its own column => no barrier
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c) { accA[c] = accB[c]; accB[c] = 0.f; }
-        } else {
-          flush(cur + 1, accB);
-#pragma unroll
-          for (int c = 0; c < CMAX; ++c) { accA[c] = 0.f; accB[c] = 0.f; }
-        }
-      }
-      cur = y0;
-    }
-    if (y0 != cy0) {
-      if (y0 == cy1) {
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) H0[c] = H1[c];
-      } else {
-        load_hrow<T, CMAX>(zb, C, plane, IW, y0, x0, x1, lx, H0);
-      }
-      cy0 = y0; cy1 = -1;
-    }
-    if (y1 != cy1) {
-      if (y1 == cy0) {
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) H1[c] = H0[c];
-      } else {
-        load_hrow<T, CMAX>(zb, C, plane, IW, y1, x0, x1, lx, H1);
-      }
-      cy1 = y1;
-    }
-    const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
-    const int64_t lab = Lab<LT>::get(labels, gp);
-    const bool valid = lab != ignore_label;
-    bool kept = valid;
-    if (valid && branch != 2) kept = prob_of_nll(nll[gp]) <= thr;
-    if (kept) {
-      const float coef = g * (weight ? weight[lab] : 1.f);
+    for (int u = 0; u < G; ++u) {
+      const bool in = oyg + u <= oy_hi;
+      const int64_t gp = (b * OH + (in ? oyg + u : oy_hi)) * (int64_t)OW + ox;
+      const int64_t lab = in ? Lab<LT>::get(labels, gp) : ignore_label;
+      const float nl = nll[gp];
       const float ls = lse[gp];
-      const float hy = 1.f - ly;
-      const int t = (int)lab;
-      const bool same = (y1 == y0);
+      const bool valid = lab != ignore_label;
+      bool kept = valid;
+      if (valid && branch != 2) kept = prob_of_nll(nl) <= thr;
+      coef_s[u * kT + tid] = kept ? g * (weight ? weight[lab] : 1.f) : 0.f;
+      lse_s[u * kT + tid] = ls;
+      lab_s[u * kT + tid] = valid ? (uint8_t)lab : (uint8_t)255;
+    }
+    const int oyg_end = (oyg + G - 1 < oy_hi) ? oyg + G - 1 : oy_hi;
+    for (int oy = oyg; oy <= oyg_end; ++oy) {
+      int y0, y1; float ly;
+      src_index(sy, oy, IH, y0, y1, ly);
+      if (y0 < r0 - 1 || y0 > r1 - 1) continue;
+      if (y0 != cur) {
+        if (cur >= 0) {
+          flush(cur, accA);
+          if (y0 == cur + 1) {
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c) {
-        if (c < C) {
-          const float v = hy * H0[c] + ly * H1[c];
-          const float gc = coef * (__expf(v - ls) - (c == t ? 1.f : 0.f));
-          if (same) accA[c] += hy * gc + ly * gc;
-          else { accA[c] += hy * gc; accB[c] += ly * gc; }
+            for (int c = 0; c < CMAX; ++c) { accA[c] = accB[c]; accB[c] = 0.f; }
+          } else {
+            flush(cur + 1, accB);
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) { accA[c] = 0.f; accB[c] = 0.f; }
+          }
+        }
+        cur = y0;
+      }
+      if (y0 != cy0) {
+        if (y0 == cy1) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) H0[c] = H1[c];
+        } else {
+          load_hrow<T, CMAX>(zb, C, plane, IW, y0, x0, x1, lx, H0);
+        }
+        cy0 = y0; cy1 = -1;
+      }
+      if (y1 != cy1) {
+        if (y1 == cy0) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) H1[c] = H0[c];
+        } else {
+          load_hrow<T, CMAX>(zb, C, plane, IW, y1, x0, x1, lx, H1);
+        }
+        cy1 = y1;
+      }
+      const float coef = coef_s[(oy - oyg) * kT + tid];
+      if (coef != 0.f) {
+        const float ls = lse_s[(oy - oyg) * kT + tid];
+        const int t = lab_s[(oy - oyg) * kT + tid];
+        const float hy = 1.f - ly;
+        const bool same = (y1 == y0);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+          if (c < C) {
+            const float v = hy * H0[c] + ly * H1[c];
+            const float gc = coef * (__expf(v - ls) - (c == t ? 1.f : 0.f));
+            if (same) accA[c] += hy * gc + ly * gc;
+            else { accA[c] += hy * gc; accB[c] += ly * gc; }
+          }
         }
       }
     }
