@@ -27,7 +27,8 @@ model in channels_last where MIOpen is faster on MI355X, and installs the aten
 upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_DTYPE=bf16|fp32   (default bf16 on GPU)    TSG_CHANNELS_LAST=1|0 (default 1 on GPU)
   TSG_FUSE_PSA=1|0      (default: on when the model has a PointwiseSpatialAttention block)
-  TSG_FUSE_HEAD=1|0     (default 1 on GPU: F.interpolate(x >= 4) feeding our criterion is fused into it)
+  TSG_FUSE_HEAD=1|0     (default 0: F.interpolate(x >= 4) feeding our criterion is fused into it; parity-tested,
+                        but on MI355X streaming the bf16 logits at ~4-5 TB/s is as fast as re-interpolating them)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
 """
 import os
@@ -233,7 +234,7 @@ class DistributedDataParallel(nn.Module):
             install_aten_overrides()
             from .psa import model_has_psa
             self.fuse_psa = _env_flag("TSG_FUSE_PSA", model_has_psa(module))
-            if _env_flag("TSG_FUSE_HEAD", True):
+            if _env_flag("TSG_FUSE_HEAD", False):
                 from .upsample import install_deferred_interpolate
                 install_deferred_interpolate()
             if _env_flag("TSG_SPLIT_BIAS", True):
