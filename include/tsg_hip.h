@@ -177,6 +177,18 @@ int tsg_chanscale_bwd(const void* dy, const void* x, const void* s, void* dx, vo
                       int dtype, int layout, int64_t N, int64_t C, int64_t HW,
                       int add_identity, void* ws, size_t ws_bytes, void* stream);
 
+/* Max pooling, channels_last — replaces ResNet's nn.MaxPool2d(kernel_size=3,
+ * stride=2, padding=1) (furnace/base_model/resnet.py:132).  x [N, IH, IW, C],
+ * y [N, OH, OW, C] with OH = (IH + 2P - K)/S + 1; argmax_u8 [N, OH, OW, C] holds
+ * the window position ky*K + kx of each maximum (first maximum in scan order, NaN
+ * wins: at::native's rule).  C % (16 / elem_size) == 0. */
+int tsg_maxpool_nhwc_fwd(const void* x, void* y, void* argmax_u8, int dtype,
+                         int64_t N, int C, int IH, int IW, int OH, int OW,
+                         int K, int S, int P, void* stream);
+int tsg_maxpool_nhwc_bwd(const void* dy, const void* argmax_u8, void* dx, int dtype,
+                         int64_t N, int C, int IH, int IW, int OH, int OW,
+                         int K, int S, int P, void* stream);
+
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
  * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.

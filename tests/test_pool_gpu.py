@@ -75,3 +75,28 @@ def test_bias_split_conv_matches_plain_conv(cuda):
     torch.testing.assert_close(b.weight.grad, a.weight.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-4, atol=1e-3)
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+
+
+@pytest.mark.parametrize("shape,k,s,p", [((2, 64, 32, 32), 3, 2, 1), ((2, 64, 33, 47), 3, 2, 1), ((4, 8, 16, 16), 2, 2, 0),
+                                         ((1, 128, 20, 12), 3, 1, 1), ((16, 64, 512, 512), 3, 2, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_channels_last(cuda, shape, k, s, p, dtype):
+    from torchseg_amd.pool import MaxPool2d
+    big = shape[0] * shape[1] * shape[2] * shape[3] > 5e7
+    if big and dtype == torch.float32:
+        pytest.skip("large case once is enough")
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(shape, generator=g)
+    x[0, :, 0, 0] = x[0, :, 0, 1]                     # a tie: the first maximum must take the gradient
+    x = x.to(dtype)
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = MaxPool2d(k, s, p)(xd)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(y.shape, generator=g).to(dtype)
+    y.backward(dy.to(cuda))
+    xr = x.float().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, k, s, p)
+    yr.backward(dy.float())
+    torch.testing.assert_close(y.detach().float().cpu(), yr.detach(), rtol=0, atol=0)
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)

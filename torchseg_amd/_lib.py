@@ -55,6 +55,8 @@ _PROTOS = {
     "tsg_gap_bwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "tsg_chanscale_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p]),
     "tsg_chanscale_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p, _sz, _p]),
+    "tsg_maxpool_nhwc_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tsg_maxpool_nhwc_bwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),
     "tsg_ohem_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _f, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tsg_ohem_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -240,6 +240,95 @@ __global__ __launch_bounds__(kT) void cs_bwd_nchw(const T* __restrict__ dy, cons
   if (threadIdx.x == 0) st1<T>(ds + blockIdx.x, acc);
 }
 
+// ---- max pooling (channels_last) ---------------------------------------------------
+// ResNet's stem pool nn.MaxPool2d(3, stride 2, padding 1) (furnace/base_model/resnet.py:132).
+// Eager PyTorch-ROCm keeps int64 argmax indices (8 B per output element) and spends
+// 0.33 ms forward + 0.82 ms backward on the 16x64x512x512 map; here the argmax is one
+// byte (position inside the window), the forward is one 16-byte-vector pass and the
+// backward is a deterministic gather over the <= ceil(K/S)^2 windows covering a pixel.
+// Tie / NaN rule as at::native max_pool2d: first maximum in (ky, kx) scan order, NaN wins.
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void maxpool_fwd_nhwc(const T* __restrict__ x, T* __restrict__ y,
+                                                       uint8_t* __restrict__ idx, int64_t N, int C, int IH,
+                                                       int IW, int OH, int OW, int K, int S, int P) {
+  const int G = C / V;
+  const int64_t total = N * OH * (int64_t)OW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int g = (int)(i % G);
+    int64_t t = i / G;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int64_t n = t / OH;
+    const int y0 = oy * S - P, x0 = ox * S - P;
+    float m[V];
+    int am[V];
+    bool first = true;
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = y0 + ky;
+      if (iy < 0 || iy >= IH) continue;
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = x0 + kx;
+        if (ix < 0 || ix >= IW) continue;
+        PV<T, V> p;
+        p.load(x + ((n * IH + iy) * (int64_t)IW + ix) * C + g * V);
+        const int pos = ky * K + kx;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (first || p.v[j] > m[j] || p.v[j] != p.v[j]) { m[j] = p.v[j]; am[j] = pos; }
+        }
+        first = false;
+      }
+    }
+    PV<T, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = m[j];
+    o.store(y + i * V);
+    uint8_t* ip = idx + i * V;
+#pragma unroll
+    for (int j = 0; j < V; ++j) ip[j] = (uint8_t)am[j];
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void maxpool_bwd_nhwc(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                       T* __restrict__ dx, int64_t N, int C, int IH, int IW,
+                                                       int OH, int OW, int K, int S, int P) {
+  const int G = C / V;
+  const int64_t total = N * IH * (int64_t)IW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int g = (int)(i % G);
+    int64_t t = i / G;
+    const int ix = (int)(t % IW); t /= IW;
+    const int iy = (int)(t % IH);
+    const int64_t n = t / IH;
+    // windows (oy, ox) with oy*S - P <= iy <= oy*S - P + K - 1
+    int oy_lo = (iy + P - K + 1 + S - 1) / S; if (iy + P - K + 1 < 0) oy_lo = 0;
+    int oy_hi = (iy + P) / S; if (oy_hi > OH - 1) oy_hi = OH - 1;
+    int ox_lo = (ix + P - K + 1 + S - 1) / S; if (ix + P - K + 1 < 0) ox_lo = 0;
+    int ox_hi = (ix + P) / S; if (ox_hi > OW - 1) ox_hi = OW - 1;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const int ky = iy - (oy * S - P);
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const int pos = ky * K + (ix - (ox * S - P));
+        const int64_t o = ((n * OH + oy) * (int64_t)OW + ox) * C + g * V;
+        PV<T, V> d;
+        d.load(dy + o);
+        const uint8_t* ip = idx + o;
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+          if (ip[j] == pos) acc[j] += d.v[j];
+      }
+    }
+    PV<T, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = acc[j];
+    o.store(dx + i * V);
+  }
+}
+
 struct GapGeom { int gt, R, S; int64_t rpb; };
 static GapGeom gap_geom(int64_t N, int64_t C, int64_t HW, int V) {
   GapGeom g;
@@ -417,6 +506,48 @@ int tsg_chanscale_bwd(const void* dy, const void* x, const void* s, void* dx, vo
     hipLaunchKernelGGL((gap_finish<float>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, 1.f, (float*)ds);
   else
     hipLaunchKernelGGL((gap_finish<bf16_t>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, 1.f, (bf16_t*)ds);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+
+int tsg_maxpool_nhwc_fwd(const void* x, void* y, void* argmax_u8, int dtype, int64_t N, int C, int IH, int IW,
+                         int OH, int OW, int K, int S, int P, void* stream) {
+  if (!x || !y || !argmax_u8) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || K <= 0 || K > 15 || S <= 0 || P < 0 || 2 * P > K) return TSG_E_SHAPE;
+  if (OH != (IH + 2 * P - K) / S + 1 || OW != (IW + 2 * P - K) / S + 1) return TSG_E_SHAPE;
+  if (!aligned16(x) || !aligned16(y)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t g = (N * OH * (int64_t)OW * (C / V) + kT - 1) / kT;
+  if (g > 16384) g = 16384;
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((maxpool_fwd_nhwc<float, 4>), dim3((unsigned)g), dim3(kT), 0, st, (const float*)x, (float*)y,
+                       (uint8_t*)argmax_u8, N, C, IH, IW, OH, OW, K, S, P);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_nhwc<bf16_t, 8>), dim3((unsigned)g), dim3(kT), 0, st, (const bf16_t*)x,
+                       (bf16_t*)y, (uint8_t*)argmax_u8, N, C, IH, IW, OH, OW, K, S, P);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_maxpool_nhwc_bwd(const void* dy, const void* argmax_u8, void* dx, int dtype, int64_t N, int C, int IH,
+                         int IW, int OH, int OW, int K, int S, int P, void* stream) {
+  if (!dy || !dx || !argmax_u8) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || K <= 0 || K > 15 || S <= 0 || P < 0) return TSG_E_SHAPE;
+  if (!aligned16(dy) || !aligned16(dx)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t g = (N * IH * (int64_t)IW * (C / V) + kT - 1) / kT;
+  if (g > 16384) g = 16384;
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((maxpool_bwd_nhwc<float, 4>), dim3((unsigned)g), dim3(kT), 0, st, (const float*)dy,
+                       (const uint8_t*)argmax_u8, (float*)dx, N, C, IH, IW, OH, OW, K, S, P);
+  else
+    hipLaunchKernelGGL((maxpool_bwd_nhwc<bf16_t, 8>), dim3((unsigned)g), dim3(kT), 0, st, (const bf16_t*)dy,
+                       (const uint8_t*)argmax_u8, (bf16_t*)dx, N, C, IH, IW, OH, OW, K, S, P);
   TSG_CHECK_LAUNCH();
   return 0;
 }

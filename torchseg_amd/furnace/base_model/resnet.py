@@ -11,6 +11,7 @@ kernel forward and one fused pair of kernels backward.
 import torch.nn as nn
 
 from seg_opr.seg_oprs import norm_act
+from torchseg_amd.pool import MaxPool2d as _MaxPool2d
 from utils.pyt_utils import load_model
 
 __all__ = ['ResNet', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152']
@@ -92,7 +93,7 @@ class ResNet(nn.Module):
             self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = norm_layer(self.inplanes, eps=bn_eps, momentum=bn_momentum)
         self.relu = nn.ReLU(inplace=inplace)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = _MaxPool2d(kernel_size=3, stride=2, padding=1)
         cfg = dict(bn_eps=bn_eps, bn_momentum=bn_momentum)
         self.layer1 = self._make_layer(block, norm_layer, 64, layers[0], inplace, **cfg)
         self.layer2 = self._make_layer(block, norm_layer, 128, layers[1], inplace, stride=2, **cfg)

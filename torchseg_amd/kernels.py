@@ -196,6 +196,25 @@ class HipKernels:
                                            ws.numel(), L.stream_ptr(x)), "tsg_chanscale_bwd")
         return dx, ds
 
+    # ---- max pool (channels_last) ------------------------------------------------
+    def maxpool_fwd(self, x, K_, S_, P_):
+        """x channels_last-dense [N,C,IH,IW] -> (y channels_last, argmax uint8 [N,OH,OW,C])"""
+        N, Cc, IH, IW = x.shape
+        OH, OW = (IH + 2 * P_ - K_) // S_ + 1, (IW + 2 * P_ - K_) // S_ + 1
+        y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_maxpool_nhwc_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), L.dtype_code(x), N, Cc,
+                                              IH, IW, OH, OW, K_, S_, P_, L.stream_ptr(x)), "tsg_maxpool_nhwc_fwd")
+        return y, idx
+
+    def maxpool_bwd(self, dy, idx, in_shape, K_, S_, P_):
+        N, Cc, IH, IW = in_shape
+        OH, OW = dy.shape[2], dy.shape[3]
+        dx = torch.empty(in_shape, dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_maxpool_nhwc_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), L.dtype_code(dy), N, Cc,
+                                              IH, IW, OH, OW, K_, S_, P_, L.stream_ptr(dy)), "tsg_maxpool_nhwc_bwd")
+        return dx
+
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
@@ -418,6 +437,8 @@ _ALGO_BYTES = {
     "bn_bwd_apply_mixed": lambda a, r: 3 * _nbytes(a[0]),
     "chanscale_fwd": lambda a, r: 2 * _nbytes(a[0]),
     "chanscale_bwd": lambda a, r: 3 * _nbytes(a[0]),
+    "maxpool_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r[0]) + _nbytes(r[1]),
+    "maxpool_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "gap_fwd": lambda a, r: _nbytes(a[0]),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
@@ -448,7 +469,7 @@ class KernelTimer:
             s.record()
             out = fn(*args, **kw)
             e.record()
-            rec.append((s, e, cost(args, out[0] if isinstance(out, tuple) else out)))
+            rec.append((s, e, cost(args, out if name == "maxpool_fwd" else (out[0] if isinstance(out, tuple) else out))))
             return out
 
         setattr(self.prov, name, timed)

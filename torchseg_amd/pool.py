@@ -84,3 +84,43 @@ def channel_scale(x, s, add_identity=False):
     if x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16):
         return _ChanScaleFn.apply(x, s, add_identity)
     return x + x * s if add_identity else x * s
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        kp = K.provider()
+        y, idx = kp.maxpool_fwd(x, k, s, p)
+        ctx.save_for_backward(idx)
+        ctx.cfg = (tuple(x.shape), k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        kp = K.provider()
+        (idx,) = ctx.saved_tensors
+        in_shape, k, s, p = ctx.cfg
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        return kp.maxpool_bwd(dy, idx, in_shape, k, s, p), None, None, None
+
+
+def _as_int(v):
+    if isinstance(v, (tuple, list)):
+        return v[0] if len(set(v)) == 1 else None
+    return v
+
+
+class MaxPool2d(nn.MaxPool2d):
+    """nn.MaxPool2d whose channels_last HIP inputs run on csrc/pool.hip (one-byte argmax,
+    deterministic gather backward); anything else takes the stock module path."""
+
+    def forward(self, x):
+        k, s, p = _as_int(self.kernel_size), _as_int(self.stride), _as_int(self.padding)
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+                and k is not None and s is not None and p is not None and _as_int(self.dilation) == 1
+                and not self.ceil_mode and not self.return_indices and 2 * p <= k and k <= 15
+                and x.shape[1] % vec == 0 and not x.is_contiguous()
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            return _MaxPoolFn.apply(x, k, s, p)
+        return super().forward(x)
