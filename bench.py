@@ -13,6 +13,7 @@ display.  Inputs are resident in HBM before the timed region.  Weak scaling:
 every rank keeps batch 16.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -29,7 +30,7 @@ NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
 
 
-def build_model(device, batch, size, criterion_cls, norm_layer, seed=12345):
+def build_model(device, batch, size, criterion_cls, norm_layer, seed=12345, fused_sgd=False):
     from torchseg_amd.workloads import ensure_furnace_on_path
     ensure_furnace_on_path()
     from torchseg_amd.workloads.bisenet import BiSeNet
@@ -47,7 +48,11 @@ def build_model(device, batch, size, criterion_cls, norm_layer, seed=12345):
     for part in (model.spatial_path, model.global_context, model.arms, model.refines, model.heads, model.ffm):
         groups = group_weight(groups, part, norm_layer, base_lr * 10)  # train.py:70-84
     model.to(device)
-    opt = torch.optim.SGD(groups, lr=base_lr, momentum=0.9, weight_decay=5e-4)   # train.py:86-89
+    if fused_sgd:
+        from torchseg_amd.optim import FusedSGD                        # same update, one HIP kernel per tensor
+        opt = FusedSGD(groups, lr=base_lr, momentum=0.9, weight_decay=5e-4)
+    else:
+        opt = torch.optim.SGD(groups, lr=base_lr, momentum=0.9, weight_decay=5e-4)   # train.py:86-89
     return model, opt, base_lr
 
 
@@ -59,18 +64,44 @@ def synthetic_batch(device, batch, size, seed=0):
     return imgs, gts
 
 
-def train_step(model, opt, imgs, gts, lr_policy, it, world):
+def set_lr(opt, lr_policy, it):
+    lr = lr_policy.get_lr(it)
+    for i, gparam in enumerate(opt.param_groups):
+        gparam['lr'] = lr if i < 2 else lr * 10                        # train.py:133-139
+    if hasattr(opt, "refresh_lr"):
+        opt.refresh_lr()                                               # device-side lr for graph replay
+
+
+def step_body(model, opt, imgs, gts, world):
     from utils.pyt_utils import all_reduce_tensor
     opt.zero_grad()
     loss = model(imgs, gts)
     if world > 1:
         all_reduce_tensor(loss, world_size=world)                      # train.py:129-131
-    lr = lr_policy.get_lr(it)
-    for i, gparam in enumerate(opt.param_groups):
-        gparam['lr'] = lr if i < 2 else lr * 10                        # train.py:133-139
     loss.backward()
     opt.step()
     return loss
+
+
+def train_step(model, opt, imgs, gts, lr_policy, it, world):
+    set_lr(opt, lr_policy, it)
+    return step_body(model, opt, imgs, gts, world)
+
+
+class GraphedStep(object):
+    """The whole step (zero_grad -> forward -> backward incl. collectives -> SGD) captured
+    once into a hipGraph and replayed: removes ~1000 host-side launches per step.  The
+    learning rate lives on the device (FusedSGD), so the per-iteration schedule is kept."""
+
+    def __init__(self, model, opt, imgs, gts, world):
+        self.graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = step_body(model, opt, imgs, gts, world)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss
 
 
 def cpu_baseline(size, batch=2, steps=2):
@@ -106,6 +137,9 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("TSG_GRAPH", "-1")),
+                    help="replay the step from a hipGraph (default: on for 1 GPU, off for N > 1)")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "0")),
                     help="torch.backends.cudnn.benchmark (train.py:35); 0 = immediate mode on the shipped MIOpen find-db (same speed, 100 s faster start)")
@@ -138,8 +172,12 @@ def main():
     ensure_furnace_on_path()
     from engine.lr_policy import PolyLR
 
+    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    if use_graph and args.optimizer != "fused":
+        sys.exit("--graph needs --optimizer fused (torch.optim.SGD bakes lr into the captured kernels)")
     model, opt, base_lr = build_model(device, args.batch, args.size, ProbOhemCrossEntropy2d, SyncBatchNorm,
-                                      seed=12345 if world == 1 else local_rank)      # train.py:37-40
+                                      seed=12345 if world == 1 else local_rank,       # train.py:37-40
+                                      fused_sgd=args.optimizer == "fused")
     model = DistributedDataParallel(model)                             # train.py:98-99
     model.train()
     imgs, gts = synthetic_batch(device, args.batch, args.size, seed=rank)
@@ -151,30 +189,54 @@ def main():
         torch.cuda.synchronize()
 
     # Per-kernel timing brackets every launch with HIP events, which costs host time
-    # (~600 event records per step); it must not distort `value`.  So: the warm-up
-    # steps run fully instrumented to learn which of our kernels dominates, and the
-    # timed region instruments ONLY that kernel (~35 launches per step).
+    # (~600 event records per step); it must not distort `value`.  So: the last eager
+    # warm-up step runs fully instrumented to learn which of our kernels dominates, and
+    # (eager mode only) the timed region instruments ONLY that kernel.  Under graph
+    # replay there are no host-side launches to bracket: the roofline then comes from
+    # the instrumented warm-up step of the same process.
     timer = None
     dominant = None
-    for it in range(args.warmup):
-        probe = None
-        if not args.no_kernel_timing and it == args.warmup - 1:
-            probe = K.KernelTimer(K.provider())
-        loss = train_step(model, opt, imgs, gts, pol, it, world)
-        if probe is not None:
-            probe.stop()
-            dominant = probe.dominant()
-            all_kernels = probe.summary()
+    all_kernels = None
+    n_eager = max(args.warmup, 3) if use_graph else args.warmup        # capture needs warmed-up libraries
+    side = torch.cuda.Stream() if use_graph else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        for it in range(n_eager):
+            probe = None
+            if not args.no_kernel_timing and it == n_eager - 1:
+                probe = K.KernelTimer(K.provider())
+            loss = train_step(model, opt, imgs, gts, pol, it, world)
+            if probe is not None:
+                probe.stop()
+                dominant = probe.dominant()
+                all_kernels = probe.summary()
+                roof_probe = probe
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
     sync()
-    if dominant is not None:
+    graphed = None
+    if use_graph:
+        graphed = GraphedStep(model, opt, imgs, gts, world)
+        for it in range(2):                                            # untimed replays
+            set_lr(opt, pol, n_eager + it)
+            loss = graphed()
+        sync()
+    elif dominant is not None:
         timer = K.KernelTimer(K.provider(), names=[dominant])
     t0 = time.perf_counter()
     for it in range(args.steps):
-        loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
+        if graphed is not None:
+            set_lr(opt, pol, args.warmup + it)
+            loss = graphed()
+        else:
+            loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
     sync()
     dt = time.perf_counter() - t0
     if timer is not None:
         timer.stop()
+    elif dominant is not None:
+        timer = roof_probe
     final_loss = float(loss.item())
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -193,10 +255,13 @@ def main():
             "config": {"workload": f"BiSeNet-R18 {args.dtype} batch {args.batch}/GPU {args.size}x{args.size} "
                                    f"synthetic crops, SyncBN + OHEM (BASELINE configs[1])",
                        "global_batch": global_batch, "parallelism": f"dp{world}",
-                       "channels_last": model.channels_last, "final_loss": round(final_loss, 4)},
+                       "channels_last": model.channels_last, "final_loss": round(final_loss, 4),
+                       "hip_graph": bool(use_graph), "optimizer": args.optimizer},
         }
         if timer is not None:
             out["roofline"] = timer.roofline(HBM_PEAK_GBS, os.path.join(ROOT, "profiles"))
+            out["roofline"]["measured_over"] = ("instrumented eager warm-up step (hipGraph replay has no host-side "
+                                                "launches to bracket)") if use_graph else "timed region"
             out["kernels_last_warmup_step"] = all_kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)

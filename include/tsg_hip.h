@@ -334,6 +334,13 @@ int tsg_sgd_step(float* param, const float* grad, float* momentum_buf,
                  int64_t n, float lr, float momentum, float weight_decay,
                  float grad_scale, int first_step, void* stream);
 
+/* Same update with lr = lr_dev[0] * lr_mult read on the device (momentum_buf must
+ * start zeroed: buf = momentum*buf + g reproduces torch's first-step buf = g), so a
+ * captured hipGraph follows a per-iteration schedule (train.py:133-139). */
+int tsg_sgd_step_dev(float* param, const float* grad, float* momentum_buf,
+                     int64_t n, const float* lr_dev, float lr_mult, float momentum,
+                     float weight_decay, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

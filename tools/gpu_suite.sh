@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-side check run: per-file pytest logs, smoke, short bench (+ optional rocprof) -> gpurun_out/
 mkdir -p gpurun_out
-for f in ${TESTS-bn ohem upsample focal psa pool fused_head}; do
+for f in ${TESTS-bn ohem upsample focal psa pool fused_head optim}; do
   timeout 900 python -m pytest tests/test_${f}_gpu.py -x -q -m gpu > gpurun_out/test_$f.log 2>&1
   echo "== $f rc=$?"; grep -E "passed|failed|error|Fatal|fault|^E  " gpurun_out/test_$f.log | tail -8
 done

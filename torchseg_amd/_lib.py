@@ -77,6 +77,7 @@ _PROTOS = {
     "tsg_psa_ws_bytes": (_sz, [_i, _i, _i64, _i64, _i64, _i64]),
     "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_psa_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_sgd_step_dev": (_i, [_p, _p, _p, _i64, _p, _f, _f, _f, _f, _p]),
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
 }
 

@@ -34,6 +34,53 @@ __global__ __launch_bounds__(256) void sgd_k(float* __restrict__ p, const float*
 }
 }  // namespace tsg
 
+namespace tsg {
+// same update with the learning rate read from device memory, so a captured hipGraph
+// keeps following the schedule (train.py:133-139 rewrites lr every iteration)
+__global__ __launch_bounds__(256) void sgd_dev_k(float* __restrict__ p, const float* __restrict__ g,
+                                                 float* __restrict__ buf, int64_t n,
+                                                 const float* __restrict__ lr_dev, float lr_mult, float mom,
+                                                 float wd, float gs) {
+  const float lr = lr_dev[0] * lr_mult;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 bv = reinterpret_cast<float4*>(buf)[i];
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = gg[j] * gs + wd * pp[j];
+      bb[j] = mom * bb[j] + d;
+      pp[j] -= lr * bb[j];
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(buf)[i] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = g[i] * gs + wd * p[i];
+    const float b = mom * buf[i] + d;
+    buf[i] = b;
+    p[i] -= lr * b;
+  }
+}
+}  // namespace tsg
+
+extern "C" int tsg_sgd_step_dev(float* param, const float* grad, float* momentum_buf, int64_t n,
+                                const float* lr_dev, float lr_mult, float momentum, float weight_decay,
+                                float grad_scale, void* stream) {
+  if (!param || !grad || !momentum_buf || !lr_dev) return TSG_E_NULL;
+  if (n <= 0) return TSG_E_SHAPE;
+  if (!tsg::aligned16(param) || !tsg::aligned16(grad) || !tsg::aligned16(momentum_buf)) return TSG_E_ALIGN;
+  int64_t g = (n / 4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(tsg::sgd_dev_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     momentum_buf, n, lr_dev, lr_mult, momentum, weight_decay, grad_scale);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tsg_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                             float momentum, float weight_decay, float grad_scale, int first_step,
                             void* stream) {

@@ -394,6 +394,12 @@ class HipKernels:
                                       int(first), L.stream_ptr(param)), "tsg_sgd_step")
 
 
+    def sgd_step_dev(self, param, grad, buf, lr_dev, lr_mult, momentum, weight_decay, grad_scale=1.0):
+        L.check(self.lib.tsg_sgd_step_dev(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(),
+                                          lr_dev.data_ptr(), float(lr_mult), float(momentum), float(weight_decay),
+                                          float(grad_scale), L.stream_ptr(param)), "tsg_sgd_step_dev")
+
+
 _provider = None
 
 
