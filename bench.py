@@ -72,14 +72,15 @@ def set_lr(opt, lr_policy, it):
         opt.refresh_lr()                                               # device-side lr for graph replay
 
 
-def step_body(model, opt, imgs, gts, world):
+def step_body(model, opt, imgs, gts, world, with_optimizer=True):
     from utils.pyt_utils import all_reduce_tensor
     opt.zero_grad()
     loss = model(imgs, gts)
     if world > 1:
         all_reduce_tensor(loss, world_size=world)                      # train.py:129-131
     loss.backward()
-    opt.step()
+    if with_optimizer:
+        opt.step()
     return loss
 
 
@@ -89,18 +90,21 @@ def train_step(model, opt, imgs, gts, lr_policy, it, world):
 
 
 class GraphedStep(object):
-    """The whole step (zero_grad -> forward -> backward incl. collectives -> SGD) captured
-    once into a hipGraph and replayed: removes ~1000 host-side launches per step.  The
-    learning rate lives on the device (FusedSGD), so the per-iteration schedule is kept."""
+    """zero_grad -> forward -> backward (incl. collectives) captured once into a hipGraph and
+    replayed, which removes ~1000 host-side launches per step; optimizer.step() stays eager
+    after each replay (62 launches), so the reference's per-iteration lr schedule
+    (train.py:133-139) needs no special handling."""
 
     def __init__(self, model, opt, imgs, gts, world):
         self.graph = torch.cuda.CUDAGraph()
+        self.opt = opt
         opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.loss = step_body(model, opt, imgs, gts, world)
+            self.loss = step_body(model, opt, imgs, gts, world, with_optimizer=False)
 
     def __call__(self):
         self.graph.replay()
+        self.opt.step()
         return self.loss
 
 
@@ -140,6 +144,7 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("TSG_GRAPH", "-1")),
                     help="replay the step from a hipGraph (default: on for 1 GPU, off for N > 1)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
+    ap.add_argument("--trace-loss", action="store_true", help="debug: print the loss of every timed step (syncs)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "0")),
                     help="torch.backends.cudnn.benchmark (train.py:35); 0 = immediate mode on the shipped MIOpen find-db (same speed, 100 s faster start)")
@@ -173,8 +178,6 @@ def main():
     from engine.lr_policy import PolyLR
 
     use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
-    if use_graph and args.optimizer != "fused":
-        sys.exit("--graph needs --optimizer fused (torch.optim.SGD bakes lr into the captured kernels)")
     model, opt, base_lr = build_model(device, args.batch, args.size, ProbOhemCrossEntropy2d, SyncBatchNorm,
                                       seed=12345 if world == 1 else local_rank,       # train.py:37-40
                                       fused_sgd=args.optimizer == "fused")
@@ -231,6 +234,8 @@ def main():
             loss = graphed()
         else:
             loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
+        if args.trace_loss and rank == 0:
+            print("step", it, "loss", float(loss.item()), "lr", opt.param_groups[0]["lr"], file=sys.stderr, flush=True)
     sync()
     dt = time.perf_counter() - t0
     if timer is not None:
