@@ -76,7 +76,7 @@ def step_body(model, opt, imgs, gts, world, with_optimizer=True):
     from utils.pyt_utils import all_reduce_tensor
     opt.zero_grad()
     loss = model(imgs, gts)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         all_reduce_tensor(loss, world_size=world)                      # train.py:129-131
     loss.backward()
     if with_optimizer:
@@ -141,8 +141,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("TSG_GRAPH", "-1")),
-                    help="replay the step from a hipGraph (default: on for 1 GPU, off for N > 1)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("TSG_GRAPH", "0")),
+                    help="EXPERIMENTAL: replay zero_grad+forward+backward from a hipGraph (default off)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--trace-loss", action="store_true", help="debug: print the loss of every timed step (syncs)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -164,8 +164,12 @@ def main():
         sys.exit("bench.py needs an AMD GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_coll = os.environ.get("TSG_FORCE_COLLECTIVES", "0") == "1"     # 1-rank run of the N>1 code path
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", init_method="env://")
     torch.backends.cudnn.benchmark = bool(args.miopen_find)            # train.py:35
 
@@ -177,7 +181,7 @@ def main():
     ensure_furnace_on_path()
     from engine.lr_policy import PolyLR
 
-    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    use_graph = bool(args.graph)
     model, opt, base_lr = build_model(device, args.batch, args.size, ProbOhemCrossEntropy2d, SyncBatchNorm,
                                       seed=12345 if world == 1 else local_rank,       # train.py:37-40
                                       fused_sgd=args.optimizer == "fused")
@@ -187,7 +191,7 @@ def main():
     pol = PolyLR(base_lr, 0.9, 80 * 1000)
 
     def sync():
-        if world > 1:
+        if world > 1 or force_coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -271,7 +275,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

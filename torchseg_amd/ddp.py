@@ -243,7 +243,8 @@ class DistributedDataParallel(nn.Module):
 
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None
-        if self.world_size > 1:
+        force = dist.is_initialized() and _env_flag("TSG_FORCE_COLLECTIVES", False)   # 1-rank validation of the N>1 path
+        if self.world_size > 1 or force:
             tensors = [p for p in module.parameters()] + [b for b in module.buffers()]
             _broadcast_coalesced(tensors, 0, process_group)
             self.reducer = Reducer(module.parameters(), process_group, message_size, delay_allreduce,

@@ -14,6 +14,8 @@ base_model, invisible to an unchanged network.py): `forward(x, residual=None,
 relu=False)` fuses the residual add and the ReLU that follow the BN into the
 normalise kernel, and their backward into the BN backward kernels.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch.nn.modules.batchnorm import _BatchNorm
@@ -39,8 +41,14 @@ def _count_words(n, device):
 
 
 def _world(group):
+    """Ranks that share batch statistics.  TSG_FORCE_COLLECTIVES=1 makes a 1-rank
+    process group take the multi-rank code path (collapse -> all-reduce -> finalize),
+    which is how the N > 1 path is exercised on a single-GPU box."""
     if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size(group)
+        w = dist.get_world_size(group)
+        if w == 1 and os.environ.get("TSG_FORCE_COLLECTIVES", "0") == "1":
+            return 2
+        return w
     return 1
 
 
