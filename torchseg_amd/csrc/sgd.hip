@@ -8,8 +8,8 @@
 namespace tsg {
 __global__ __launch_bounds__(256) void sgd_k(float* __restrict__ p, const float* __restrict__ g,
                                              float* __restrict__ buf, int64_t n, float lr, float mom,
-                                             float wd, float gs, int first) {
-  const int64_t n4 = n / 4;
+                                             float wd, float gs, int first, int vec) {
+  const int64_t n4 = vec ? n / 4 : 0;     // 16-byte path only when all three pointers are aligned
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -40,9 +40,9 @@ namespace tsg {
 __global__ __launch_bounds__(256) void sgd_dev_k(float* __restrict__ p, const float* __restrict__ g,
                                                  float* __restrict__ buf, int64_t n,
                                                  const float* __restrict__ lr_dev, float lr_mult, float mom,
-                                                 float wd, float gs) {
+                                                 float wd, float gs, int vec) {
   const float lr = lr_dev[0] * lr_mult;
-  const int64_t n4 = n / 4;
+  const int64_t n4 = vec ? n / 4 : 0;     // gradients that are views into a DDP bucket may be unaligned
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -71,12 +71,12 @@ extern "C" int tsg_sgd_step_dev(float* param, const float* grad, float* momentum
                                 float grad_scale, void* stream) {
   if (!param || !grad || !momentum_buf || !lr_dev) return TSG_E_NULL;
   if (n <= 0) return TSG_E_SHAPE;
-  if (!tsg::aligned16(param) || !tsg::aligned16(grad) || !tsg::aligned16(momentum_buf)) return TSG_E_ALIGN;
-  int64_t g = (n / 4 + 255) / 256;
+  const int vec = tsg::aligned16(param) && tsg::aligned16(grad) && tsg::aligned16(momentum_buf);
+  int64_t g = ((vec ? n / 4 : n) + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(tsg::sgd_dev_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     momentum_buf, n, lr_dev, lr_mult, momentum, weight_decay, grad_scale);
+                     momentum_buf, n, lr_dev, lr_mult, momentum, weight_decay, grad_scale, vec);
   TSG_CHECK_LAUNCH();
   return 0;
 }
@@ -86,12 +86,12 @@ extern "C" int tsg_sgd_step(float* param, const float* grad, float* momentum_buf
                             void* stream) {
   if (!param || !grad || !momentum_buf) return TSG_E_NULL;
   if (n <= 0) return TSG_E_SHAPE;
-  if (!tsg::aligned16(param) || !tsg::aligned16(grad) || !tsg::aligned16(momentum_buf)) return TSG_E_ALIGN;
-  int64_t g = (n / 4 + 255) / 256;
+  const int vec = tsg::aligned16(param) && tsg::aligned16(grad) && tsg::aligned16(momentum_buf);
+  int64_t g = ((vec ? n / 4 : n) + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(tsg::sgd_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     momentum_buf, n, lr, momentum, weight_decay, grad_scale, first_step);
+                     momentum_buf, n, lr, momentum, weight_decay, grad_scale, first_step, vec);
   TSG_CHECK_LAUNCH();
   return 0;
 }

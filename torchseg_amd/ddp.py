@@ -67,7 +67,7 @@ class _Bucket(object):
         n = 0
         for p in params:
             self.offsets.append(n)
-            n += p.numel()
+            n += (p.numel() + 3) // 4 * 4        # keep every gradient view 16-byte aligned (vector kernels)
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.pending = len(params)
         self.work = None
