@@ -162,6 +162,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's banner off stdout (one JSON line contract)
     os.environ["TSG_DTYPE"] = args.dtype
     from torchseg_amd.tuning import use_shipped_miopen_db
     use_shipped_miopen_db(rank=rank)
@@ -257,6 +259,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    out = None
     if rank == 0:
         global_batch = args.batch * world
         value = global_batch * args.steps / dt
@@ -279,9 +282,18 @@ def main():
             out["kernels_last_warmup_step"] = all_kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if world > 1 or force_coll:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is block-buffered when stdout is a
+        # pipe/file: flush it first so that the JSON line is the LAST thing on stdout.
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
