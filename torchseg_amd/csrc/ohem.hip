@@ -26,6 +26,7 @@
 #include "tsg_resample.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace tsg {
 
@@ -829,7 +830,9 @@ int tsg_ohem_fwd(const void* logits, int dtype, const void* labels, int ltype, i
   const int native = dtype == TSG_BF16 ? 8 : 4;
   const bool vec = (HW % native == 0) && aligned16(logits) && aligned16(nll) && aligned16(lse);
   const int bins0 = pl.levels > 0 ? pl.bins[0] : 0;
-  const size_t sh = (size_t)(bins0 > 0 ? bins0 : 1) * sizeof(uint32_t);
+  static const size_t pa_throttle = [] { const char* e = getenv("TSG_OHEM_FWD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+  size_t sh = (size_t)(bins0 > 0 ? bins0 : 1) * sizeof(uint32_t);
+  if (sh < pa_throttle) sh = pa_throttle;
 #define PA(T, VV, LTT)                                                                         \
   hipLaunchKernelGGL((ohem_pass_a<T, VV, LTT>), dim3(pl.grid), dim3(kT), sh, st, (const T*)logits, \
                      labels, pl.P, C, HW, ignore_label, thresh, tb, pl.shift[0], bins0, weight, \
@@ -861,8 +864,12 @@ int tsg_ohem_bwd(const void* logits, int dtype, const void* labels, int ltype, i
   const bool vec = (HW % native == 0) && aligned16(logits) && aligned16(dlogits);
   const int V = vec ? native : 1;
   const int grid = pixel_grid(P / V);
+  // occupancy throttle (tuning knob): unused dynamic LDS caps the resident waves per CU
+  // (measured on MI355X, 16x19x1024^2 bf16: 0 B -> 407 us, 40 KB (4 blocks/CU) -> 354 us, 64 KB -> 476 us: with 38
+  //  concurrent 2-MB-strided class planes per block, fewer resident blocks thrash DRAM pages / L2 less)
+  static const size_t throttle = [] { const char* e = getenv("TSG_OHEM_BWD_LDS"); return e ? (size_t)atol(e) : (size_t)40000; }();
 #define PB(T, VV, LTT)                                                                          \
-  hipLaunchKernelGGL((ohem_bwd_k<T, VV, LTT>), dim3(grid), dim3(kT), 0, st, (const T*)logits, labels, \
+  hipLaunchKernelGGL((ohem_bwd_k<T, VV, LTT>), dim3(grid), dim3(kT), throttle, st, (const T*)logits, labels, \
                      P, C, HW, ignore_label, weight, nll, lse, sel, gscale, (T*)dlogits)
   if (dtype == TSG_F32) {
     if (vec) { if (ltype == TSG_I64) PB(float, 4, TSG_I64); else PB(float, 4, TSG_U8); }

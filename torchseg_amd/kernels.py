@@ -59,12 +59,20 @@ class HipKernels:
 
     def __init__(self):
         self.lib = L.lib()
+        self._npart = {}
+
+    def _num_partials(self, layout, N, Cc, HW):
+        key = (layout, N, Cc, HW)
+        v = self._npart.get(key)
+        if v is None:
+            v = self._npart[key] = self.lib.tsg_bn_num_partials(layout, N, Cc, HW)
+        return v
 
     # ---- SyncBN -----------------------------------------------------------
     def bn_stats(self, x, layout, N, Cc, HW):
         """-> (partial fp32 [S,2,C], S)"""
         lib = self.lib
-        smax = lib.tsg_bn_num_partials(layout, N, Cc, HW)
+        smax = self._num_partials(layout, N, Cc, HW)
         partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
         rows = C.c_int(0)
         L.check(lib.tsg_bn_stats(x.data_ptr(), L.dtype_code(x), layout, N, Cc, HW,
@@ -106,7 +114,7 @@ class HipKernels:
     def bn_bwd_reduce(self, dy, x, y, layout, N, Cc, HW, fp, relu):
         """-> (partial fp32 [S,2,C] = {sum dy', sum dy'(x-mean)}, S)"""
         lib = self.lib
-        smax = lib.tsg_bn_num_partials(layout, N, Cc, HW)
+        smax = self._num_partials(layout, N, Cc, HW)
         partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
         rows = C.c_int(0)
         L.check(lib.tsg_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), L.ptr(y), L.dtype_code(x),
