@@ -131,16 +131,33 @@ __global__ __launch_bounds__(256) void psa_split_k(const float* __restrict__ in,
   }
 }
 
-// delta[b][j] = sum_c out[b][c][j] * dout[b][c][j]
+// delta[b][j] = sum_c out[b][c][j] * dout[b][c][j]; stage 1 splits the Cx rows over
+// gridDim.y chunks (a single pass had only N/256 blocks in flight), stage 2 folds them.
+constexpr int kDeltaChunks = 16;
+
 template <typename T>
 __global__ __launch_bounds__(256) void psa_delta(const T* __restrict__ out, const T* __restrict__ dout,
-                                                 int64_t Cx, int64_t N, float* __restrict__ delta) {
+                                                 int64_t Cx, int64_t N, float* __restrict__ part) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  if (j >= N) return;
+  const int64_t per = (Cx + kDeltaChunks - 1) / kDeltaChunks;
+  int64_t c0 = chunk * per, c1 = c0 + per;
+  if (c1 > Cx) c1 = Cx;
+  float acc = 0.f;
+  for (int64_t c = c0; c < c1; ++c)
+    acc += ld1<T>(out + (b * Cx + c) * N + j) * ld1<T>(dout + (b * Cx + c) * N + j);
+  part[(b * kDeltaChunks + chunk) * N + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void psa_delta_fold(const float* __restrict__ part, int64_t N,
+                                                      float* __restrict__ delta) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t b = blockIdx.y;
   if (j >= N) return;
   float acc = 0.f;
-  for (int64_t c = 0; c < Cx; ++c)
-    acc += ld1<T>(out + (b * Cx + c) * N + j) * ld1<T>(dout + (b * Cx + c) * N + j);
+  for (int c = 0; c < kDeltaChunks; ++c) acc += part[(b * kDeltaChunks + c) * N + j];
   delta[b * N + j] = acc;
 }
 
@@ -288,6 +305,7 @@ struct PsaWs {
   bf16_t* D_hi; bf16_t* D_lo;        // bwd: dOut (split) and dOut^T
   bf16_t* Dt_hi; bf16_t* Dt_lo;
   float* delta;
+  float* delta_part;                 // [B, kDeltaChunks, N]
   float* dP;                         // fp32 path bwd: [B, K, N]
   size_t total;
 };
@@ -306,13 +324,14 @@ static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, 
   w.P_lo = f32 ? (bf16_t*)take((size_t)B * K * N * 2) : nullptr;
   w.X_hi = (bf16_t*)take((size_t)B * Cx * K * 2);
   w.X_lo = f32 ? (bf16_t*)take((size_t)B * Cx * K * 2) : nullptr;
-  w.D_hi = w.D_lo = w.Dt_hi = w.Dt_lo = nullptr; w.delta = nullptr; w.dP = nullptr;
+  w.D_hi = w.D_lo = w.Dt_hi = w.Dt_lo = nullptr; w.delta = nullptr; w.delta_part = nullptr; w.dP = nullptr;
   if (bwd) {
     w.D_hi = (bf16_t*)take((size_t)B * Cx * N * 2);
     w.D_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
     w.Dt_hi = (bf16_t*)take((size_t)B * Cx * N * 2);
     w.Dt_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
     w.delta = (float*)take((size_t)B * N * 4);
+    w.delta_part = (float*)take((size_t)B * kDeltaChunks * N * 4);
     w.dP = f32 ? (float*)take((size_t)B * K * N * 4) : nullptr;
   }
   w.total = off;
@@ -405,6 +424,7 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
   dim3 xgrid((unsigned)((K + 63) / 64), (unsigned)((Cx + 63) / 64), (unsigned)B);   // X [Cx, K] -> [K, Cx]
   dim3 dgrid((unsigned)((N + 63) / 64), (unsigned)((Cx + 63) / 64), (unsigned)B);   // dOut [Cx, N] -> [N, Cx]
   dim3 jgrid((unsigned)((N + 255) / 256), (unsigned)B);
+  dim3 dgrid3((unsigned)((N + 255) / 256), (unsigned)kDeltaChunks, (unsigned)B);
   GemmArgs gx = {};   // dX[c][i] = sum_j dOut[c][j] * P[i][j]
   gx.M = Cx; gx.N = K; gx.K = N; gx.sA = Cx * N; gx.sB = K * N; gx.sC = Cx * K; gx.C = dX;
   GemmArgs ga = {};   // dP[i][j] = sum_c Xt[i][c] * dOt[j][c]
@@ -412,7 +432,9 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
   if (f32) {
     hipLaunchKernelGGL((psa_prob<float, true>), pgrid, dim3(256), 0, st, (const float*)A, lse, K, N, w.P_hi, w.P_lo);
     TSG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((psa_delta<float>), jgrid, dim3(256), 0, st, (const float*)out, (const float*)dout, Cx, N, w.delta);
+    hipLaunchKernelGGL((psa_delta<float>), dgrid3, dim3(256), 0, st, (const float*)out, (const float*)dout, Cx, N, w.delta_part);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(psa_delta_fold, jgrid, dim3(256), 0, st, w.delta_part, N, w.delta);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL(psa_split_k, dim3(egrid(B * Cx * N)), dim3(256), 0, st, (const float*)dout, B * Cx * N, w.D_hi, w.D_lo);
     TSG_CHECK_LAUNCH();
@@ -443,7 +465,9 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
     hipLaunchKernelGGL((psa_prob<bf16_t, false>), pgrid, dim3(256), 0, st, (const bf16_t*)A, lse, K, N, w.P_hi,
                        (bf16_t*)nullptr);
     TSG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((psa_delta<bf16_t>), jgrid, dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta);
+    hipLaunchKernelGGL((psa_delta<bf16_t>), dgrid3, dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta_part);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(psa_delta_fold, jgrid, dim3(256), 0, st, w.delta_part, N, w.delta);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL((psa_transpose<bf16_t, 0, false>), xgrid, dim3(256), 0, st, (const bf16_t*)X,
                        (const float*)nullptr, Cx, K, w.X_hi, (bf16_t*)nullptr);
