@@ -85,3 +85,55 @@ def test_other_families_import_and_step(tmp_path, family, exp, kind, nparam):
     assert np.isfinite(out["loss"])
     if kind == "dfn":
         assert out["nograd"] == 5      # statically unused params: DDP must tolerate them
+
+
+_WORKLOAD_EQ = r'''
+import json, torch, torch.nn as nn
+from config import config
+import network
+kind = "%s"
+def build(ref):
+    torch.manual_seed(3)
+    crit = nn.CrossEntropyLoss(reduction='mean', ignore_index=-1)
+    if kind == "dfn":
+        from oracle.focal_ref import SigmoidFocalLoss
+        args = dict(criterion=nn.CrossEntropyLoss(ignore_index=255), aux_criterion=SigmoidFocalLoss(255, 2.0, 0.25),
+                    alpha=config.aux_loss_alpha, pretrained_model=None, norm_layer=nn.BatchNorm2d)
+        if ref:
+            return network.DFN(config.num_classes, **args)
+        from torchseg_amd.workloads.dfn import DFN
+        return DFN(config.num_classes, **args)
+    if ref:
+        return network.PSPNet(config.num_classes, criterion=crit, pretrained_model=None, norm_layer=nn.BatchNorm2d)
+    from torchseg_amd.workloads.pspnet import PSPNet, PSANet
+    cls = PSPNet if kind == "pspnet" else PSANet
+    return cls(config.num_classes, crit, None, nn.BatchNorm2d, depth=50)
+ref, ours = build(True), build(False)
+sr, so = ref.state_dict(), ours.state_dict()
+assert list(sr.keys()) == list(so.keys()), [k for k in sr if k not in so][:5]
+assert all(torch.equal(sr[k], so[k]) for k in sr), "seeded init differs"
+ref.eval(); ours.eval()            # dropout off, running stats: deterministic comparison
+g = torch.Generator().manual_seed(1)
+if kind == "dfn":
+    x = torch.randn(1, 3, 64, 64, generator=g); y = torch.randint(0, config.num_classes, (1, 64, 64), generator=g)
+    e = torch.randint(0, 2, (1, 64, 64), generator=g)
+    lr, lo = ref(x, y, e), ours(x, y, e)
+else:
+    S = 480 if kind == "psanet" else 96
+    x = torch.randn(1, 3, S, S, generator=g); y = torch.randint(0, config.num_classes, (1, S, S), generator=g)
+    lr, lo = ref(x, y), ours(x, y)
+print(json.dumps(dict(loss_ref=lr.item(), loss_ours=lo.item(), nkeys=len(sr))))
+'''
+
+
+@pytest.mark.parametrize("family,exp,kind", [
+    ("pspnet", "ade.pspnet.R50_v1c", "pspnet"),
+    ("dfn", "cityscapes.dfn.R101_v1c", "dfn"),
+    ("psanet", "ade.psanet.R50_v1c", "psanet"),
+])
+def test_workload_builders_equal_reference_networks(tmp_path, family, exp, kind):
+    """torchseg_amd/workloads/{pspnet,dfn}.py are the reference networks: same state-dict keys,
+    identical seeded init, identical loss."""
+    d = stage(tmp_path, family, exp)
+    out = json.loads(run_in(d, _WORKLOAD_EQ % kind, timeout=900).strip().splitlines()[-1])
+    assert abs(out["loss_ref"] - out["loss_ours"]) <= 1e-5 * max(1.0, abs(out["loss_ref"])), out

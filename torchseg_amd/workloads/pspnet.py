@@ -1,0 +1,125 @@
+"""PSPNet and PSANet (dilated ResNet-v1c backbones) — BASELINE configs 3 and 5.
+
+Architectures of model/pspnet/ade.pspnet.R50_v1c/network.py:14-109 (PSPNet :14-72,
+PyramidPooling :75-109) and model/psanet/ade.psanet.R101_v1c/network.py:14-144
+(PointwiseSpatialAttention :75-144), on the furnace surface; attribute names and
+construction order follow the reference files (state dicts interchangeable).
+PSANet's attention is written exactly as the reference writes it,
+`torch.bmm(x, torch.softmax(a, dim=1))`: the fusion into the MFMA kernel happens
+in torchseg_amd.psa.FusePsaMode, as it does for the unchanged network.py.
+"""
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ensure_furnace_on_path
+
+ensure_furnace_on_path()
+from base_model import resnet50, resnet101  # noqa: E402
+from seg_opr.seg_oprs import ConvBnRelu  # noqa: E402
+
+
+def _cbr(cin, cout, k, s, p, norm_layer, bn=True, relu=True):
+    return ConvBnRelu(cin, cout, k, s, p, has_bn=bn, has_relu=relu, has_bias=False, norm_layer=norm_layer)
+
+
+def _up(x, size=None, scale=None):
+    return F.interpolate(x, size=size, scale_factor=scale, mode='bilinear', align_corners=True)
+
+
+def _nostride_dilate(m, dilate):
+    """stride-2 convs become stride 1 and the 3x3 convs get dilated (pspnet network.py:62-72)."""
+    if isinstance(m, nn.Conv2d):
+        if m.stride == (2, 2):
+            m.stride = (1, 1)
+            if m.kernel_size == (3, 3):
+                m.dilation = (dilate // 2, dilate // 2)
+                m.padding = (dilate // 2, dilate // 2)
+        elif m.kernel_size == (3, 3):
+            m.dilation = (dilate, dilate)
+            m.padding = (dilate, dilate)
+
+
+class PyramidPooling(nn.Module):
+    def __init__(self, name, out_planes, fc_dim=4096, pool_scales=(1, 2, 3, 6), norm_layer=nn.BatchNorm2d):
+        super(PyramidPooling, self).__init__()
+        self.ppm = nn.ModuleList([
+            nn.Sequential(OrderedDict([('{}/pool_1'.format(name), nn.AdaptiveAvgPool2d(scale)),
+                                       ('{}/cbr'.format(name), _cbr(fc_dim, 512, 1, 1, 0, norm_layer))]))
+            for scale in pool_scales])
+        self.conv6 = nn.Sequential(_cbr(fc_dim + len(pool_scales) * 512, 512, 3, 1, 1, norm_layer),
+                                   nn.Dropout2d(0.1, inplace=False),
+                                   nn.Conv2d(512, out_planes, kernel_size=1))
+
+    def forward(self, x):
+        size = x.shape[2:]
+        return self.conv6(torch.cat([x] + [_up(p(x), size=size) for p in self.ppm], 1))
+
+
+class PointwiseSpatialAttention(nn.Module):
+    def __init__(self, name, out_planes, fc_dim=4096, pool_scales=(1, 2, 3, 6), norm_layer=nn.BatchNorm2d):
+        super(PointwiseSpatialAttention, self).__init__()
+        self.inner_channel = 512
+
+        def attention():
+            return nn.Sequential(_cbr(512, 512, 1, 1, 0, norm_layer),
+                                 _cbr(512, 3600, 1, 1, 0, norm_layer, bn=False, relu=False))
+        self.collect_reduction = _cbr(fc_dim, 512, 1, 1, 0, norm_layer)
+        self.collect_attention = attention()
+        self.distribute_reduction = _cbr(fc_dim, 512, 1, 1, 0, norm_layer)
+        self.distribute_attention = attention()
+        self.proj = _cbr(1024, 2048, 1, 1, 0, norm_layer)
+        self.conv6 = nn.Sequential(_cbr(fc_dim + len(pool_scales) * 512, 512, 3, 1, 1, norm_layer),
+                                   nn.Dropout2d(0.1, inplace=False),
+                                   nn.Conv2d(512, out_planes, kernel_size=1))
+
+    def _branch(self, x, reduction, attention):
+        rx = reduction(x)
+        a = attention(rx)
+        b, c, h, w = a.size()
+        fm = torch.bmm(rx.view(b, self.inner_channel, -1), torch.softmax(a.view(b, c, -1), dim=1))
+        return fm.view(b, self.inner_channel, h, w)
+
+    def forward(self, x):
+        collect = self._branch(x, self.collect_reduction, self.collect_attention)
+        distribute = self._branch(x, self.distribute_reduction, self.distribute_attention)
+        psa = self.proj(torch.cat([collect, distribute], dim=1))
+        return self.conv6(torch.cat([x, psa], dim=1))
+
+
+class _DilatedSegNet(nn.Module):
+    def __init__(self, out_planes, criterion, backbone, head_cls, head_attr, pretrained_model=None,
+                 norm_layer=nn.BatchNorm2d, bn_eps=1e-5, bn_momentum=0.1):
+        super(_DilatedSegNet, self).__init__()
+        self.backbone = backbone(pretrained_model, norm_layer=norm_layer, bn_eps=bn_eps, bn_momentum=bn_momentum,
+                                 deep_stem=True, stem_width=64)
+        self.backbone.layer3.apply(partial(_nostride_dilate, dilate=2))
+        self.backbone.layer4.apply(partial(_nostride_dilate, dilate=4))
+        self.business_layer = []
+        self._head_attr = head_attr
+        setattr(self, head_attr, head_cls(head_attr.split('_')[0], out_planes, 2048, norm_layer=norm_layer))
+        self.aux_layer = nn.Sequential(_cbr(1024, 1024, 3, 1, 1, norm_layer), nn.Dropout2d(0.1, inplace=False),
+                                       nn.Conv2d(1024, out_planes, kernel_size=1))
+        self.business_layer += [getattr(self, head_attr), self.aux_layer]
+        self.criterion = criterion
+
+    def forward(self, data, label=None):
+        blocks = self.backbone(data)
+        fm = F.log_softmax(_up(getattr(self, self._head_attr)(blocks[-1]), scale=8), dim=1)
+        aux = F.log_softmax(_up(self.aux_layer(blocks[-2]), scale=8), dim=1)
+        if label is not None:
+            return self.criterion(fm, label) + 0.4 * self.criterion(aux, label)   # network.py:53-57
+        return fm
+
+
+def PSPNet(out_planes, criterion, pretrained_model=None, norm_layer=nn.BatchNorm2d, depth=50, **kw):
+    return _DilatedSegNet(out_planes, criterion, resnet50 if depth == 50 else resnet101, PyramidPooling,
+                          'psp_layer', pretrained_model, norm_layer, **kw)
+
+
+def PSANet(out_planes, criterion, pretrained_model=None, norm_layer=nn.BatchNorm2d, depth=101, **kw):
+    return _DilatedSegNet(out_planes, criterion, resnet50 if depth == 50 else resnet101,
+                          PointwiseSpatialAttention, 'psa_layer', pretrained_model, norm_layer, **kw)
