@@ -189,6 +189,23 @@ int tsg_maxpool_nhwc_bwd(const void* dy, const void* argmax_u8, void* dx, int dt
                          int64_t N, int C, int IH, int IW, int OH, int OW,
                          int K, int S, int P, void* stream);
 
+/* Stem convolution — replaces the cuDNN call behind nn.Conv2d(3, 64, kernel_size=7,
+ * stride=2, padding=3, bias=False): ResNet conv1 (furnace/base_model/resnet.py:96-97) and
+ * BiSeNet's SpatialPath.conv_7x7 (model/bisenet/cityscapes.bisenet.R18/network.py:116,
+ * through ConvBnRelu, furnace/seg_opr/seg_oprs.py:27-31).  The image needs no gradient, so
+ * training is forward + weight gradient.  x [B,3,H,W] bf16 NCHW (W even); y and dy
+ * [B,OH,OW,64] bf16 channels_last, OH = (H-1)/2+1; w and dw fp32 [64,3,7,7] (rounded to bf16
+ * for the MFMA as autocast does; fp32 accumulation; dw summed in a fixed order).
+ * ws: tsg_stem_conv_ws_bytes() bytes, 16-B aligned.  tsg_stem_conv_supported returns 1 when
+ * a convolution with these hyper-parameters is handled here. */
+int tsg_stem_conv_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                            int dilation, int groups, int64_t H, int64_t W);
+size_t tsg_stem_conv_ws_bytes(void);
+int tsg_stem_conv_fwd(const void* x, const float* w, void* y, int64_t B, int64_t H, int64_t W,
+                      void* ws, size_t ws_bytes, void* stream);
+int tsg_stem_conv_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
  * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.

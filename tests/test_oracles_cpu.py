@@ -67,3 +67,19 @@ def test_nearest_oracle_matches_torch_cpu():
     for oh, ow in [(10, 15), (40, 45), (7, 11), (20, 30)]:
         y = F.interpolate(x, size=(oh, ow), mode="nearest")
         np.testing.assert_array_equal(upsample_ref.upsample_nearest(x.numpy(), oh, ow), y.numpy())
+
+
+def test_conv_oracle_matches_torch_cpu_convolution():
+    """oracle/conv_ref.py (tap-by-tap restatement) == torch's CPU conv2d and its autograd, fp64."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import conv_ref
+    g = torch.Generator().manual_seed(4)
+    for (B, H, W) in [(2, 20, 24), (1, 33, 18)]:
+        x = torch.randn(B, 3, H, W, dtype=torch.float64, generator=g)
+        w = torch.randn(64, 3, 7, 7, dtype=torch.float64, generator=g).requires_grad_()
+        y = F.conv2d(x, w, None, 2, 3)
+        dy = torch.randn(y.shape, dtype=torch.float64, generator=g)
+        y.backward(dy)
+        assert torch.allclose(conv_ref.conv2d_ref(x, w.detach()), y.detach(), rtol=0, atol=1e-11)
+        assert torch.allclose(conv_ref.conv2d_wgrad_ref(x, dy), w.grad, rtol=0, atol=1e-10)

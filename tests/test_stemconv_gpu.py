@@ -1,0 +1,78 @@
+"""GPU parity of tsg_stem_conv_fwd/_wrw (through the C-ABI) with oracle/conv_ref.py on the same
+bf16-rounded operands.  Tolerances: y is bf16 -> one bf16 ulp of the fp64 result (2^-8 relative)
+plus 1e-3 of the output scale for cancellation; dw is fp32 -> 1e-4 relative L2 (north_star)."""
+import pytest
+import torch
+
+from oracle import conv_ref
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 64, 64), (1, 70, 96), (3, 22, 130), (2, 129, 66), (1, 8, 2)]
+
+
+def _data(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, 64, oh, ow, generator=g)
+    return x, w, dy
+
+
+def _check(cuda, B, H, W, seed=0):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    x, w, dy = _data(B, H, W, seed)
+    xb = x.to(cuda).bfloat16()
+    assert kp.stem_conv_supported(xb, w.to(cuda), 2, 3, 1, 1)
+    y = kp.stem_conv_fwd(xb, w.to(cuda))
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.dtype == torch.bfloat16
+    y_ref = conv_ref.conv2d_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(w))
+    err = (y.double().cpu() - y_ref).abs()
+    bound = y_ref.abs() * 2.0 ** -8 + 1e-3 * y_ref.abs().max()
+    assert bool((err <= bound).all()), (err.max().item(), y_ref.abs().max().item())
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dw = kp.stem_conv_wrw(xb, dyb)
+    dw_ref = conv_ref.conv2d_wgrad_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(dy))
+    rel = ((dw.double().cpu() - dw_ref).norm() / dw_ref.norm()).item()
+    assert rel <= 1e-4, rel
+    return y, dw
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_stem_conv_vs_oracle(cuda, shape):
+    _check(cuda, *shape)
+
+
+def test_stem_conv_full_size_and_determinism(cuda):
+    """BASELINE config 2 geometry (1024^2 crops; B = 4 keeps the fp64 oracle to seconds), run twice: bit-identical."""
+    y1, dw1 = _check(cuda, 4, 1024, 1024, seed=3)
+    y2, dw2 = _check(cuda, 4, 1024, 1024, seed=3)
+    assert torch.equal(y1, y2) and torch.equal(dw1, dw2)
+
+
+def test_stem_conv_module_swap_matches_stock_autocast(cuda):
+    """StemConv2d under autocast == nn.Conv2d under autocast (MIOpen) on the same weights: output within
+    bf16 rounding, weight gradient within 1e-2 relative L2 of each other (both round operands to bf16)."""
+    import torch.nn as nn
+    from torchseg_amd.stemconv import StemConv2d, install_stem_conv
+    torch.manual_seed(0)
+    ref = nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(cuda)
+    mod = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False)).to(cuda)
+    mod[0].load_state_dict(ref.state_dict())
+    assert install_stem_conv(mod) == 1 and isinstance(mod[0], StemConv2d)
+    x = torch.randn(2, 3, 96, 160, device=cuda)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y0, y1 = ref(x), mod(x)
+    assert y1.dtype == torch.bfloat16 and y1.shape == y0.shape
+    assert (y1.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * y0.float().abs().max().item()
+    dy = torch.randn_like(y0)
+    y0.backward(dy)
+    y1.backward(dy)
+    g0, g1 = ref.weight.grad, mod[0].weight.grad
+    assert g1.dtype == torch.float32
+    assert ((g1 - g0).norm() / g0.norm()).item() <= 1e-2
+    # fp32 compute stays on the stock convolution
+    y2 = mod(x)
+    assert y2.dtype == torch.float32

@@ -57,6 +57,10 @@ _PROTOS = {
     "tsg_chanscale_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p, _sz, _p]),
     "tsg_maxpool_nhwc_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tsg_maxpool_nhwc_bwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tsg_stem_conv_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64]),
+    "tsg_stem_conv_ws_bytes": (_sz, []),
+    "tsg_stem_conv_fwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_stem_conv_wrw": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),
     "tsg_ohem_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _f, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tsg_ohem_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -1,0 +1,337 @@
+// Stem convolution of the ResNet-18 context path and of BiSeNet's spatial path:
+// Conv2d(3, 64, kernel 7, stride 2, padding 3, bias=False) on a [B,3,H,W] image
+// (furnace/base_model/resnet.py:96-97 conv1; model/bisenet/*/network.py:116
+// SpatialPath.conv_7x7).  The input needs no gradient, so the training step is
+// forward + weight gradient.  Both are implicit GEMMs on the bf16 MFMA
+// (32x32x16), memory-bound by the [B,OH,OW,64] activation (0.54 GB at B=16,
+// 1024^2):
+//
+//   K axis of the GEMM: k = r * 8 + s, r = ic * 7 + kh (21 rows + 1 zero row),
+//   s = kw + 1 (slot 0 is a zero tap) -> 176.  With that padding the 8 taps of a
+//   K-fragment are 8 consecutive input columns starting at the even column
+//   2*ow - 4, i.e. four aligned 32-bit LDS reads from the staged input patch.
+//
+//   forward : y[pixel][oc] = sum_k im2col[pixel][k] * w[oc][k]; weights live in
+//             registers (A operand), pixels stream through LDS (B operand); the
+//             tile is re-laid through LDS so every lane stores 16 B of NHWC.
+//   wgrad   : dw[oc][k] = sum_pixel dy[pixel][oc] * im2col[pixel][k]; the GEMM K
+//             axis is the pixel axis, so dy is transposed through LDS and the
+//             patch is staged as even/odd column planes (two alignments each) to
+//             keep the 8 consecutive pixels of a fragment contiguous.  Persistent
+//             blocks accumulate in MFMA registers; per-block partials are summed
+//             in a fixed order (fp64) => deterministic, no atomics.
+//
+// x: NCHW bf16.  y / dy: NHWC bf16 (channels_last).  w / dw: fp32 [64,3,7,7].
+#include "tsg_common.h"
+
+namespace tsg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int SC_OC = 64;
+constexpr int SC_KP = 176;             // padded GEMM-K: 22 rows x 8 slots
+constexpr int SC_KSTEPS = SC_KP / 16;  // 11
+constexpr int SC_TH = 4, SC_TW = 32;   // output tile of a block: 4 rows (one per wave) x 32 columns
+constexpr int SC_PR = 2 * SC_TH + 5;   // 13 input rows per channel
+constexpr int SC_PD = SC_TW + 4;       // 36 dwords = 72 input columns (70 used), origin column 2*ow0 - 4
+constexpr int SC_NPART = 768;          // persistent blocks of the weight-gradient kernel (3 per CU)
+
+// ---------------------------------------------------------------- weights -> bf16 [64][176]
+__global__ void stem_pack_w(const float* __restrict__ w, bf16_t* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= SC_OC * SC_KP) return;
+  const int oc = i / SC_KP, k = i % SC_KP, r = k >> 3, s = k & 7;
+  float v = 0.f;
+  if (r < 21 && s >= 1) v = w[oc * 147 + r * 7 + (s - 1)];
+  wp[i] = f32_to_bf16(v);
+}
+
+struct StemGeom {
+  int B, H, W, OH, OW, tiles_h, tiles_w, ntiles;
+};
+
+__device__ __forceinline__ uint32_t load_pair(const bf16_t* __restrict__ x, const StemGeom& g, int b, int ic, int ih,
+                                              int iw) {
+  // iw is even and W is even: the pair is either fully inside the image or fully in the padding
+  if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0u;
+  return *reinterpret_cast<const uint32_t*>(x + (((int64_t)b * 3 + ic) * g.H + ih) * g.W + iw);
+}
+
+// ---------------------------------------------------------------- forward
+constexpr int SC_NPD = 3 * SC_PR * SC_PD;               // 1404 input dwords per tile
+constexpr int SC_NPF = (SC_NPD + 255) / 256;            // 6 per thread
+
+struct TilePos { int b, oh0, ow0; };
+__device__ __forceinline__ TilePos tile_pos(const StemGeom& g, int tile) {
+  TilePos t;
+  t.ow0 = (tile % g.tiles_w) * SC_TW;
+  t.oh0 = ((tile / g.tiles_w) % g.tiles_h) * SC_TH;
+  t.b = tile / (g.tiles_w * g.tiles_h);
+  return t;
+}
+
+__device__ __forceinline__ void fetch_patch(const bf16_t* __restrict__ x, const StemGeom& g, const TilePos& tp, int tid,
+                                            uint32_t (&rp)[SC_NPF]) {
+#pragma unroll
+  for (int u = 0; u < SC_NPF; ++u) {
+    const int idx = tid + 256 * u;
+    rp[u] = 0u;
+    if (idx < SC_NPD) {
+      const int pr = idx / SC_PD, dc = idx % SC_PD, ic = pr / SC_PR, rr = pr % SC_PR;
+      rp[u] = load_pair(x, g, tp.b, ic, 2 * tp.oh0 - 3 + rr, 2 * tp.ow0 - 4 + 2 * dc);
+    }
+  }
+}
+
+// 4 waves: wave = (row pair wr) * 2 + (oc half wm).  A wave keeps the weights of its 32 output channels in
+// registers (11 K-fragments) and runs two pixel rows against them.
+__global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                  bf16_t* __restrict__ y, StemGeom g) {
+  __shared__ __attribute__((aligned(16))) uint32_t patch[SC_NPD];                 // 5616 B
+  __shared__ __attribute__((aligned(16))) bf16_t outs[SC_TH * SC_TW * 72];        // 18432 B: [pixel][64 oc + 8 pad]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int wm = wave & 1, wr = wave >> 1;
+
+  bf16x8 fw[SC_KSTEPS];
+#pragma unroll
+  for (int t = 0; t < SC_KSTEPS; ++t)
+    fw[t] = *reinterpret_cast<const bf16x8*>(wp + (wm * 32 + p) * SC_KP + t * 16 + half * 8);
+
+  uint32_t rp[SC_NPF];
+  int tile = blockIdx.x;
+  if (tile < g.ntiles) fetch_patch(x, g, tile_pos(g, tile), tid, rp);
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    const TilePos tp = tile_pos(g, tile);
+    __syncthreads();                                   // the previous tile's reads of patch/outs are done
+#pragma unroll
+    for (int u = 0; u < SC_NPF; ++u)
+      if (tid + 256 * u < SC_NPD) patch[tid + 256 * u] = rp[u];
+    __syncthreads();
+    if (tile + (int)gridDim.x < g.ntiles)              // in flight during the MFMAs below
+      fetch_patch(x, g, tile_pos(g, tile + gridDim.x), tid, rp);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < SC_KSTEPS; ++t) {
+      int r = 2 * t + half;
+      if (r >= 21) r = 0;                              // zero weights: any finite data will do
+      const int ic = r / 7, kh = r % 7;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t* q = patch + (ic * SC_PR + 2 * (2 * wr + i) + kh) * SC_PD + p;
+        union { uint32_t u[4]; bf16x8 v; } fb;
+        fb.u[0] = q[0]; fb.u[1] = q[1]; fb.u[2] = q[2]; fb.u[3] = q[3];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[t], fb.v, acc[i], 0, 0, 0);
+      }
+    }
+
+    // acc[i][r]: oc = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, pixel = (row 2 wr + i, column p).  Re-lay as [pixel][oc].
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int oc0 = 32 * wm + 8 * gq + 4 * half;
+        uint2 v;
+        v.x = (uint32_t)f32_to_bf16(acc[i][4 * gq + 0]) | ((uint32_t)f32_to_bf16(acc[i][4 * gq + 1]) << 16);
+        v.y = (uint32_t)f32_to_bf16(acc[i][4 * gq + 2]) | ((uint32_t)f32_to_bf16(acc[i][4 * gq + 3]) << 16);
+        *reinterpret_cast<uint2*>(outs + ((2 * wr + i) * SC_TW + p) * 72 + oc0) = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int c = tid + 256 * qd, pl = c >> 3, part = c & 7, row = pl >> 5, pix = pl & 31;
+      const int oh = tp.oh0 + row, ow = tp.ow0 + pix;
+      if (oh < g.OH && ow < g.OW)
+        *reinterpret_cast<uint4*>(y + (((int64_t)tp.b * g.OH + oh) * g.OW + ow) * SC_OC + part * 8) =
+            *reinterpret_cast<const uint4*>(outs + pl * 72 + part * 8);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+constexpr int SC_DS = 136;                 // dy^T row: 128 pixels + 8 pad (272 B, 16-B multiple)
+constexpr int SC_RS = 24;                  // plane row stride in dwords (bank pattern: rows land 24 apart)
+constexpr int SC_RIC = 15;                 // plane rows per input channel (13 used); 15 = 7 mod 8 keeps r -> bank regular
+constexpr int SC_PLANE = 1088;             // dwords per plane copy (45 rows x 24 = 1080, rounded to 17 x 64)
+
+__device__ __forceinline__ int plane_base(int q, int sg) {   // parity q, alignment copy sg; bank offsets 0, 1, 32, 33
+  return (q * 2 + sg) * SC_PLANE + sg + 32 * q;
+}
+
+__global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                  float* __restrict__ part, StemGeom g) {
+  __shared__ __attribute__((aligned(16))) bf16_t dyT[SC_OC * SC_DS];       // 17408 B: [oc][pixel of the tile]
+  __shared__ __attribute__((aligned(16))) uint32_t planes[4 * SC_PLANE];   // 17408 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, n = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bbase[3];                            // dword offset of this lane's tap (k index) for its 3 N-tiles
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k = 32 * (3 * wn + j) + n;
+    int r = k >> 3, s = k & 7;
+    if (r >= 21) { r = 0; s = 0; }         // columns 168..191 of the GEMM are padding, never written out
+    const int ic = r / 7, kh = r % 7, q = s & 1, sh = s >> 1, sg = sh & 1;
+    bbase[j] = plane_base(q, sg) + (ic * SC_RIC + kh) * SC_RS + ((sh + sg) >> 1);
+  }
+  bf16_t* pl16 = reinterpret_cast<bf16_t*>(planes);
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int spix = tid & 31, spart = tid >> 5;          // dy staging: pixel within a tile row, group of 8 oc
+  uint4 rd[SC_TH];
+  uint32_t rp[SC_NPF];
+  auto fetch = [&](int tile) {
+    const TilePos tp = tile_pos(g, tile);
+#pragma unroll
+    for (int t = 0; t < SC_TH; ++t) {
+      const int oh = tp.oh0 + t, ow = tp.ow0 + spix;
+      rd[t] = (oh < g.OH && ow < g.OW)
+                  ? *reinterpret_cast<const uint4*>(dy + (((int64_t)tp.b * g.OH + oh) * g.OW + ow) * SC_OC + spart * 8)
+                  : make_uint4(0, 0, 0, 0);
+    }
+    fetch_patch(x, g, tp, tid, rp);
+  };
+  int tile = blockIdx.x;
+  if (tile < g.ntiles) fetch(tile);
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();                                      // previous tile's fragment reads are done
+#pragma unroll
+    for (int t = 0; t < SC_TH; ++t) {
+      const uint32_t wv[4] = {rd[t].x, rd[t].y, rd[t].z, rd[t].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        dyT[(spart * 8 + e) * SC_DS + t * 32 + spix] = (bf16_t)((wv[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+    }
+#pragma unroll
+    for (int u = 0; u < SC_NPF; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < SC_NPD) {
+        const int pr = idx / SC_PD, dc = idx % SC_PD, ic = pr / SC_PR, rr = pr % SC_PR;
+        const int row = (ic * SC_RIC + rr) * SC_RS * 2;  // in bf16 elements
+        const bf16_t e0 = (bf16_t)(rp[u] & 0xffffu), e1 = (bf16_t)(rp[u] >> 16);
+        pl16[plane_base(0, 0) * 2 + row + dc] = e0;
+        pl16[plane_base(0, 1) * 2 + row + dc + 1] = e0;
+        pl16[plane_base(1, 0) * 2 + row + dc] = e1;
+        pl16[plane_base(1, 1) * 2 + row + dc + 1] = e1;
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < g.ntiles) fetch(tile + gridDim.x);   // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                      // 16 pixels per step: tile row ks >> 1, columns 16 (ks & 1) ..
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(dyT + (32 * wm + n) * SC_DS + ks * 16 + 8 * half);
+      const int off = (2 * (ks >> 1)) * SC_RS + (ks & 1) * 8 + 4 * half;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const uint32_t* q = planes + bbase[j] + off;
+        union { uint32_t u[4]; bf16x8 v; } fb;
+        fb.u[0] = q[0]; fb.u[1] = q[1]; fb.u[2] = q[2]; fb.u[3] = q[3];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb.v, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // acc[j][r]: oc = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, k = 32 (3 wn + j) + n
+  float* out = part + (int64_t)blockIdx.x * SC_OC * SC_KP;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k = 32 * (3 * wn + j) + n;
+    if (k < SC_KP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[oc * SC_KP + k] = acc[j][r];
+      }
+    }
+  }
+}
+
+// dw[oc][ic][kh][kw] = sum over the per-block partials, fixed order, fp64.
+__global__ __launch_bounds__(256) void stem_wrw_fold(const float* __restrict__ part, int nparts,
+                                                     float* __restrict__ dw) {
+  __shared__ double sm[4][64];
+  const int o = threadIdx.x & 63, gs = threadIdx.x >> 6;
+  const int flat = blockIdx.x * 64 + o;                   // index into [64][176]
+  double a = 0.0;
+  for (int gidx = gs; gidx < nparts; gidx += 4) a += (double)part[(int64_t)gidx * SC_OC * SC_KP + flat];
+  sm[gs][o] = a;
+  __syncthreads();
+  if (gs == 0) {
+    const double t = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
+    const int oc = flat / SC_KP, k = flat % SC_KP, r = k >> 3, s = k & 7;
+    if (r < 21 && s >= 1) dw[oc * 147 + r * 7 + (s - 1)] = (float)t;
+  }
+}
+
+static size_t sc_align(size_t v) { return (v + 255) / 256 * 256; }
+
+static bool stem_geom(int64_t B, int64_t H, int64_t W, StemGeom* g) {
+  if (B <= 0 || H <= 0 || W <= 0 || (W & 1)) return false;
+  const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t th = (OH + SC_TH - 1) / SC_TH, tw = (OW + SC_TW - 1) / SC_TW;
+  if (B * th * tw > 0x7fffffffLL || B * 3 * H * W > 0x7fffffffffffLL) return false;
+  g->B = (int)B; g->H = (int)H; g->W = (int)W; g->OH = (int)OH; g->OW = (int)OW;
+  g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
+  return true;
+}
+
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" {
+
+int tsg_stem_conv_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
+                            int groups, int64_t H, int64_t W) {
+  return dtype == TSG_BF16 && Cin == 3 && Cout == SC_OC && kh == 7 && kw == 7 && stride == 2 && pad == 3 &&
+         dilation == 1 && groups == 1 && H > 0 && W > 0 && (W & 1) == 0;
+}
+
+size_t tsg_stem_conv_ws_bytes(void) {
+  return sc_align((size_t)SC_OC * SC_KP * sizeof(bf16_t)) + (size_t)SC_NPART * SC_OC * SC_KP * sizeof(float);
+}
+
+int tsg_stem_conv_fwd(const void* x, const float* w, void* y, int64_t B, int64_t H, int64_t W, void* ws,
+                      size_t ws_bytes, void* stream) {
+  if (!x || !w || !y || !ws) return TSG_E_NULL;
+  StemGeom g;
+  if (!stem_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  if (ws_bytes < sc_align((size_t)SC_OC * SC_KP * sizeof(bf16_t))) return TSG_E_WS;
+  if (!aligned16(y) || !aligned16(ws) || (((uintptr_t)x) & 3u)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* wp = (bf16_t*)ws;
+  hipLaunchKernelGGL(stem_pack_w, dim3((SC_OC * SC_KP + 255) / 256), dim3(256), 0, st, w, wp);
+  TSG_CHECK_LAUNCH();
+  const int grid = g.ntiles < 768 ? g.ntiles : 768;             // 3 resident blocks per CU (164 VGPRs)
+  hipLaunchKernelGGL(stem_fwd_k, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, (bf16_t*)y, g);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_stem_conv_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
+                      size_t ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !ws) return TSG_E_NULL;
+  StemGeom g;
+  if (!stem_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_stem_conv_ws_bytes()) return TSG_E_WS;
+  if (!aligned16(dy) || !aligned16(ws) || (((uintptr_t)x) & 3u)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)((char*)ws + sc_align((size_t)SC_OC * SC_KP * sizeof(bf16_t)));
+  const int grid = g.ntiles < SC_NPART ? g.ntiles : SC_NPART;
+  hipLaunchKernelGGL(stem_wrw_k, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, part, g);
+  TSG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(stem_wrw_fold, dim3(SC_OC * SC_KP / 64), dim3(256), 0, st, (const float*)part, grid, dw);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

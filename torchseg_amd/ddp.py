@@ -30,6 +30,7 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_FUSE_HEAD=1|0     (default 0: F.interpolate(x >= 4) feeding our criterion is fused into it; parity-tested,
                         but on MI355X streaming the bf16 logits at ~4-5 TB/s is as fast as re-interpolating them)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
+  TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
 """
 import os
 
@@ -240,6 +241,9 @@ class DistributedDataParallel(nn.Module):
             if _env_flag("TSG_SPLIT_BIAS", True):
                 from .convbias import split_conv_bias
                 split_conv_bias(self.module)
+            if _env_flag("TSG_STEM_CONV", True):
+                from .stemconv import install_stem_conv
+                install_stem_conv(self.module)
 
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None

@@ -223,6 +223,44 @@ class HipKernels:
                                               IH, IW, OH, OW, K_, S_, P_, L.stream_ptr(dy)), "tsg_maxpool_nhwc_bwd")
         return dx
 
+    # ---- stem convolution ----------------------------------------------------
+    def stem_conv_supported(self, x, weight, stride, padding, dilation, groups):
+        if x.dim() != 4 or weight.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous():
+            return False
+        return bool(self.lib.tsg_stem_conv_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
+                                                     weight.shape[3], stride, padding, dilation, groups,
+                                                     x.shape[2], x.shape[3]))
+
+    def _stem_ws(self, dev):
+        ws = getattr(self, "_stem_ws_buf", None)
+        if ws is None or ws.device != dev:
+            ws = torch.empty(self.lib.tsg_stem_conv_ws_bytes(), dtype=torch.uint8, device=dev)
+            self._stem_ws_buf = ws
+        return ws
+
+    def stem_conv_fwd(self, x, weight):
+        """x [B,3,H,W] bf16 contiguous, weight fp32 [64,3,7,7] -> y [B,64,OH,OW] bf16 channels_last"""
+        _require_contiguous(x, weight)
+        B, _, H, W = x.shape
+        y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, H, W, ws.data_ptr(),
+                                           ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_fwd")
+        return y
+
+    def stem_conv_wrw(self, x, dy):
+        """x as in stem_conv_fwd, dy [B,64,OH,OW] bf16 channels_last -> dw fp32 [64,3,7,7]"""
+        _require_contiguous(x)
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("stem_conv_wrw expects a channels_last gradient")
+        B, _, H, W = x.shape
+        dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(),
+                                           ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_wrw")
+        return dw
+
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
@@ -454,6 +492,8 @@ _ALGO_BYTES = {
     "maxpool_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r[0]) + _nbytes(r[1]),
     "maxpool_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "gap_fwd": lambda a, r: _nbytes(a[0]),
+    "stem_conv_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
 
