@@ -51,19 +51,12 @@ struct StemGeom {
   int B, H, W, OH, OW, tiles_h, tiles_w, ntiles;
 };
 
-__device__ __forceinline__ uint32_t load_pair(const bf16_t* __restrict__ x, const StemGeom& g, int b, int ic, int ih,
-                                              int iw) {
-  // iw is even and W is even: the pair is either fully inside the image or fully in the padding
-  if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0u;
-  return *reinterpret_cast<const uint32_t*>(x + (((int64_t)b * 3 + ic) * g.H + ih) * g.W + iw);
-}
-
-// ---------------------------------------------------------------- forward
-constexpr int SC_NPD = 3 * SC_PR * SC_PD;               // 1404 input dwords per tile
+// ---------------------------------------------------------------- input patch of a tile
+constexpr int SC_NPD = 3 * SC_PR * SC_PD;               // 1404 input dwords (bf16 pairs) per tile
 constexpr int SC_NPF = (SC_NPD + 255) / 256;            // 6 per thread
 
 struct TilePos { int b, oh0, ow0; };
-__device__ __forceinline__ TilePos tile_pos(const StemGeom& g, int tile) {
+__device__ __forceinline__ TilePos tile_pos(const StemGeom& g, int tile) {   // uniform: scalar ALU
   TilePos t;
   t.ow0 = (tile % g.tiles_w) * SC_TW;
   t.oh0 = ((tile / g.tiles_w) % g.tiles_h) * SC_TH;
@@ -71,19 +64,55 @@ __device__ __forceinline__ TilePos tile_pos(const StemGeom& g, int tile) {
   return t;
 }
 
-__device__ __forceinline__ void fetch_patch(const bf16_t* __restrict__ x, const StemGeom& g, const TilePos& tp, int tid,
-                                            uint32_t (&rp)[SC_NPF]) {
+// The tile-independent half of the patch addressing, computed once per thread: pair `u` of this thread sits at
+// input row 2*oh0 - 3 + rr[u], column 2*ow0 - 4 + cc[u] of channel ic, i.e. at element `off[u]` from
+// &x[b, 0, 2*oh0, 2*ow0].  rr < 0 marks the slots past the 1404th pair.
+struct PatchLane {
+  int off[SC_NPF];
+  int rc[SC_NPF];                                        // rr | cc << 8, or -1
+};
+
+__device__ __forceinline__ void patch_lane_init(const StemGeom& g, int tid, PatchLane& pl) {
 #pragma unroll
   for (int u = 0; u < SC_NPF; ++u) {
     const int idx = tid + 256 * u;
-    rp[u] = 0u;
-    if (idx < SC_NPD) {
-      const int pr = idx / SC_PD, dc = idx % SC_PD, ic = pr / SC_PR, rr = pr % SC_PR;
-      rp[u] = load_pair(x, g, tp.b, ic, 2 * tp.oh0 - 3 + rr, 2 * tp.ow0 - 4 + 2 * dc);
+    const int pr = idx / SC_PD, dc = idx % SC_PD, ic = pr / SC_PR, rr = pr % SC_PR;
+    pl.rc[u] = idx < SC_NPD ? (rr | ((2 * dc) << 8)) : -1;
+    pl.off[u] = (ic * g.H + rr - 3) * g.W + 2 * dc - 4;
+  }
+}
+
+// iw is even and W is even: a pair is either fully inside the image or fully in the padding.
+__device__ __forceinline__ void fetch_patch(const bf16_t* __restrict__ x, const StemGeom& g, const TilePos& tp,
+                                            const PatchLane& pl, uint32_t (&rp)[SC_NPF]) {
+  const bf16_t* org = x + ((int64_t)tp.b * 3 * g.H + 2 * tp.oh0) * g.W + 2 * tp.ow0;
+  const int ih0 = 2 * tp.oh0 - 3, iw0 = 2 * tp.ow0 - 4;
+  const bool interior = ih0 >= 0 && ih0 + SC_PR <= g.H && iw0 >= 0 && iw0 + 2 * SC_PD <= g.W;   // uniform
+  if (interior) {
+#pragma unroll
+    for (int u = 0; u < SC_NPF; ++u) {
+      rp[u] = 0u;
+      if (u < SC_NPF - 1 || pl.rc[u] >= 0) rp[u] = *reinterpret_cast<const uint32_t*>(org + pl.off[u]);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < SC_NPF; ++u) {
+      const int ih = ih0 + (pl.rc[u] & 0xff), iw = iw0 + (pl.rc[u] >> 8);
+      rp[u] = 0u;
+      if (pl.rc[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+        rp[u] = *reinterpret_cast<const uint32_t*>(org + pl.off[u]);
     }
   }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even
+  const f32x2_t f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+
+// ---------------------------------------------------------------- forward
 // 4 waves: wave = (row pair wr) * 2 + (oc half wm).  A wave keeps the weights of its 32 output channels in
 // registers (11 K-fragments) and runs two pixel rows against them.
 __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
@@ -98,18 +127,32 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, 
   for (int t = 0; t < SC_KSTEPS; ++t)
     fw[t] = *reinterpret_cast<const bf16x8*>(wp + (wm * 32 + p) * SC_KP + t * 16 + half * 8);
 
+  int rowoff[SC_KSTEPS];                               // patch row (in dwords) of this lane's K-fragment, tile row 0
+#pragma unroll
+  for (int t = 0; t < SC_KSTEPS; ++t) {
+    int r = 2 * t + half;
+    if (r >= 21) r = 0;                                // zero weights: any finite data will do
+    rowoff[t] = ((r / 7) * SC_PR + r % 7) * SC_PD + p;
+  }
+  const int spl = tid >> 3, spart = tid & 7;           // store: tile column spl, 16-B part spart
+
+  PatchLane pl;
+  patch_lane_init(g, tid, pl);
   uint32_t rp[SC_NPF];
   int tile = blockIdx.x;
-  if (tile < g.ntiles) fetch_patch(x, g, tile_pos(g, tile), tid, rp);
+  TilePos tp = tile_pos(g, tile < g.ntiles ? tile : 0);
+  if (tile < g.ntiles) fetch_patch(x, g, tp, pl, rp);
   for (; tile < g.ntiles; tile += gridDim.x) {
-    const TilePos tp = tile_pos(g, tile);
     __syncthreads();                                   // the previous tile's reads of patch/outs are done
 #pragma unroll
     for (int u = 0; u < SC_NPF; ++u)
       if (tid + 256 * u < SC_NPD) patch[tid + 256 * u] = rp[u];
     __syncthreads();
-    if (tile + (int)gridDim.x < g.ntiles)              // in flight during the MFMAs below
-      fetch_patch(x, g, tile_pos(g, tile + gridDim.x), tid, rp);
+    TilePos tn = tp;
+    if (tile + (int)gridDim.x < g.ntiles) {            // in flight during the MFMAs below
+      tn = tile_pos(g, tile + gridDim.x);
+      fetch_patch(x, g, tn, pl, rp);
+    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -118,12 +161,9 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, 
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < SC_KSTEPS; ++t) {
-      int r = 2 * t + half;
-      if (r >= 21) r = 0;                              // zero weights: any finite data will do
-      const int ic = r / 7, kh = r % 7;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const uint32_t* q = patch + (ic * SC_PR + 2 * (2 * wr + i) + kh) * SC_PD + p;
+        const uint32_t* q = patch + rowoff[t] + 2 * (2 * wr + i) * SC_PD;
         union { uint32_t u[4]; bf16x8 v; } fb;
         fb.u[0] = q[0]; fb.u[1] = q[1]; fb.u[2] = q[2]; fb.u[3] = q[3];
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[t], fb.v, acc[i], 0, 0, 0);
@@ -137,19 +177,20 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, 
       for (int gq = 0; gq < 4; ++gq) {
         const int oc0 = 32 * wm + 8 * gq + 4 * half;
         uint2 v;
-        v.x = (uint32_t)f32_to_bf16(acc[i][4 * gq + 0]) | ((uint32_t)f32_to_bf16(acc[i][4 * gq + 1]) << 16);
-        v.y = (uint32_t)f32_to_bf16(acc[i][4 * gq + 2]) | ((uint32_t)f32_to_bf16(acc[i][4 * gq + 3]) << 16);
+        v.x = pack_bf16(acc[i][4 * gq + 0], acc[i][4 * gq + 1]);
+        v.y = pack_bf16(acc[i][4 * gq + 2], acc[i][4 * gq + 3]);
         *reinterpret_cast<uint2*>(outs + ((2 * wr + i) * SC_TW + p) * 72 + oc0) = v;
       }
     __syncthreads();
+    // thread -> (tile row qd, pixel spl, 16-B part spart): a wave stores 1 KB of consecutive NHWC bytes
+    bf16_t* yt = y + (((int64_t)tp.b * g.OH + tp.oh0) * g.OW + tp.ow0) * SC_OC;
+    const bool colok = tp.ow0 + spl < g.OW;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int c = tid + 256 * qd, pl = c >> 3, part = c & 7, row = pl >> 5, pix = pl & 31;
-      const int oh = tp.oh0 + row, ow = tp.ow0 + pix;
-      if (oh < g.OH && ow < g.OW)
-        *reinterpret_cast<uint4*>(y + (((int64_t)tp.b * g.OH + oh) * g.OW + ow) * SC_OC + part * 8) =
-            *reinterpret_cast<const uint4*>(outs + pl * 72 + part * 8);
-    }
+    for (int qd = 0; qd < SC_TH; ++qd)
+      if (tp.oh0 + qd < g.OH && colok)
+        *reinterpret_cast<uint4*>(yt + ((int64_t)qd * g.OW + spl) * SC_OC + spart * 8) =
+            *reinterpret_cast<const uint4*>(outs + (qd * SC_TW + spl) * 72 + spart * 8);
+    tp = tn;
   }
 }
 
@@ -188,18 +229,25 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int spix = tid & 31, spart = tid >> 5;          // dy staging: pixel within a tile row, group of 8 oc
+  PatchLane pl;
+  patch_lane_init(g, tid, pl);
+  int pdst[SC_NPF];                                     // where pair u goes in plane (0,0), in bf16 elements
+#pragma unroll
+  for (int u = 0; u < SC_NPF; ++u) {
+    const int idx = tid + 256 * u, pr = idx / SC_PD, dc = idx % SC_PD, ic = pr / SC_PR, rr = pr % SC_PR;
+    pdst[u] = (ic * SC_RIC + rr) * SC_RS * 2 + dc;
+  }
   uint4 rd[SC_TH];
   uint32_t rp[SC_NPF];
   auto fetch = [&](int tile) {
     const TilePos tp = tile_pos(g, tile);
+    const bf16_t* dt = dy + (((int64_t)tp.b * g.OH + tp.oh0) * g.OW + tp.ow0) * SC_OC + spix * SC_OC + spart * 8;
+    const bool colok = tp.ow0 + spix < g.OW;
 #pragma unroll
-    for (int t = 0; t < SC_TH; ++t) {
-      const int oh = tp.oh0 + t, ow = tp.ow0 + spix;
-      rd[t] = (oh < g.OH && ow < g.OW)
-                  ? *reinterpret_cast<const uint4*>(dy + (((int64_t)tp.b * g.OH + oh) * g.OW + ow) * SC_OC + spart * 8)
-                  : make_uint4(0, 0, 0, 0);
-    }
-    fetch_patch(x, g, tp, tid, rp);
+    for (int t = 0; t < SC_TH; ++t)
+      rd[t] = (tp.oh0 + t < g.OH && colok) ? *reinterpret_cast<const uint4*>(dt + (int64_t)t * g.OW * SC_OC)
+                                           : make_uint4(0, 0, 0, 0);
+    fetch_patch(x, g, tp, pl, rp);
   };
   int tile = blockIdx.x;
   if (tile < g.ntiles) fetch(tile);
@@ -214,15 +262,13 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
     }
 #pragma unroll
     for (int u = 0; u < SC_NPF; ++u) {
-      const int idx = tid + 256 * u;
-      if (idx < SC_NPD) {
-        const int pr = idx / SC_PD, dc = idx % SC_PD, ic = pr / SC_PR, rr = pr % SC_PR;
-        const int row = (ic * SC_RIC + rr) * SC_RS * 2;  // in bf16 elements
+      if (u < SC_NPF - 1 || pl.rc[u] >= 0) {
         const bf16_t e0 = (bf16_t)(rp[u] & 0xffffu), e1 = (bf16_t)(rp[u] >> 16);
-        pl16[plane_base(0, 0) * 2 + row + dc] = e0;
-        pl16[plane_base(0, 1) * 2 + row + dc + 1] = e0;
-        pl16[plane_base(1, 0) * 2 + row + dc] = e1;
-        pl16[plane_base(1, 1) * 2 + row + dc + 1] = e1;
+        bf16_t* d = pl16 + pdst[u];
+        d[plane_base(0, 0) * 2] = e0;
+        d[plane_base(0, 1) * 2 + 1] = e0;
+        d[plane_base(1, 0) * 2] = e1;
+        d[plane_base(1, 1) * 2 + 1] = e1;
       }
     }
     __syncthreads();
