@@ -52,7 +52,7 @@ def fwd(x, w):
     return y
 
 def plane_base(q, sg):
-    return (q * 2 + sg) * PLANE + sg + 32 * q
+    return (q * 2 + sg) * PLANE + sg + 4 * q
 
 def wrw(x, dy):                                    # dy: [B, OH, OW, 64]
     B, _, H, W = x.shape
@@ -64,12 +64,14 @@ def wrw(x, dy):                                    # dy: [B, OH, OW, 64]
                 oh0, ow0 = th * TH, tw * TW
                 dyT = np.zeros(64 * DS)
                 for tid in range(256):
-                    spix, spart = tid & 31, tid >> 5
-                    for t in range(4):
-                        oh, ow = oh0 + t, ow0 + spix
-                        v = dy[b, oh, ow, spart * 8: spart * 8 + 8] if (oh < OH and ow < OW) else np.zeros(8)
-                        for e in range(8):
-                            dyT[(spart * 8 + e) * DS + t * 32 + spix] = v[e]
+                    spp, strow, spart = tid & 15, (tid >> 4) & 1, tid >> 5
+                    for rs in range(2):
+                        t = strow + 2 * rs
+                        for px in range(2):
+                            oh, ow = oh0 + t, ow0 + 2 * spp + px
+                            v = dy[b, oh, ow, spart * 8: spart * 8 + 8] if (oh < OH and ow < OW) else np.zeros(8)
+                            for e in range(8):
+                                dyT[(spart * 8 + e) * DS + 2 * (16 * t + spp) + px] = v[e]
                 pl = np.full(4 * PLANE * 2, np.nan)
                 patch = load_patch(x, b, oh0, ow0)
                 for idx in range(3 * PR * PD):
@@ -86,7 +88,7 @@ def wrw(x, dy):                                    # dy: [B, OH, OW, 64]
                             for n in range(32):
                                 k = 32 * (3 * wn + j) + n
                                 r, s = k >> 3, k & 7
-                                if r >= 21: r, s = 0, 0
+                                if r >= 21: r = 20
                                 ic, kh = divmod(r, 7); q, sh = s & 1, s >> 1; sg = sh & 1
                                 bbase = plane_base(q, sg) + (ic * RIC + kh) * RS + ((sh + sg) >> 1)
                                 for ks in range(8):
@@ -107,21 +109,22 @@ def wrw(x, dy):                                    # dy: [B, OH, OW, 64]
     return dw.reshape(64, 3, 7, 7)
 
 def banks():
-    """LDS bank check of the wgrad B-fragment reads: 64 lanes of one ds_read_b32 -> 64 distinct banks?"""
+    """LDS bank check of the wgrad B-fragment reads (MI355X_MICROARCH.md: a ds_read_b32 is serviced in two groups
+    of 32 lanes, bank = dword address mod 32): distinct addresses per bank within a group."""
     worst = 0
     for wn in range(2):
         for j in range(3):
             for ks in range(8):
                 for i in range(4):
+                  for half in range(2):
                     seen = {}
-                    for lane in range(64):
-                        n, half = lane & 31, lane >> 5
+                    for n in range(32):
                         k = 32 * (3 * wn + j) + n
                         r, s = k >> 3, k & 7
-                        if r >= 21: r, s = 0, 0
+                        if r >= 21: r = 20
                         ic, kh = divmod(r, 7); q, sh = s & 1, s >> 1; sg = sh & 1
                         a = plane_base(q, sg) + (ic * RIC + kh) * RS + ((sh + sg) >> 1) + (2 * (ks >> 1)) * RS + (ks & 1) * 8 + 4 * half + i
-                        seen.setdefault(a % 64, set()).add(a)
+                        seen.setdefault(a % 32, set()).add(a)
                     worst = max(worst, max(len(v) for v in seen.values()))
     return worst
 

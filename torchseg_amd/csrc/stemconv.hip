@@ -200,8 +200,10 @@ constexpr int SC_RS = 24;                  // plane row stride in dwords (bank p
 constexpr int SC_RIC = 15;                 // plane rows per input channel (13 used); 15 = 7 mod 8 keeps r -> bank regular
 constexpr int SC_PLANE = 1088;             // dwords per plane copy (45 rows x 24 = 1080, rounded to 17 x 64)
 
-__device__ __forceinline__ int plane_base(int q, int sg) {   // parity q, alignment copy sg; bank offsets 0, 1, 32, 33
-  return (q * 2 + sg) * SC_PLANE + sg + 32 * q;
+// parity q, alignment copy sg.  The bank offsets 0, 1, 4, 5 (with RS = 24 and RIC = 15) make the 32 lanes of a
+// B-fragment ds_read_b32 hit 32 different banks (tools/emulate_stemconv.py checks it).
+__device__ __forceinline__ int plane_base(int q, int sg) {
+  return (q * 2 + sg) * SC_PLANE + sg + 4 * q;
 }
 
 __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -216,11 +218,12 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
   for (int j = 0; j < 3; ++j) {
     const int k = 32 * (3 * wn + j) + n;
     int r = k >> 3, s = k & 7;
-    if (r >= 21) { r = 0; s = 0; }         // columns 168..191 of the GEMM are padding, never written out
+    if (r >= 21) r = 20;                   // columns 168..191 of the GEMM are padding, never written out; alias a real lane
     const int ic = r / 7, kh = r % 7, q = s & 1, sh = s >> 1, sg = sh & 1;
     bbase[j] = plane_base(q, sg) + (ic * SC_RIC + kh) * SC_RS + ((sh + sg) >> 1);
   }
   bf16_t* pl16 = reinterpret_cast<bf16_t*>(planes);
+  uint32_t* dyT32 = reinterpret_cast<uint32_t*>(dyT);
 
   f32x16 acc[3];
 #pragma unroll
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int spix = tid & 31, spart = tid >> 5;          // dy staging: pixel within a tile row, group of 8 oc
+  // dy staging: pixel pair spp of tile rows strow and strow + 2, group of 8 oc spart (two pixels -> one 32-bit LDS write)
+  const int spp = tid & 15, strow = (tid >> 4) & 1, spart = tid >> 5;
   PatchLane pl;
   patch_lane_init(g, tid, pl);
   int pdst[SC_NPF];                                     // where pair u goes in plane (0,0), in bf16 elements
@@ -241,12 +245,14 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
   uint32_t rp[SC_NPF];
   auto fetch = [&](int tile) {
     const TilePos tp = tile_pos(g, tile);
-    const bf16_t* dt = dy + (((int64_t)tp.b * g.OH + tp.oh0) * g.OW + tp.ow0) * SC_OC + spix * SC_OC + spart * 8;
-    const bool colok = tp.ow0 + spix < g.OW;
+    const bf16_t* dt = dy + (((int64_t)tp.b * g.OH + tp.oh0 + strow) * g.OW + tp.ow0 + 2 * spp) * SC_OC + spart * 8;
 #pragma unroll
-    for (int t = 0; t < SC_TH; ++t)
-      rd[t] = (tp.oh0 + t < g.OH && colok) ? *reinterpret_cast<const uint4*>(dt + (int64_t)t * g.OW * SC_OC)
-                                           : make_uint4(0, 0, 0, 0);
+    for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+        rd[rs * 2 + px] = (tp.oh0 + strow + 2 * rs < g.OH && tp.ow0 + 2 * spp + px < g.OW)
+                              ? *reinterpret_cast<const uint4*>(dt + ((int64_t)rs * 2 * g.OW + px) * SC_OC)
+                              : make_uint4(0, 0, 0, 0);
     fetch_patch(x, g, tp, pl, rp);
   };
   int tile = blockIdx.x;
@@ -254,11 +260,14 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
   for (; tile < g.ntiles; tile += gridDim.x) {
     __syncthreads();                                      // previous tile's fragment reads are done
 #pragma unroll
-    for (int t = 0; t < SC_TH; ++t) {
-      const uint32_t wv[4] = {rd[t].x, rd[t].y, rd[t].z, rd[t].w};
+    for (int rs = 0; rs < 2; ++rs) {
+      const uint32_t wa[4] = {rd[2 * rs].x, rd[2 * rs].y, rd[2 * rs].z, rd[2 * rs].w};                  // pixel 2 spp
+      const uint32_t wb[4] = {rd[2 * rs + 1].x, rd[2 * rs + 1].y, rd[2 * rs + 1].z, rd[2 * rs + 1].w};  // pixel 2 spp + 1
+      uint32_t* drow = dyT32 + (spart * 8) * (SC_DS / 2) + 16 * (strow + 2 * rs) + spp;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        dyT[(spart * 8 + e) * SC_DS + t * 32 + spix] = (bf16_t)((wv[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        drow[e * (SC_DS / 2)] = (e & 1) ? ((wa[e >> 1] >> 16) | (wb[e >> 1] & 0xffff0000u))
+                                        : ((wa[e >> 1] & 0xffffu) | (wb[e >> 1] << 16));
     }
 #pragma unroll
     for (int u = 0; u < SC_NPF; ++u) {
