@@ -358,6 +358,20 @@ int tsg_sgd_step_dev(float* param, const float* grad, float* momentum_buf,
                      int64_t n, const float* lr_dev, float lr_mult, float momentum,
                      float weight_decay, float grad_scale, void* stream);
 
+/* Multi-tensor form of tsg_sgd_step_dev: one launch updates up to TSG_SGD_MAX_SEGS parameter
+ * tensors (the ~113 of BiSeNet-R18 in one launch instead of one each; torch's foreach path
+ * issues ~7 launches per parameter group).  params/grads/bufs: host arrays of device addresses;
+ * numel, group: host arrays; lr_dev [ngroups] on the device; momentum / weight_decay: host
+ * arrays per group.  blockmap_dev: device copy of the int pairs tsg_sgd_multi_blockmap writes
+ * (static for a model); call it with map_host = NULL to get the block count. */
+#define TSG_SGD_MAX_SEGS   128
+#define TSG_SGD_MAX_GROUPS 16
+int64_t tsg_sgd_multi_blockmap(const int64_t* numel, int nseg, int* map_host, int64_t cap_blocks);
+int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* grads, const uint64_t* bufs,
+                           const int64_t* numel, const int* group, int nseg, const float* lr_dev,
+                           const float* momentum, const float* weight_decay, int ngroups,
+                           const int* blockmap_dev, int64_t nblocks, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,19 @@ def test_argument_validation_without_gpu():
     # NULL pointers are rejected before any launch
     assert lib.tsg_bn_stats(None, 0, 0, 1, 1, 1, None, None, None) < 0
     assert lib.tsg_sgd_step(None, None, None, 4, 0.1, 0.9, 0.0, 1.0, 1, None) < 0
+    # host-side helpers of the multi-tensor SGD and the stem convolution
+    import numpy as np
+    n = np.array([1, 4096, 4097, 10000], dtype=np.int64)
+    nb = lib.tsg_sgd_multi_blockmap(n.ctypes.data, 4, None, 0)
+    m = np.empty((nb, 2), np.int32)
+    assert nb == 7 and lib.tsg_sgd_multi_blockmap(n.ctypes.data, 4, m.ctypes.data, nb) == 7
+    assert m.tolist() == [[0, 0], [1, 0], [2, 0], [2, 1], [3, 0], [3, 1], [3, 2]]
+    assert lib.tsg_sgd_multi_blockmap(n.ctypes.data, 129, None, 0) < 0
+    assert lib.tsg_stem_conv_supported(_lib.BF16, 3, 64, 7, 7, 2, 3, 1, 1, 1024, 1024) == 1
+    assert lib.tsg_stem_conv_supported(_lib.F32, 3, 64, 7, 7, 2, 3, 1, 1, 1024, 1024) == 0
+    assert lib.tsg_stem_conv_supported(_lib.BF16, 3, 64, 3, 3, 2, 1, 1, 1, 1024, 1024) == 0
+    assert lib.tsg_stem_conv_ws_bytes() > 64 * 176 * 2
+    assert lib.tsg_stem_conv_fwd(None, None, None, 1, 8, 8, None, 0, None) < 0
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -65,3 +65,34 @@ def test_fused_sgd_under_hip_graph_follows_lr(cuda):
         oe.step(); graph.replay()
     torch.cuda.synchronize()
     torch.testing.assert_close(pg.detach(), pe.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_fused_sgd_many_tensors_one_launch(cuda):
+    """150 tensors (two launches of the multi-tensor kernel), ragged sizes incl. 1, 4095..4097 and a tensor larger
+    than several chunks, three groups, and a gradient that is an unaligned view into a flat bucket."""
+    from torchseg_amd.optim import FusedSGD
+    g = torch.Generator().manual_seed(2)
+    sizes = [1, 2, 3, 5, 4095, 4096, 4097, 8191, 70001] + [int(v) for v in torch.randint(1, 3000, (141,), generator=g)]
+    ref = [nn.Parameter(torch.randn(n, generator=g).to(cuda)) for n in sizes]
+    our = [nn.Parameter(p.detach().clone()) for p in ref]
+    def groups(ps):
+        return [dict(params=ps[0::3], lr=0.1), dict(params=ps[1::3], lr=0.02, weight_decay=0.0),
+                dict(params=ps[2::3], lr=0.3, momentum=0.5)]
+    oa = torch.optim.SGD(groups(ref), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    ob = FusedSGD(groups(our), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    flat = torch.zeros(sum(sizes) + 1, device=cuda)
+    for step in range(3):
+        off = 1                                            # +1: every view starts 4 bytes off a 16-byte boundary
+        for p, q in zip(ref, our):
+            gr = torch.randn(p.numel(), generator=g).to(cuda)
+            p.grad = gr.clone()
+            if step == 1:
+                view = flat[off:off + q.numel()]
+                view.copy_(gr)
+                q.grad = view
+                off += q.numel()
+            else:
+                q.grad = gr.clone()
+        oa.step(); ob.step()
+    for i, (p, q) in enumerate(zip(ref, our)):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6, msg="tensor %d (n=%d)" % (i, sizes[i]))

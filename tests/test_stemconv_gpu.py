@@ -76,3 +76,35 @@ def test_stem_conv_module_swap_matches_stock_autocast(cuda):
     # fp32 compute stays on the stock convolution
     y2 = mod(x)
     assert y2.dtype == torch.float32
+
+
+def test_bisenet_bf16_step_same_loss_with_and_without_stem_kernels(cuda, monkeypatch):
+    """BiSeNet-R18 under the DDP wrapper (bf16 autocast, channels_last): loss with the stems on tsg_stem_conv_*
+    vs on MIOpen, same weights and batch, within 1e-2 (bf16 activations).  Both round the operands to bf16 and
+    accumulate in fp32, so the stems differ by accumulation order only; the weight gradients of a randomly
+    initialised net at B = 2 are too ill-conditioned in bf16 to compare run against run (0.46 relative L2
+    measured between the two), the kernels' own gradients are checked against the oracle above."""
+    import torch.nn as nn
+    from torchseg_amd.ddp import DistributedDataParallel
+    from torchseg_amd.losses import ProbOhemCrossEntropy2d
+    from torchseg_amd.stemconv import StemConv2d
+    from torchseg_amd.syncbn import SyncBatchNorm
+    from torchseg_amd.workloads.bisenet import BiSeNet
+    B, S = 2, 256
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 3, S, S, generator=g).to(cuda)
+    y = torch.randint(0, 19, (B, S, S), generator=g).to(cuda)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TSG_STEM_CONV", flag)
+        torch.manual_seed(12345)
+        net = BiSeNet(19, True, ProbOhemCrossEntropy2d(255, thresh=0.7, min_kept=B * S * S // 16), None, SyncBatchNorm)
+        net = DistributedDataParallel(net.to(cuda), compute_dtype=torch.bfloat16)
+        nstem = sum(isinstance(m, StemConv2d) for m in net.modules())
+        assert nstem == (2 if flag == "1" else 0)
+        loss = net(x, y)
+        loss.backward()
+        out[flag] = loss.item()
+        assert net.module.spatial_path.conv_7x7.conv.weight.grad is not None
+        assert net.module.context_path.conv1.weight.grad is not None
+    assert abs(out["1"] - out["0"]) <= 1e-2 * abs(out["0"]), out

@@ -95,3 +95,106 @@ extern "C" int tsg_sgd_step(float* param, const float* grad, float* momentum_buf
   TSG_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ---------------------------------------------------------------- multi-tensor step
+// One launch for up to TSG_SGD_MAX_SEGS parameter tensors: the pointer table travels by value in the kernel
+// argument block (copied at launch, so the host can rebuild it every step without a staging buffer), the
+// block -> (tensor, chunk) map is static per model and lives in device memory.
+namespace tsg {
+constexpr int kSgdChunk = 4096;            // elements per block: 256 threads x 4 float4
+struct SgdSegs {
+  float* p[TSG_SGD_MAX_SEGS];
+  const float* g[TSG_SGD_MAX_SEGS];
+  float* b[TSG_SGD_MAX_SEGS];
+  int n[TSG_SGD_MAX_SEGS];
+  unsigned char grp[TSG_SGD_MAX_SEGS];
+  float mom[TSG_SGD_MAX_GROUPS];
+  float wd[TSG_SGD_MAX_GROUPS];
+};
+static_assert(sizeof(SgdSegs) <= 3900, "kernel argument block is limited to 4 KiB");
+
+__global__ __launch_bounds__(256) void sgd_multi_k(const SgdSegs s, const int2* __restrict__ map,
+                                                   const float* __restrict__ lr_dev, float gs) {
+  const int2 m = map[blockIdx.x];
+  const int seg = m.x;
+  float* __restrict__ p = s.p[seg];
+  const float* __restrict__ g = s.g[seg];
+  float* __restrict__ buf = s.b[seg];
+  const int n = s.n[seg], grp = s.grp[seg];
+  const float lr = lr_dev[grp], mom = s.mom[grp], wd = s.wd[grp];
+  const int base = m.y * kSgdChunk;
+  const int end = base + kSgdChunk < n ? base + kSgdChunk : n;
+  const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)buf)) & 15u) == 0;
+  if (vec) {
+    const int end4 = base + ((end - base) & ~3);
+    for (int i = base + 4 * threadIdx.x; i < end4; i += 1024) {
+      float4 pv = *reinterpret_cast<float4*>(p + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 bv = *reinterpret_cast<float4*>(buf + i);
+      float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = gg[j] * gs + wd * pp[j];
+        bb[j] = mom * bb[j] + d;
+        pp[j] -= lr * bb[j];
+      }
+      *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      *reinterpret_cast<float4*>(buf + i) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+    }
+    for (int i = end4 + threadIdx.x; i < end; i += 256) {
+      const float d = g[i] * gs + wd * p[i];
+      const float b = mom * buf[i] + d;
+      buf[i] = b;
+      p[i] -= lr * b;
+    }
+  } else {
+    for (int i = base + threadIdx.x; i < end; i += 256) {
+      const float d = g[i] * gs + wd * p[i];
+      const float b = mom * buf[i] + d;
+      buf[i] = b;
+      p[i] -= lr * b;
+    }
+  }
+}
+}  // namespace tsg
+
+extern "C" int64_t tsg_sgd_multi_blockmap(const int64_t* numel, int nseg, int* map_host, int64_t cap_blocks) {
+  if (!numel || nseg <= 0 || nseg > TSG_SGD_MAX_SEGS) return TSG_E_SHAPE;
+  int64_t nb = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (numel[i] <= 0 || numel[i] > 0x7fffffffLL) return TSG_E_SHAPE;
+    const int64_t c = (numel[i] + tsg::kSgdChunk - 1) / tsg::kSgdChunk;
+    if (map_host) {
+      if (nb + c > cap_blocks) return TSG_E_WS;
+      for (int64_t j = 0; j < c; ++j) { map_host[2 * (nb + j)] = i; map_host[2 * (nb + j) + 1] = (int)j; }
+    }
+    nb += c;
+  }
+  return nb;
+}
+
+extern "C" int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* grads, const uint64_t* bufs,
+                                      const int64_t* numel, const int* group, int nseg, const float* lr_dev,
+                                      const float* momentum, const float* weight_decay, int ngroups,
+                                      const int* blockmap_dev, int64_t nblocks, float grad_scale, void* stream) {
+  if (!params || !grads || !bufs || !numel || !group || !lr_dev || !momentum || !weight_decay || !blockmap_dev)
+    return TSG_E_NULL;
+  if (nseg <= 0 || nseg > TSG_SGD_MAX_SEGS || ngroups <= 0 || ngroups > TSG_SGD_MAX_GROUPS) return TSG_E_SHAPE;
+  if (nblocks != tsg_sgd_multi_blockmap(numel, nseg, nullptr, 0)) return TSG_E_SHAPE;
+  tsg::SgdSegs s = {};
+  for (int i = 0; i < nseg; ++i) {
+    if (!params[i] || !grads[i] || !bufs[i]) return TSG_E_NULL;
+    if (group[i] < 0 || group[i] >= ngroups) return TSG_E_SHAPE;
+    s.p[i] = (float*)(uintptr_t)params[i];
+    s.g[i] = (const float*)(uintptr_t)grads[i];
+    s.b[i] = (float*)(uintptr_t)bufs[i];
+    s.n[i] = (int)numel[i];
+    s.grp[i] = (unsigned char)group[i];
+  }
+  for (int i = 0; i < ngroups; ++i) { s.mom[i] = momentum[i]; s.wd[i] = weight_decay[i]; }
+  hipLaunchKernelGGL(tsg::sgd_multi_k, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, s,
+                     reinterpret_cast<const int2*>(blockmap_dev), lr_dev, grad_scale);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}

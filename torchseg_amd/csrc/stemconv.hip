@@ -310,20 +310,27 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
   }
 }
 
-// dw[oc][ic][kh][kw] = sum over the per-block partials, fixed order, fp64.
+// dw[oc][ic][kh][kw] = sum over the per-block partials, fixed order, fp64.  A block folds 64 consecutive
+// entries of the [64][176] partial: 16 float4 columns x 16 interleaved slices of the partial index.
 __global__ __launch_bounds__(256) void stem_wrw_fold(const float* __restrict__ part, int nparts,
                                                      float* __restrict__ dw) {
-  __shared__ double sm[4][64];
-  const int o = threadIdx.x & 63, gs = threadIdx.x >> 6;
-  const int flat = blockIdx.x * 64 + o;                   // index into [64][176]
-  double a = 0.0;
-  for (int gidx = gs; gidx < nparts; gidx += 4) a += (double)part[(int64_t)gidx * SC_OC * SC_KP + flat];
-  sm[gs][o] = a;
+  __shared__ double sm[16][64];
+  const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
+  const float* src = part + blockIdx.x * 64 + c4 * 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+  for (int gidx = gs; gidx < nparts; gidx += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)gidx * SC_OC * SC_KP);
+    a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  }
+  sm[gs][c4 * 4 + 0] = a0; sm[gs][c4 * 4 + 1] = a1; sm[gs][c4 * 4 + 2] = a2; sm[gs][c4 * 4 + 3] = a3;
   __syncthreads();
-  if (gs == 0) {
-    const double t = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
-    const int oc = flat / SC_KP, k = flat % SC_KP, r = k >> 3, s = k & 7;
-    if (r < 21 && s >= 1) dw[oc * 147 + r * 7 + (s - 1)] = (float)t;
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x];
+    const int flat = blockIdx.x * 64 + threadIdx.x, oc = flat / SC_KP, k = flat % SC_KP, r = k >> 3, sl = k & 7;
+    if (r < 21 && sl >= 1) dw[oc * 147 + r * 7 + (sl - 1)] = (float)t;
   }
 }
 

@@ -445,6 +445,29 @@ class HipKernels:
                                           lr_dev.data_ptr(), float(lr_mult), float(momentum), float(weight_decay),
                                           float(grad_scale), L.stream_ptr(param)), "tsg_sgd_step_dev")
 
+    SGD_MAX_SEGS = 128
+
+    def sgd_multi_blockmap(self, numel, device):
+        """Static block -> (tensor, chunk) table for sgd_multi_step_dev, as a device int32 tensor."""
+        import numpy as np
+        n = np.ascontiguousarray(numel, dtype=np.int64)
+        nb = self.lib.tsg_sgd_multi_blockmap(n.ctypes.data, len(n), None, 0)
+        if nb < 0:
+            L.check(int(nb), "tsg_sgd_multi_blockmap")
+        host = np.empty((nb, 2), dtype=np.int32)
+        L.check(int(min(0, self.lib.tsg_sgd_multi_blockmap(n.ctypes.data, len(n), host.ctypes.data, nb))),
+                "tsg_sgd_multi_blockmap")
+        return torch.from_numpy(host).to(device)
+
+    def sgd_multi_step_dev(self, ptrs, numel, group, lr_dev, momentum, weight_decay, blockmap, grad_scale=1.0):
+        """ptrs: uint64 numpy [3, nseg] (param, grad, momentum buffer addresses); numel int64 / group int32 numpy
+        [nseg]; momentum / weight_decay float32 numpy [ngroups]; blockmap from sgd_multi_blockmap."""
+        L.check(self.lib.tsg_sgd_multi_step_dev(ptrs[0].ctypes.data, ptrs[1].ctypes.data, ptrs[2].ctypes.data,
+                                                numel.ctypes.data, group.ctypes.data, len(numel), lr_dev.data_ptr(),
+                                                momentum.ctypes.data, weight_decay.ctypes.data, len(momentum),
+                                                blockmap.data_ptr(), blockmap.shape[0], float(grad_scale),
+                                                L.stream_ptr(lr_dev)), "tsg_sgd_multi_step_dev")
+
 
 _provider = None
 

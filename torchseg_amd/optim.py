@@ -2,9 +2,10 @@
 
 Same update as the `torch.optim.SGD(params_list, lr, momentum, weight_decay)` the
 reference builds (model/bisenet/cityscapes.bisenet.R18/train.py:86-89): dampening 0,
-no nesterov,  g += wd*p ; buf = momentum*buf + g ; p -= lr*buf.  One kernel per
-parameter (torch's foreach path issues ~7 per parameter group plus scalar-list
-setup on the host), and the learning rate is read from a device scalar so that the
+no nesterov,  g += wd*p ; buf = momentum*buf + g ; p -= lr*buf.  One launch per
+128 parameter tensors (tsg_sgd_multi_step_dev: the pointer table travels in the
+kernel arguments; torch's foreach path issues ~7 launches per parameter group plus
+scalar-list setup on the host), and the learning rate is read from a device vector so that the
 reference's per-iteration `param_groups[i]['lr'] = ...` (train.py:133-139) keeps
 working when the whole step is replayed from a hipGraph.
 """
@@ -18,6 +19,7 @@ class FusedSGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._lr_dev = None
         self._lr_host = None
+        self._plans = {}
 
     def _sync_lr(self, device):
         """One [n_groups] device vector of learning rates, refreshed only when a group's lr changed."""
@@ -48,8 +50,10 @@ class FusedSGD(torch.optim.Optimizer):
             return None
         if not capturing:
             self._sync_lr(first.device)
+        if len(self.param_groups) > 16:
+            raise K.L.TsgError("FusedSGD supports at most 16 parameter groups")
+        segs = []                                   # (param view, grad view, buffer, group index)
         for gi, group in enumerate(self.param_groups):
-            lr_slot = self._lr_dev[gi:gi + 1]
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -74,5 +78,23 @@ class FusedSGD(torch.optim.Optimizer):
                     bv = buf
                 else:
                     raise K.L.TsgError("FusedSGD: parameter is neither contiguous nor channels_last")
-                kp.sgd_step_dev(pv, gv, bv, lr_slot, 1.0, group["momentum"], group["weight_decay"])
+                segs.append((pv, gv, bv, gi))
+        if not segs:
+            return None
+        import numpy as np
+        mom = np.array([g["momentum"] for g in self.param_groups], dtype=np.float32)
+        wd = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float32)
+        cap = kp.SGD_MAX_SEGS
+        for c0 in range(0, len(segs), cap):
+            chunk = segs[c0:c0 + cap]
+            numel = tuple(t[0].numel() for t in chunk)
+            key = (c0, numel)
+            plan = self._plans.get(key)
+            if plan is None:                        # static per model: sizes, groups, block map
+                plan = (np.array(numel, dtype=np.int64), np.array([t[3] for t in chunk], dtype=np.int32),
+                        kp.sgd_multi_blockmap(numel, first.device))
+                self._plans[key] = plan
+            ptrs = np.array([[t[0].data_ptr() for t in chunk], [t[1].data_ptr() for t in chunk],
+                             [t[2].data_ptr() for t in chunk]], dtype=np.uint64)
+            kp.sgd_multi_step_dev(ptrs, plan[0], plan[1], self._lr_dev, mom, wd, plan[2])
         return None
