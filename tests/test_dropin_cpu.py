@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from _dropin import have_reference, run_in, stage
+from _dropin import ROOT, have_reference, run_in, stage
 
 pytestmark = pytest.mark.skipif(not have_reference(), reason="reference checkout not present")
 
@@ -137,3 +137,91 @@ def test_workload_builders_equal_reference_networks(tmp_path, family, exp, kind)
     d = stage(tmp_path, family, exp)
     out = json.loads(run_in(d, _WORKLOAD_EQ % kind, timeout=900).strip().splitlines()[-1])
     assert abs(out["loss_ref"] - out["loss_ours"]) <= 1e-5 * max(1.0, abs(out["loss_ref"])), out
+
+
+_CKPT_COMMON = r'''
+import sys, types, json, torch, torch.nn as nn
+def make():
+    torch.manual_seed(5)
+    m = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 1))
+    return m
+def groups(m):
+    return [dict(params=[p for p in m.parameters() if p.dim() > 1], lr=0.05),
+            dict(params=[p for p in m.parameters() if p.dim() <= 1], lr=0.5, weight_decay=0.0)]
+def digest(m, opt):
+    sd = opt.state_dict()
+    return dict(params=[float(p.double().sum()) for p in m.parameters()],
+                bufs=[float(b.double().sum()) for b in m.buffers()],
+                mom=[float(sd['state'][k]['momentum_buffer'].double().sum()) for k in sorted(sd['state'])],
+                mom_shapes=[list(sd['state'][k]['momentum_buffer'].shape) for k in sorted(sd['state'])],
+                lrs=[g['lr'] for g in sd['param_groups']])
+class Wrapped(nn.Module):            # what apex / our DDP wrapper looks like to the state dict: 'module.' prefix
+    def __init__(self, m):
+        super().__init__(); self.module = m
+'''
+
+_CKPT_REF_WRITE = _CKPT_COMMON + r'''
+sys.path.insert(0, "/root/reference/furnace")
+import utils.pyt_utils
+from engine.engine import Engine, State
+m = make(); opt = torch.optim.SGD(groups(m), lr=0.05, momentum=0.9, weight_decay=5e-4)
+for _ in range(2):
+    opt.zero_grad(); m(torch.randn(2, 3, 8, 8)).square().mean().backward(); opt.step()
+st = State(); st.register(model=Wrapped(m), optimizer=opt); st.epoch = 3; st.iteration = 77
+Engine.save_checkpoint(types.SimpleNamespace(state=st), sys.argv[1])
+print(json.dumps(digest(m, opt)))
+'''
+
+_CKPT_OURS = _CKPT_COMMON + r'''
+from engine.engine import Engine, State          # torchseg_amd/furnace (cwd-staged path)
+from torchseg_amd.optim import FusedSGD
+m = make()
+for p in m.parameters():
+    p.data.add_(1.0)                             # make sure the restore really overwrites
+m[3].weight.data = m[3].weight.data.contiguous(memory_format=torch.channels_last)
+opt = FusedSGD(groups(m), lr=0.01, momentum=0.9, weight_decay=5e-4)
+st = State(); st.register(model=Wrapped(m), optimizer=opt)
+eng = types.SimpleNamespace(state=st, continue_state_object=sys.argv[1], distributed=True)
+Engine.restore_checkpoint(eng)
+assert st.epoch == 4 and st.iteration == 77, (st.epoch, st.iteration)
+Engine.save_checkpoint(eng, sys.argv[2])
+print(json.dumps(digest(st.model.module, opt)))
+'''
+
+_CKPT_REF_READ = _CKPT_COMMON + r'''
+sys.path.insert(0, "/root/reference/furnace")
+import utils.pyt_utils
+from engine.engine import Engine, State
+m = make(); opt = torch.optim.SGD(groups(m), lr=0.01, momentum=0.9, weight_decay=5e-4)
+st = State(); st.register(model=Wrapped(m), optimizer=opt)
+eng = types.SimpleNamespace(state=st, continue_state_object=sys.argv[1], distributed=True)
+Engine.restore_checkpoint(eng)
+assert st.epoch == 5 and st.iteration == 77
+opt.zero_grad(); m(torch.ones(1, 3, 8, 8)).square().mean().backward(); opt.step()    # the restored state is usable
+print(json.dumps(digest(m, opt)))
+'''
+
+
+def test_checkpoints_interchange_with_reference_engine(tmp_path):
+    """SURVEY 8(f)-4: a checkpoint written by the reference Engine (torch SGD, 'module.'-stripped keys) restores
+    into our Engine + FusedSGD, and the checkpoint our Engine writes restores into the reference's."""
+    import subprocess
+    import sys as _sys
+    d = stage(tmp_path, "bisenet", "cityscapes.bisenet.R18")
+    ref_ckpt, our_ckpt = str(tmp_path / "ref.pth"), str(tmp_path / "ours.pth")
+
+    def run(script, *args, ours):
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "torchseg_amd", "shims")]
+                                            + ([os.path.join(ROOT, "torchseg_amd", "furnace")] if ours else []))
+        r = subprocess.run([_sys.executable, "-c", script, *args], cwd=d, env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    a = run(_CKPT_REF_WRITE, ref_ckpt, ours=False)
+    b = run(_CKPT_OURS, ref_ckpt, our_ckpt, ours=True)
+    for k in ("params", "bufs", "mom", "mom_shapes", "lrs"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    c = run(_CKPT_REF_READ, our_ckpt, ours=False)
+    assert c["mom_shapes"] == a["mom_shapes"] and c["lrs"] == a["lrs"]

@@ -96,3 +96,38 @@ def test_fused_sgd_many_tensors_one_launch(cuda):
         oa.step(); ob.step()
     for i, (p, q) in enumerate(zip(ref, our)):
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6, msg="tensor %d (n=%d)" % (i, sizes[i]))
+
+
+def test_fused_sgd_state_dict_interchanges_with_torch_sgd(cuda):
+    """Checkpoint compatibility (engine.py:103-137 stores optimizer.state_dict()): momentum buffers keep the
+    parameter's logical shape even for channels_last weights, torch.optim.SGD loads a FusedSGD state dict and
+    FusedSGD loads torch's, and both continue identically."""
+    import copy
+    from torchseg_amd.optim import FusedSGD
+    a, b = _models(cuda)                                   # b[3].weight is channels_last
+    oa = torch.optim.SGD(_groups(a), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    ob = FusedSGD(_groups(b), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    g = torch.Generator(device=cuda).manual_seed(3)
+
+    def one_step(pairs):
+        x = torch.randn(4, 3, 16, 16, device=cuda, generator=g)
+        y = torch.randint(0, 5, (4,), device=cuda, generator=g)
+        for m, o in pairs:
+            o.zero_grad()
+            nn.functional.cross_entropy(m(x), y).backward()
+            o.step()
+
+    for _ in range(2):
+        one_step(((a, oa), (b, ob)))
+    sa, sb = copy.deepcopy(oa.state_dict()), copy.deepcopy(ob.state_dict())
+    for k, st in sb["state"].items():
+        assert st["momentum_buffer"].shape == sa["state"][k]["momentum_buffer"].shape
+        torch.testing.assert_close(st["momentum_buffer"].contiguous(), sa["state"][k]["momentum_buffer"], rtol=1e-5, atol=1e-6)
+    oa2 = torch.optim.SGD(_groups(a), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    ob2 = FusedSGD(_groups(b), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    oa2.load_state_dict(sb)                                # torch <- ours
+    ob2.load_state_dict(sa)                                # ours  <- torch (contiguous buffers for a channels_last weight)
+    for _ in range(2):
+        one_step(((a, oa2), (b, ob2)))
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6, msg=n)

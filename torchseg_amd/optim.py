@@ -14,6 +14,18 @@ import torch
 from . import kernels as K
 
 
+def _same_dense_order(a, b):
+    """Same element order in memory?  Equal strides, or a [O, I, 1, 1] tensor, whose contiguous and
+    channels_last forms coincide in memory while reporting different strides."""
+    if a.stride() == b.stride():
+        return True
+    if a.dim() == 4 and a.shape == b.shape and a.shape[2] == 1 and a.shape[3] == 1:
+        def dense(t):
+            return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)
+        return dense(a) and dense(b)
+    return False
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-2, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
@@ -58,26 +70,26 @@ class FusedSGD(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                if "momentum_buffer" not in st:
-                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                grad = p.grad
                 if p.dtype != torch.float32:
                     raise K.L.TsgError("FusedSGD keeps fp32 master parameters (autocast casts them per op)")
-                if grad.dtype != torch.float32 or grad.stride() != p.stride():
+                if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                    raise K.L.TsgError("FusedSGD: parameter is neither contiguous nor channels_last")
+                # The update is element-wise, so parameter, gradient and momentum buffer only have to share one
+                # dense layout; the buffer keeps the parameter's logical shape (what torch.optim.SGD stores), so
+                # optimizer state dicts are interchangeable with the reference's (engine.py:103-137).
+                buf = st.get("momentum_buffer")
+                if buf is None:
+                    buf = st["momentum_buffer"] = torch.zeros_like(p)
+                elif not _same_dense_order(buf, p) or buf.dtype != p.dtype or buf.device != p.device:
+                    b2 = torch.empty_like(p)          # e.g. restored from a checkpoint written in another layout
+                    b2.copy_(buf)
+                    buf = st["momentum_buffer"] = b2
+                grad = p.grad
+                if grad.dtype != torch.float32 or not _same_dense_order(grad, p):
                     g2 = torch.empty_like(p)          # same dense layout as the parameter
                     g2.copy_(grad)
                     grad = g2
-                buf = st["momentum_buffer"]
-                if p.is_contiguous():
-                    pv, gv, bv = p, grad, buf
-                elif p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
-                    # the update is element-wise: address the dense NHWC storage directly
-                    pv, gv = p.permute(0, 2, 3, 1), grad.permute(0, 2, 3, 1)
-                    if buf.shape != pv.shape:
-                        st["momentum_buffer"] = buf = torch.zeros(pv.shape, dtype=p.dtype, device=p.device)
-                    bv = buf
-                else:
-                    raise K.L.TsgError("FusedSGD: parameter is neither contiguous nor channels_last")
+                pv, gv, bv = p, grad, buf
                 segs.append((pv, gv, bv, gi))
         if not segs:
             return None
