@@ -344,6 +344,22 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
                 void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Evaluation metric — replaces hist_info (furnace/seg_opr/metric.py:9-19) as the
+ * evaluators call it (model/bisenet/cityscapes.bisenet.R18/eval.py:31-33) on the
+ * arg-max of the score map (furnace/engine/evaluator.py).  out is int64
+ * [n_cl*n_cl + 3] = hist (row = ground truth, column = prediction), labeled,
+ * correct, and the number of labelled pixels whose prediction is outside [0, n_cl)
+ * (numpy would raise there); the call ADDS to out, so one zeroed buffer accumulates
+ * a whole validation set.  gt values outside [0, n_cl) (255, -1) are skipped.
+ * n_cl <= 192.  tsg_confusion_logits fuses the class arg-max over logits [B, C, HW]
+ * (first maximum, NaN wins: numpy/torch rule).
+ * ---------------------------------------------------------------------- */
+int tsg_confusion_map(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int64_t P,
+                      int n_cl, int64_t* out, void* stream);
+int tsg_confusion_logits(const void* logits, int dtype, const void* gt, int gt_dtype, int64_t B,
+                         int C, int64_t HW, int n_cl, int64_t* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused SGD step over a flat parameter bucket (torch.optim.SGD semantics as
  * configured at train.py:86-89: momentum, weight decay, no nesterov).
  * ---------------------------------------------------------------------- */

@@ -105,6 +105,35 @@ def main():
         out[name + "/grad"] = pred.grad.numpy()
         print(name, "focal", loss.item())
     np.savez_compressed(os.path.join(HERE, "focal_golden.npz"), **out)
+    metric_golden()
+
+
+def metric_golden():
+    """hist_info / compute_score of the reference's furnace/seg_opr/metric.py on seeded label maps."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_metric", os.path.join(REF, "furnace/seg_opr/metric.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.RandomState(7)
+    out = {}
+    for name, (n_cl, shape, ignore, p_right) in {"city19": (19, (2, 40, 56), 255, 0.7), "ade150": (150, (1, 64, 48), -1, 0.4),
+                                                 "tiny2": (2, (1, 5, 7), 255, 0.5), "all_ignored": (19, (1, 8, 8), 255, 0.5)}.items():
+        gt = rng.randint(0, n_cl, size=shape).astype(np.int64)
+        pred = np.where(rng.rand(*shape) < p_right, gt, rng.randint(0, n_cl, size=shape)).astype(np.int64)
+        gt[rng.rand(*shape) < 0.1] = ignore
+        if name == "all_ignored":
+            gt[:] = ignore
+        hist, labeled, correct = ref.hist_info(n_cl, pred, gt)
+        iu, miu, miu_nb, acc = ref.compute_score(hist, correct, labeled)
+        out[name + "/n_cl"] = np.array(n_cl)
+        out[name + "/pred"] = pred.astype(np.int16)
+        out[name + "/gt"] = gt.astype(np.int16)
+        out[name + "/hist"] = hist.astype(np.int64)
+        out[name + "/counts"] = np.array([labeled, correct], dtype=np.int64)
+        out[name + "/iu"] = np.asarray(iu, dtype=np.float64)
+        out[name + "/scores"] = np.array([miu, miu_nb, acc], dtype=np.float64)
+        print(name, "labeled", labeled, "correct", correct, "mIoU", miu)
+    np.savez_compressed(os.path.join(HERE, "metric_golden.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -83,3 +83,41 @@ def test_conv_oracle_matches_torch_cpu_convolution():
         y.backward(dy)
         assert torch.allclose(conv_ref.conv2d_ref(x, w.detach()), y.detach(), rtol=0, atol=1e-11)
         assert torch.allclose(conv_ref.conv2d_wgrad_ref(x, dy), w.grad, rtol=0, atol=1e-10)
+
+
+def _metric_cases():
+    z = np.load(os.path.join(GOLD, "metric_golden.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        yield name, {k.split("/")[1]: z[k] for k in z.files if k.startswith(name + "/")}
+
+
+def test_metric_oracle_matches_reference_golden():
+    """oracle/metric_ref.py == the reference's metric.py (hist bit-exact, scores to 1e-12, NaN where it is NaN)."""
+    from oracle import metric_ref
+    n = 0
+    for name, c in _metric_cases():
+        n_cl = int(c["n_cl"])
+        hist, labeled, correct = metric_ref.hist_info(n_cl, c["pred"], c["gt"])
+        assert np.array_equal(hist, c["hist"]), name
+        assert [labeled, correct] == c["counts"].tolist(), name
+        iu, miu, miu_nb, acc = metric_ref.compute_score(hist, correct, labeled)
+        np.testing.assert_allclose(iu, c["iu"], rtol=1e-12, atol=0, equal_nan=True, err_msg=name)
+        np.testing.assert_allclose([miu, miu_nb, acc], c["scores"], rtol=1e-12, atol=0, equal_nan=True, err_msg=name)
+        n += 1
+    assert n == 4
+
+
+def test_metric_host_mirror_scores_and_cpu_refusal():
+    """Our seg_opr.metric.compute_score (host arithmetic) == reference golden; hist_info refuses to run without a GPU."""
+    import sys
+    import pytest
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "torchseg_amd", "furnace"))
+    from seg_opr import metric
+    for name, c in _metric_cases():
+        iu, miu, miu_nb, acc = metric.compute_score(c["hist"], c["counts"][1], c["counts"][0])
+        np.testing.assert_allclose(iu, c["iu"], rtol=1e-12, equal_nan=True, err_msg=name)
+        np.testing.assert_allclose([miu, miu_nb, acc], c["scores"], rtol=1e-12, equal_nan=True, err_msg=name)
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            metric.hist_info(19, np.zeros((4, 4), np.int64), np.zeros((4, 4), np.int64))

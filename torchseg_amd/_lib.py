@@ -61,6 +61,8 @@ _PROTOS = {
     "tsg_stem_conv_ws_bytes": (_sz, []),
     "tsg_stem_conv_fwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_stem_conv_wrw": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_confusion_map": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p]),
+    "tsg_confusion_logits": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i, _p, _p]),
     "tsg_sgd_multi_blockmap": (_i64, [_p, _i, _p, _i64]),
     "tsg_sgd_multi_step_dev": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i64, _f, _p]),
     "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),

@@ -445,6 +445,31 @@ class HipKernels:
                                           lr_dev.data_ptr(), float(lr_mult), float(momentum), float(weight_decay),
                                           float(grad_scale), L.stream_ptr(param)), "tsg_sgd_step_dev")
 
+    # ---- evaluation metric ----------------------------------------------------
+    def confusion_map(self, pred, gt, n_cl, out=None):
+        """pred, gt: class-index maps (int64 or uint8, same numel) -> int64 [n_cl*n_cl + 3], accumulated into `out`"""
+        _require_contiguous(pred, gt)
+        if pred.numel() != gt.numel():
+            raise ValueError("pred and gt must have the same number of pixels")
+        if out is None:
+            out = torch.zeros(n_cl * n_cl + 3, dtype=torch.int64, device=gt.device)
+        L.check(self.lib.tsg_confusion_map(pred.data_ptr(), _label_code(pred), gt.data_ptr(), _label_code(gt),
+                                           gt.numel(), n_cl, out.data_ptr(), L.stream_ptr(gt)), "tsg_confusion_map")
+        return out
+
+    def confusion_logits(self, logits, gt, n_cl, out=None):
+        """logits [B,C,H,W] (f32 / bf16, contiguous), gt [B,H,W] -> as confusion_map with pred = argmax_C"""
+        _require_contiguous(logits, gt)
+        B, Cc = logits.shape[0], logits.shape[1]
+        HW = logits.numel() // max(B * Cc, 1)
+        if gt.numel() != B * HW:
+            raise ValueError("gt must have one label per pixel of logits")
+        if out is None:
+            out = torch.zeros(n_cl * n_cl + 3, dtype=torch.int64, device=gt.device)
+        L.check(self.lib.tsg_confusion_logits(logits.data_ptr(), L.dtype_code(logits), gt.data_ptr(), _label_code(gt),
+                                              B, Cc, HW, n_cl, out.data_ptr(), L.stream_ptr(gt)), "tsg_confusion_logits")
+        return out
+
     SGD_MAX_SEGS = 128
 
     def sgd_multi_blockmap(self, numel, device):

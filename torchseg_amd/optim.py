@@ -28,7 +28,11 @@ def _same_dense_order(a, b):
 
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-2, momentum=0.0, weight_decay=0.0):
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        # the keys torch.optim.SGD keeps per group, so state dicts load in either direction (checkpoint compat);
+        # the values below are the only ones implemented (and the ones the reference uses, train.py:86-89)
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay,
+                                      nesterov=False, maximize=False, foreach=None, differentiable=False,
+                                      fused=None))
         self._lr_dev = None
         self._lr_host = None
         self._plans = {}
@@ -66,6 +70,8 @@ class FusedSGD(torch.optim.Optimizer):
             raise K.L.TsgError("FusedSGD supports at most 16 parameter groups")
         segs = []                                   # (param view, grad view, buffer, group index)
         for gi, group in enumerate(self.param_groups):
+            if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
+                raise K.L.TsgError("FusedSGD implements dampening=0, nesterov=False, maximize=False only")
             for p in group["params"]:
                 if p.grad is None:
                     continue
