@@ -1,0 +1,31 @@
+"""profiles/traffic.json from a `tools/pmc_traffic.sh` run: HBM bytes per launch (PMC) for each kernel family
+bench.py reports a roofline for.  bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB for 16-B/lane streams (the gfx950
+FETCH_SIZE correction of MI355X_MICROARCH.md); kernels whose loads are 4 B/lane or scalar use the uncorrected sum
+(listed in UNCORRECTED).  Launch-weighted mean over the template instances of a family."""
+import json, re, sys
+src = json.load(open(sys.argv[1]))
+FAMILIES = [("bn_stats", r"bn_reduce_(nhwc|nchw)<[^,]+, \d+, 0,"), ("bn_bwd_reduce", r"bn_reduce_(nhwc|nchw)<[^,]+, \d+, 1,"),
+            ("bn_apply_fwd", r"bn_fwd_(nhwc|nchw)<"), ("bn_bwd_apply", r"bn_bwd_(nhwc|nchw)<"),
+            ("ohem_fwd", r"ohem_pass_a<"), ("ohem_bwd", r"ohem_bwd_k<"),
+            ("upsample_fwd", r"tsg::up_fwd<"), ("upsample_bwd", r"tsg::up_bwd(_tiled)?<"),
+            ("upsample_fwd_nhwc", r"up_fwd_nhwc<"), ("upsample_bwd_nhwc", r"up_bwd_nhwc<"),
+            ("chanscale_fwd", r"cs_fwd_"), ("chanscale_bwd", r"cs_bwd_"), ("gap_fwd", r"gap_fwd"), ("gap_bwd", r"gap_bwd"),
+            ("maxpool_fwd", r"maxpool_fwd_nhwc<"), ("maxpool_bwd", r"maxpool_bwd_nhwc<"),
+            ("stem_conv_fwd", r"stem_fwd_k"), ("stem_conv_wrw", r"stem_wrw_k"), ("sgd_multi_step", r"sgd_multi_k")]
+UNCORRECTED = {"ohem_bwd", "stem_conv_fwd"}          # scalar side-array loads / 4-B-per-lane patch loads
+out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 2`, "
+                  "MI355X, tools/pmc_traffic.sh + tools/make_traffic_json.py; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                  "(KiB units, FETCH_SIZE counts 1/2 of 16-B/lane streams on gfx950: MI355X_MICROARCH.md), uncorrected sum for "
+                  + ", ".join(sorted(UNCORRECTED)) + " whose loads are not 16-B/lane streams; stem_conv_wrw mixes both (dy 16 B, x 4 B per lane) "
+                  "and is reported corrected (upper bound)."}
+for fam, pat in FAMILIES:
+    tot = n = 0
+    for k, v in src.items():
+        if re.search(pat, k):
+            f, w, l = v["FETCH_SIZE_KiB_per_launch"], v["WRITE_SIZE_KiB_per_launch"], v["launches"]
+            b = ((1 if fam in UNCORRECTED else 2) * f + w) * 1024
+            tot += b * l; n += l
+    if n:
+        out[fam] = int(tot / n)
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "_source"}, indent=1))
