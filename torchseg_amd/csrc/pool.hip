@@ -289,10 +289,13 @@ __global__ __launch_bounds__(kT) void maxpool_fwd_nhwc(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int V>
+// FIX = true: the ResNet pooling geometry K = 3, S = 2, P = 1 as compile-time constants (shifts instead of
+// runtime integer divisions); the window positions of a vector arrive as one 4- or 8-byte load.
+template <typename T, int V, bool FIX>
 __global__ __launch_bounds__(kT) void maxpool_bwd_nhwc(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                        T* __restrict__ dx, int64_t N, int C, int IH, int IW,
-                                                       int OH, int OW, int K, int S, int P) {
+                                                       int OH, int OW, int K_, int S_, int P_) {
+  const int K = FIX ? 3 : K_, S = FIX ? 2 : S_, P = FIX ? 1 : P_;
   const int G = C / V;
   const int64_t total = N * IH * (int64_t)IW * G;
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
@@ -316,10 +319,16 @@ __global__ __launch_bounds__(kT) void maxpool_bwd_nhwc(const T* __restrict__ dy,
         const int64_t o = ((n * OH + oy) * (int64_t)OW + ox) * C + g * V;
         PV<T, V> d;
         d.load(dy + o);
-        const uint8_t* ip = idx + o;
+        uint32_t w[2];
+        if (V == 8) {
+          const uint2 u = *reinterpret_cast<const uint2*>(idx + o);
+          w[0] = u.x; w[1] = u.y;
+        } else {
+          w[0] = *reinterpret_cast<const uint32_t*>(idx + o); w[1] = 0u;
+        }
 #pragma unroll
         for (int j = 0; j < V; ++j)
-          if (ip[j] == pos) acc[j] += d.v[j];
+          if ((int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu) == pos) acc[j] += d.v[j];
       }
     }
     PV<T, V> o;
@@ -542,12 +551,22 @@ int tsg_maxpool_nhwc_bwd(const void* dy, const void* argmax_u8, void* dx, int dt
   hipStream_t st = (hipStream_t)stream;
   int64_t g = (N * IH * (int64_t)IW * (C / V) + kT - 1) / kT;
   if (g > 16384) g = 16384;
-  if (dtype == TSG_F32)
-    hipLaunchKernelGGL((maxpool_bwd_nhwc<float, 4>), dim3((unsigned)g), dim3(kT), 0, st, (const float*)dy,
-                       (const uint8_t*)argmax_u8, (float*)dx, N, C, IH, IW, OH, OW, K, S, P);
-  else
-    hipLaunchKernelGGL((maxpool_bwd_nhwc<bf16_t, 8>), dim3((unsigned)g), dim3(kT), 0, st, (const bf16_t*)dy,
-                       (const uint8_t*)argmax_u8, (bf16_t*)dx, N, C, IH, IW, OH, OW, K, S, P);
+  const bool fix = K == 3 && S == 2 && P == 1;
+  if (dtype == TSG_F32) {
+    if (fix)
+      hipLaunchKernelGGL((maxpool_bwd_nhwc<float, 4, true>), dim3((unsigned)g), dim3(kT), 0, st, (const float*)dy,
+                         (const uint8_t*)argmax_u8, (float*)dx, N, C, IH, IW, OH, OW, K, S, P);
+    else
+      hipLaunchKernelGGL((maxpool_bwd_nhwc<float, 4, false>), dim3((unsigned)g), dim3(kT), 0, st, (const float*)dy,
+                         (const uint8_t*)argmax_u8, (float*)dx, N, C, IH, IW, OH, OW, K, S, P);
+  } else {
+    if (fix)
+      hipLaunchKernelGGL((maxpool_bwd_nhwc<bf16_t, 8, true>), dim3((unsigned)g), dim3(kT), 0, st, (const bf16_t*)dy,
+                         (const uint8_t*)argmax_u8, (bf16_t*)dx, N, C, IH, IW, OH, OW, K, S, P);
+    else
+      hipLaunchKernelGGL((maxpool_bwd_nhwc<bf16_t, 8, false>), dim3((unsigned)g), dim3(kT), 0, st, (const bf16_t*)dy,
+                         (const uint8_t*)argmax_u8, (bf16_t*)dx, N, C, IH, IW, OH, OW, K, S, P);
+  }
   TSG_CHECK_LAUNCH();
   return 0;
 }
