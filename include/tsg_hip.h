@@ -206,6 +206,17 @@ int tsg_stem_conv_fwd(const void* x, const float* w, void* y, int64_t B, int64_t
 int tsg_stem_conv_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / padding 1 convolutions (ResNet-18 layer1:
+ * BasicBlock.conv1 / conv2, furnace/base_model/resnet.py:24-29,36-53) — replaces the cuDNN
+ * backward-filter call autograd makes for them.  x [B,H,W,64] and dy [B,H,W,64] bf16 channels_last;
+ * dw fp32 in the channels_last weight layout [oc][kh][kw][ci] (fp32 accumulation, fixed summation
+ * order).  ws: tsg_conv3x3_wrw_ws_bytes() bytes.  Forward and the data gradient stay on MIOpen. */
+int tsg_conv3x3_wrw_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                              int dilation, int groups);
+size_t tsg_conv3x3_wrw_ws_bytes(void);
+int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
+                    void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
  * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.

@@ -1,0 +1,71 @@
+"""Weight gradient of ResNet-18 layer1's 3x3 convolutions on our MFMA kernel.
+
+The four `conv3x3(64, 64)` of layer1 (furnace/base_model/resnet.py:24-29,36-53) see the largest
+activations of the context path ([16, 64, 256, 256] at BASELINE config 2).  MIOpen computes their
+weight gradient as a split-K implicit GEMM framed by a zero fill and a cast (244 µs each for
+268 MB of operands, tools/bench_conv3wrw.py); `tsg_conv3x3_wrw` streams the two operands once
+(154 µs, fp32 result instead of a bf16-rounded one).  Forward and the data
+gradient stay on MIOpen: the module is re-classed to `WrwConv2d`, whose autograd function calls
+`aten::convolution_backward` for dx only.
+
+On by default under the DDP wrapper (bf16, channels_last); TSG_CONV_WRW=0 restores MIOpen's path."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels as K
+
+
+class _ConvWrwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, wb):
+        # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
+        y = F.conv2d(x, wb, None, 1, 1)
+        ctx.save_for_backward(x, wb)
+        ctx.wdtype = weight.dtype
+        ctx.need_dx = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = None
+        if ctx.need_dx:
+            dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        dw = K.provider().conv3x3_wrw(x, dy)
+        return dx, dw.to(ctx.wdtype), None
+
+
+class WrwConv2d(nn.Conv2d):
+    def forward(self, x):
+        if (x.is_cuda and self.bias is None and self.weight.dtype == torch.float32 and x.dim() == 4
+                and self.padding_mode == "zeros" and torch.is_grad_enabled() and self.weight.requires_grad
+                and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and x.dtype == torch.float32
+                                                    and torch.get_autocast_dtype("cuda") == torch.bfloat16))):
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            xb = xb.contiguous(memory_format=torch.channels_last)
+            if K.provider().conv3x3_wrw_supported(xb, self.weight, self.stride[0], self.padding[0], self.dilation[0],
+                                                  self.groups):
+                with torch.autocast("cuda", enabled=False):
+                    wb = self.weight.detach().to(torch.bfloat16)
+                    return _ConvWrwFn.apply(xb, self.weight, wb)
+        return super().forward(x)
+
+
+def _eligible(m):
+    return (type(m) is nn.Conv2d and m.in_channels == 64 and m.out_channels == 64 and m.kernel_size == (3, 3)
+            and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None)
+
+
+def install_conv_wrw(module):
+    """Re-class the eligible convolutions in place; returns how many were found."""
+    n = 0
+    for m in module.modules():
+        if _eligible(m):
+            m.__class__ = WrwConv2d
+            n += 1
+    return n

@@ -1,0 +1,218 @@
+// Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / padding 1 convolutions of ResNet-18's layer1
+// (furnace/base_model/resnet.py:24-29 BasicBlock.conv1/conv2 with planes = 64; four per step at
+// [16, 64, 256, 256]), channels_last bf16:
+//
+//     dw[oc][kh][kw][ci] = sum_{b, oh, ow} dy[b, oh, ow, oc] * x[b, oh + kh - 1, ow + kw - 1, ci]
+//
+// MIOpen runs this as a split-K implicit GEMM with a zero fill and a cast around it (198 + ~25 us per
+// convolution on MI355X for 268 MB of operands).  Here: GEMM M = oc (64), N = (tap, ci) = 576, K = pixels.
+// K is the pixel axis, so both operands are transposed while they are staged in LDS:
+//   dy^T [oc][128 pixels of the tile]                       (two pixels per 32-bit write)
+//   x^T  [ci][6 x 34 patch pixels], stored twice (element j at index j and at j + 1) so that the 8 consecutive
+//        pixels of a fragment start on a 32-bit boundary for every tap column kw; the per-channel stride of
+//        121 dwords spreads the 32 lanes of a ds_read_b32 over the 32 banks.
+// A block's 4 waves own the whole [64 x 576] accumulator (9 tiles of 32x32 each: oc half x ci half x 9 taps)
+// in MFMA registers across all its tiles; per-block partials are summed in fp64 in a fixed order.
+#include "tsg_common.h"
+
+namespace tsg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+// The LDS images are written with 16- and 32-bit stores and read back as 32- and 128-bit fragments: every
+// access goes through may_alias types so that type-based alias analysis cannot reorder or drop them.
+typedef uint32_t __attribute__((may_alias)) lds_u32;
+typedef uint16_t __attribute__((may_alias)) lds_u16;
+typedef bf16x8 __attribute__((may_alias)) lds_bf16x8;
+
+constexpr int W3_C = 64;                    // channels in and out
+constexpr int W3_N = 9 * W3_C;              // 576 = (tap, ci)
+constexpr int W3_TH = 4, W3_TW = 32;        // output tile: 4 rows x 32 columns = 8 K-steps of 16 pixels
+constexpr int W3_PR = W3_TH + 2;            // 6 patch rows
+constexpr int W3_PP = (W3_TW + 2) / 2;      // 17 pixel pairs per patch row
+constexpr int W3_RD = 20;                   // patch row stride in dwords (40 elements, 34 used)
+constexpr int W3_CS = 121;                  // per-channel stride in dwords (6 x 20 = 120 used; odd => conflict-free)
+constexpr int W3_COPY = W3_C * W3_CS;       // dwords per alignment copy
+constexpr int W3_DS = 68;                   // dy^T row stride in dwords (128 pixels + 8 pad elements)
+constexpr int W3_NCH = 8 * W3_PR * W3_PP;   // 816 (pixel pair, 8-channel group) chunks of a patch
+constexpr int W3_NU = (W3_NCH + 255) / 256; // 4 per thread
+constexpr int W3_NPART = 256;               // persistent blocks: the 144-register accumulator allows one block per CU
+
+// `two` is the constant 2 passed at run time: the two 16-bit stores of alignment copy 1 are adjacent in memory, and
+// with a compile-time distance the compiler merges them into one 32-bit store off its natural alignment.
+struct W3Geom { int B, H, W, tiles_h, tiles_w, ntiles, two; };
+
+__global__ __launch_bounds__(256) void conv3_wrw_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                   float* __restrict__ part, W3Geom g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  lds_u32* dyT = reinterpret_cast<lds_u32*>(lds);       // [64][W3_DS]
+  lds_u32* xT = dyT + W3_C * W3_DS;                     // [2 copies][64][W3_CS]
+  lds_u16* xT16 = reinterpret_cast<lds_u16*>(xT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, n = lane & 31;
+  const int wm = wave >> 1, wh = wave & 1;              // oc half, ci half
+
+  // ---- tile-independent staging descriptors
+  const int spp = tid & 15, strow = (tid >> 4) & 1, spart = tid >> 5;      // dy: pixel pair, row (and +2), 8-oc group
+  int xoff[W3_NU], xrc[W3_NU], xdst[W3_NU];             // x: element offset from &x[b, oh0, ow0, 0]; r | c << 8; LDS dword
+#pragma unroll
+  for (int u = 0; u < W3_NU; ++u) {
+    const int q = tid + 256 * u;
+    const int cpart = q / (W3_PR * W3_PP), rem = q % (W3_PR * W3_PP), r = rem / W3_PP, pc = rem % W3_PP;
+    xrc[u] = q < W3_NCH ? (r | ((2 * pc) << 8)) : -1;
+    xoff[u] = ((r - 1) * g.W + 2 * pc - 1) * W3_C + cpart * 8;
+    xdst[u] = (cpart * 8) * W3_CS + r * W3_RD + pc;
+  }
+  // ---- fragment addressing (dwords)
+  const lds_u32* afrag = dyT + (32 * wm + n) * W3_DS + 4 * half;          // + ks * 8
+  const lds_u32* bfrag = xT + (32 * wh + n) * W3_CS + 4 * half;           // + copy / row / column offsets
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  uint4 rd[4];
+  uint4 rx[W3_NU][2];
+  auto fetch = [&](int tile) {
+    const int ow0 = (tile % g.tiles_w) * W3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
+    const int b = tile / (g.tiles_w * g.tiles_h);
+    const int64_t org = (((int64_t)b * g.H + oh0) * g.W + ow0) * W3_C;
+    const bf16_t* dt = dy + org + ((int64_t)strow * g.W + 2 * spp) * W3_C + spart * 8;
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+        rd[rs * 2 + px] = (oh0 + strow + 2 * rs < g.H && ow0 + 2 * spp + px < g.W)
+                              ? *reinterpret_cast<const uint4*>(dt + ((int64_t)rs * 2 * g.W + px) * W3_C)
+                              : make_uint4(0, 0, 0, 0);
+    const bf16_t* xo = x + org;
+#pragma unroll
+    for (int u = 0; u < W3_NU; ++u) {
+      const int ih = oh0 - 1 + (xrc[u] & 0xff), iw = ow0 - 1 + (xrc[u] >> 8);
+      const bool rowok = xrc[u] >= 0 && ih >= 0 && ih < g.H;
+      rx[u][0] = (rowok && iw >= 0 && iw < g.W) ? *reinterpret_cast<const uint4*>(xo + xoff[u]) : make_uint4(0, 0, 0, 0);
+      rx[u][1] = (rowok && iw + 1 >= 0 && iw + 1 < g.W) ? *reinterpret_cast<const uint4*>(xo + xoff[u] + W3_C)
+                                                         : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < g.ntiles) fetch(tile);
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();                                    // the previous tile's fragment reads are done
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const uint32_t wa[4] = {rd[2 * rs].x, rd[2 * rs].y, rd[2 * rs].z, rd[2 * rs].w};
+      const uint32_t wb[4] = {rd[2 * rs + 1].x, rd[2 * rs + 1].y, rd[2 * rs + 1].z, rd[2 * rs + 1].w};
+      lds_u32* drow = dyT + (spart * 8) * W3_DS + 16 * (strow + 2 * rs) + spp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        drow[e * W3_DS] = (e & 1) ? ((wa[e >> 1] >> 16) | (wb[e >> 1] & 0xffff0000u))
+                                  : ((wa[e >> 1] & 0xffffu) | (wb[e >> 1] << 16));
+    }
+#pragma unroll
+    for (int u = 0; u < W3_NU; ++u) {
+      if (u < W3_NU - 1 || xrc[u] >= 0) {
+        const uint32_t wa[4] = {rx[u][0].x, rx[u][0].y, rx[u][0].z, rx[u][0].w};      // patch column 2 pc
+        const uint32_t wb[4] = {rx[u][1].x, rx[u][1].y, rx[u][1].z, rx[u][1].w};      // patch column 2 pc + 1
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t a = (e & 1) ? (wa[e >> 1] >> 16) : (wa[e >> 1] & 0xffffu);
+          const uint32_t b2 = (e & 1) ? (wb[e >> 1] >> 16) : (wb[e >> 1] & 0xffffu);
+          const int d = xdst[u] + e * W3_CS;
+          xT[d] = a | (b2 << 16);                                                    // copy 0: element j at j
+          xT16[2 * (W3_COPY + d) + 1] = (uint16_t)a;                                   // copy 1: element j at j + 1
+          xT16[2 * (W3_COPY + d) + g.two] = (uint16_t)b2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < g.ntiles) fetch(tile + gridDim.x);                   // in flight during the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                    // tile row ks >> 1, columns 16 (ks & 1) + 8 half ..
+      const bf16x8 fa = *reinterpret_cast<const lds_bf16x8*>(afrag + ks * 8);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int sg = kw & 1;
+          const lds_u32* q = bfrag + sg * W3_COPY + ((ks >> 1) + kh) * W3_RD + (ks & 1) * 8 + ((kw + sg) >> 1);
+          union { uint32_t u[4]; bf16x8 v; } fb;
+          fb.u[0] = q[0]; fb.u[1] = q[1]; fb.u[2] = q[2]; fb.u[3] = q[3];
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb.v, acc[kh * 3 + kw], 0, 0, 0);
+        }
+    }
+  }
+  // acc[t][r]: oc = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, column = t * 64 + 32 wh + n
+  float* out = part + (int64_t)blockIdx.x * W3_C * W3_N;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[oc * W3_N + t * W3_C + 32 * wh + n] = acc[t][r];
+    }
+}
+
+// dw[flat] = sum over the per-block partials (fixed order, fp64); 64 consecutive entries per block
+__global__ __launch_bounds__(256) void conv3_wrw_fold(const float* __restrict__ part, int nparts, int64_t stride,
+                                                      float* __restrict__ dw) {
+  __shared__ double sm[16][64];
+  const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
+  const float* src = part + blockIdx.x * 64 + c4 * 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+  for (int gidx = gs; gidx < nparts; gidx += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)gidx * stride);
+    a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  }
+  sm[gs][c4 * 4 + 0] = a0; sm[gs][c4 * 4 + 1] = a1; sm[gs][c4 * 4 + 2] = a2; sm[gs][c4 * 4 + 3] = a3;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x];
+    dw[blockIdx.x * 64 + threadIdx.x] = (float)t;
+  }
+}
+
+constexpr size_t W3_LDS = (size_t)(W3_C * W3_DS + 2 * W3_COPY) * sizeof(uint32_t) + 16;   // 79,376 B
+
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" {
+
+int tsg_conv3x3_wrw_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
+                              int groups) {
+  return dtype == TSG_BF16 && Cin == W3_C && Cout == W3_C && kh == 3 && kw == 3 && stride == 1 && pad == 1 &&
+         dilation == 1 && groups == 1;
+}
+
+size_t tsg_conv3x3_wrw_ws_bytes(void) { return (size_t)W3_NPART * W3_C * W3_N * sizeof(float); }
+
+int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !ws) return TSG_E_NULL;
+  if (B <= 0 || H <= 0 || W <= 0) return TSG_E_SHAPE;
+  const int64_t th = (H + W3_TH - 1) / W3_TH, tw = (W + W3_TW - 1) / W3_TW;
+  if (B * th * tw > 0x7fffffffLL || H * W * W3_C > 0x7fffffffLL) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_conv3x3_wrw_ws_bytes()) return TSG_E_WS;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
+  W3Geom g;
+  g.B = (int)B; g.H = (int)H; g.W = (int)W; g.tiles_h = (int)th; g.tiles_w = (int)tw; g.ntiles = (int)(B * th * tw); g.two = 2;
+  hipStream_t st = (hipStream_t)stream;
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)W3_LDS));
+  const int grid = g.ntiles < W3_NPART ? g.ntiles : W3_NPART;
+  hipLaunchKernelGGL(conv3_wrw_k, dim3(grid), dim3(256), W3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy, (float*)ws, g);
+  TSG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv3_wrw_fold, dim3(W3_C * W3_N / 64), dim3(256), 0, st, (const float*)ws, grid,
+                     (int64_t)W3_C * W3_N, dw);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -31,6 +31,7 @@ upsample overrides.  Controlled by env so train.py needs no edit:
                         but on MI355X streaming the bf16 logits at ~4-5 TB/s is as fast as re-interpolating them)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
   TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
+  TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw)
 """
 import os
 
@@ -244,6 +245,9 @@ class DistributedDataParallel(nn.Module):
             if _env_flag("TSG_STEM_CONV", True):
                 from .stemconv import install_stem_conv
                 install_stem_conv(self.module)
+            if _env_flag("TSG_CONV_WRW", True):
+                from .convwrw import install_conv_wrw
+                install_conv_wrw(self.module)
 
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None

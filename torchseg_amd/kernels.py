@@ -445,6 +445,29 @@ class HipKernels:
                                           lr_dev.data_ptr(), float(lr_mult), float(momentum), float(weight_decay),
                                           float(grad_scale), L.stream_ptr(param)), "tsg_sgd_step_dev")
 
+    # ---- 3x3 weight gradient ----------------------------------------------------
+    def conv3x3_wrw_supported(self, x, weight, stride, padding, dilation, groups):
+        if x.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+            return False
+        return bool(self.lib.tsg_conv3x3_wrw_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
+                                                       weight.shape[3], stride, padding, dilation, groups))
+
+    def conv3x3_wrw(self, x, dy):
+        """x, dy [B,64,H,W] bf16 channels_last -> dw fp32 [64,64,3,3] channels_last"""
+        for t in (x, dy):
+            if not t.is_contiguous(memory_format=torch.channels_last) or t.dtype != torch.bfloat16:
+                raise ValueError("conv3x3_wrw expects bf16 channels_last tensors")
+        B, _, H, W = x.shape
+        if tuple(dy.shape) != (B, 64, H, W):
+            raise ValueError("conv3x3_wrw: dy must have the shape of x (stride 1, padding 1)")
+        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        ws = getattr(self, "_c3_ws", None)
+        if ws is None or ws.device != x.device:
+            ws = self._c3_ws = torch.empty(self.lib.tsg_conv3x3_wrw_ws_bytes(), dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_conv3x3_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
+                                         L.stream_ptr(x)), "tsg_conv3x3_wrw")
+        return dw
+
     # ---- evaluation metric ----------------------------------------------------
     def confusion_map(self, pred, gt, n_cl, out=None):
         """pred, gt: class-index maps (int64 or uint8, same numel) -> int64 [n_cl*n_cl + 3], accumulated into `out`"""
@@ -542,6 +565,7 @@ _ALGO_BYTES = {
     "gap_fwd": lambda a, r: _nbytes(a[0]),
     "stem_conv_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
+    "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
 

@@ -56,7 +56,7 @@ class _StemConvFn(torch.autograd.Function):
 def _wants_bf16(x):
     if x.dtype == torch.bfloat16:
         return True
-    return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16 and x.dtype == torch.float32
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype == torch.float32
 
 
 class StemConv2d(nn.Conv2d):
