@@ -13,5 +13,10 @@ the build container (tests/golden/make_golden.py -> tests/golden/*.npz); the
 SyncBN restatement follows the legacy in-tree kernels, which cannot be built
 (CUDA-only, torch-1.0 API) and is pinned against torch.nn.BatchNorm2d on the
 rank-concatenated batch instead.  apex itself is absent: "parity unpinned" for
-anything that only apex defines.
+anything that only apex defines.  metric_ref.py (confusion matrix, mIoU) is
+pinned against the reference's furnace/seg_opr/metric.py through
+tests/golden/metric_golden.npz.  conv_ref.py restates torch's Conv2d
+definition (the reference's stems and layer1 call cuDNN through it) and is
+pinned against torch's CPU convolution and autograd in fp64: no reference
+vectors can exist for a library call ("parity unpinned" beyond that).
 """
