@@ -1,9 +1,9 @@
 """Stock PyTorch-ROCm sanity baseline: the same BiSeNet-R18 step with
 nn.BatchNorm2d (== SyncBN at world 1), ATen upsample, and the reference-Python OHEM
-(oracle restatement, run on the GPU) — the 'before' img/s each hand-written kernel must beat.
-    python tools/bench_stock.py [--steps K --warmup W --batch B --size S --dtype bf16|fp32 --nchw]"""
+(oracle restatement, run on the GPU) — the "before" img/s each hand-written kernel must beat.
+    python tests/bench_stock_baseline.py [--steps K --warmup W --batch B --size S --dtype bf16|fp32 --nchw]"""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import torch, torch.nn as nn
 import bench
 from oracle.ohem_ref import ProbOhemCrossEntropy2d as RefOhem
