@@ -399,6 +399,13 @@ int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* grads, const 
                            const float* momentum, const float* weight_decay, int ngroups,
                            const int* blockmap_dev, int64_t nblocks, float grad_scale, void* stream);
 
+/* Multi-tensor copy dst[i][:] = scale * src[i][:] (fp32), one launch for up to TSG_SGD_MAX_SEGS
+ * tensors: gathers the gradients autograd produced into the flat all-reduce bucket of the DDP
+ * wrapper (apex.parallel.DistributedDataParallel flattens them with apex_C.flatten, reference
+ * train.py:98-99).  Same block map as tsg_sgd_multi_step_dev (tsg_sgd_multi_blockmap). */
+int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* numel, int nseg,
+                       const int* blockmap_dev, int64_t nblocks, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,7 +53,9 @@ def _worker(rank, world, port, q):
     from torchseg_amd.syncbn import SyncBatchNorm
     K._set_provider_for_tests(OracleProvider())
     torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
-    model = DistributedDataParallel(Net(SyncBatchNorm), message_size=300)
+    net = Net(SyncBatchNorm)
+    net.c2.weight.data = net.c2.weight.data.contiguous(memory_format=torch.channels_last)   # strided bucket view
+    model = DistributedDataParallel(net, message_size=300)
     g = torch.Generator().manual_seed(7)
     xs = torch.randn(world, 3, 3, 6, 6, generator=g)       # unequal batches are allowed: rank r uses 3 (+1 for rank 1)
     ys = torch.randint(0, 5, (world, 3, 6, 6), generator=g)

@@ -131,3 +131,37 @@ def test_fused_sgd_state_dict_interchanges_with_torch_sgd(cuda):
         one_step(((a, oa2), (b, ob2)))
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6, msg=n)
+
+
+def test_ddp_bucket_gather_multi_tensor_copy(cuda):
+    """The N>1 gradient path on the GPU: fresh autograd gradients (contiguous, channels_last, 1-D) are gathered into
+    the flat all-reduce bucket by one multi-tensor launch, param.grad become views with the parameter's strides,
+    a planned parameter without a gradient leaves a zeroed hole, and a second pass reuses the views."""
+    from torchseg_amd.ddp import Reducer, _Bucket
+    g = torch.Generator().manual_seed(4)
+    shapes = [(8, 3, 3, 3), (16, 8, 3, 3), (16,), (5, 16, 1, 1), (5,), (4097,)]
+    params = [nn.Parameter(torch.randn(*s, generator=g).to(cuda)) for s in shapes]
+    params[1].data = params[1].data.contiguous(memory_format=torch.channels_last)
+    bucket = _Bucket(params, cuda)
+    for rnd in range(2):
+        grads = []
+        for i, p in enumerate(params):
+            gr = torch.randn(*p.shape, generator=g).to(cuda)
+            if i == 1:
+                gr = gr.contiguous(memory_format=torch.channels_last)
+            grads.append(gr)
+            p.grad = None if i == 4 else gr.clone(memory_format=torch.preserve_format)
+            bucket.ready[i] = i != 4
+        Reducer._gather(bucket)
+        torch.cuda.synchronize()
+        for i, p in enumerate(params):
+            v = bucket.views[i]
+            assert v.stride() == p.stride() and v.shape == p.shape
+            if i == 4:
+                assert p.grad is None and float(v.abs().sum()) == 0.0
+            else:
+                assert p.grad.data_ptr() == v.data_ptr()
+                assert torch.equal(p.grad, grads[i])
+        # the slots hold the gradients in the parameters' memory order
+        off = bucket.offsets[1]
+        assert torch.equal(bucket.flat[off:off + params[1].numel()], grads[1].permute(0, 2, 3, 1).reshape(-1))

@@ -198,3 +198,52 @@ extern "C" int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* gr
   TSG_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ---------------------------------------------------------------- multi-tensor copy (gradient -> DDP bucket)
+namespace tsg {
+struct CopySegs {
+  const float* s[TSG_SGD_MAX_SEGS];
+  float* d[TSG_SGD_MAX_SEGS];
+  int n[TSG_SGD_MAX_SEGS];
+};
+
+__global__ __launch_bounds__(256) void multi_copy_k(const CopySegs c, const int2* __restrict__ map, float scale) {
+  const int2 m = map[blockIdx.x];
+  const float* __restrict__ src = c.s[m.x];
+  float* __restrict__ dst = c.d[m.x];
+  const int n = c.n[m.x];
+  const int base = m.y * kSgdChunk;
+  const int end = base + kSgdChunk < n ? base + kSgdChunk : n;
+  const bool vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0;
+  if (vec) {
+    const int end4 = base + ((end - base) & ~3);
+    for (int i = base + 4 * threadIdx.x; i < end4; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(src + i);
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      *reinterpret_cast<float4*>(dst + i) = v;
+    }
+    for (int i = end4 + threadIdx.x; i < end; i += 256) dst[i] = src[i] * scale;
+  } else {
+    for (int i = base + threadIdx.x; i < end; i += 256) dst[i] = src[i] * scale;
+  }
+}
+}  // namespace tsg
+
+extern "C" int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* numel, int nseg,
+                                  const int* blockmap_dev, int64_t nblocks, float scale, void* stream) {
+  if (!src || !dst || !numel || !blockmap_dev) return TSG_E_NULL;
+  if (nseg <= 0 || nseg > TSG_SGD_MAX_SEGS) return TSG_E_SHAPE;
+  if (nblocks != tsg_sgd_multi_blockmap(numel, nseg, nullptr, 0)) return TSG_E_SHAPE;
+  tsg::CopySegs c = {};
+  for (int i = 0; i < nseg; ++i) {
+    if (!src[i] || !dst[i]) return TSG_E_NULL;
+    c.s[i] = (const float*)(uintptr_t)src[i];
+    c.d[i] = (float*)(uintptr_t)dst[i];
+    c.n[i] = (int)numel[i];
+  }
+  hipLaunchKernelGGL(tsg::multi_copy_k, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, c,
+                     reinterpret_cast<const int2*>(blockmap_dev), scale);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}

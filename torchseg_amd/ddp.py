@@ -61,7 +61,7 @@ def apply_channels_last(module):
 
 
 class _Bucket(object):
-    __slots__ = ("params", "offsets", "flat", "pending", "work", "ready")
+    __slots__ = ("params", "offsets", "flat", "pending", "work", "ready", "views", "maps")
 
     def __init__(self, params, device):
         self.params = params
@@ -74,10 +74,17 @@ class _Bucket(object):
         self.pending = len(params)
         self.work = None
         self.ready = [False] * len(params)
+        self.views = None           # filled lazily: one strided view per parameter
+        self.maps = {}              # static block maps of the multi-tensor gather, keyed by the copied indices
 
     def view(self, i):
+        """The slot of parameter i, shaped and strided like the parameter (a channels_last weight gets a
+        channels_last gradient view: same element order, so gather and optimizer address both as flat arrays)."""
         p = self.params[i]
-        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+        flat = self.flat[self.offsets[i]:self.offsets[i] + p.numel()]
+        if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            return flat.as_strided(p.shape, p.stride())
+        return flat.view_as(p)
 
 
 class Reducer(object):
@@ -119,17 +126,49 @@ class Reducer(object):
             return
         b, i = slot
         bucket = self.buckets[b]
-        view = bucket.view(i)
-        if p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)
-            p.grad = view
         if not bucket.ready[i]:
             bucket.ready[i] = True
             bucket.pending -= 1
             if bucket.pending == 0 and not self.delay:
                 self._launch(bucket)
 
+    @staticmethod
+    def _gather(bucket):
+        """Move the gradients autograd produced this pass into the flat buffer (one multi-tensor launch per 128
+        tensors on the GPU) and make `param.grad` the bucket views."""
+        if bucket.views is None:
+            bucket.views = [bucket.view(i) for i in range(len(bucket.params))]
+        todo = []
+        for i, p in enumerate(bucket.params):
+            v = bucket.views[i]
+            if not bucket.ready[i]:
+                v.zero_()                                # planned parameter without a gradient this pass
+            elif p.grad.data_ptr() != v.data_ptr():
+                todo.append(i)
+        if not todo:
+            return
+        on_gpu = bucket.flat.is_cuda
+        fast = []
+        for i in todo:
+            p, v = bucket.params[i], bucket.views[i]
+            g = p.grad
+            if on_gpu and g.dtype == torch.float32 and g.stride() == v.stride():
+                fast.append(i)
+            else:
+                v.copy_(g)
+                p.grad = v
+        if fast:
+            from . import kernels as K
+            kp = K.provider()
+            for c0 in range(0, len(fast), kp.SGD_MAX_SEGS):
+                idx = tuple(fast[c0:c0 + kp.SGD_MAX_SEGS])
+                srcs = [bucket.params[i].grad for i in idx]
+                bucket.maps[idx] = kp.multi_copy(srcs, [bucket.views[i] for i in idx], bucket.maps.get(idx))
+            for i in fast:
+                bucket.params[i].grad = bucket.views[i]
+
     def _launch(self, bucket):
+        self._gather(bucket)
         if self.prediv != 1.0:
             bucket.flat.div_(self.prediv)
         bucket.work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -171,10 +210,7 @@ class Reducer(object):
             self._build_plan()
         for bucket in self.buckets:
             if bucket.work is None:
-                # incomplete (a planned param got no grad this pass) or delayed: zero the holes
-                for i, ok in enumerate(bucket.ready):
-                    if not ok:
-                        bucket.view(i).zero_()
+                # incomplete (a planned param got no grad this pass; _gather zeroes the hole) or delayed
                 self._launch(bucket)
         for p in self._stragglers:
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)

@@ -516,6 +516,19 @@ class HipKernels:
                                                 blockmap.data_ptr(), blockmap.shape[0], float(grad_scale),
                                                 L.stream_ptr(lr_dev)), "tsg_sgd_multi_step_dev")
 
+    def multi_copy(self, srcs, dsts, blockmap=None, scale=1.0):
+        """dsts[i].copy_(srcs[i]) * scale for lists of dense fp32 tensors with pairwise equal element order
+        (<= SGD_MAX_SEGS per launch); returns the block map so a static list can reuse it."""
+        import numpy as np
+        numel = np.array([t.numel() for t in srcs], dtype=np.int64)
+        if blockmap is None:
+            blockmap = self.sgd_multi_blockmap(numel, srcs[0].device)
+        ptrs = np.array([[t.data_ptr() for t in srcs], [t.data_ptr() for t in dsts]], dtype=np.uint64)
+        L.check(self.lib.tsg_multi_copy_f32(ptrs[0].ctypes.data, ptrs[1].ctypes.data, numel.ctypes.data, len(srcs),
+                                            blockmap.data_ptr(), blockmap.shape[0], float(scale),
+                                            L.stream_ptr(srcs[0])), "tsg_multi_copy_f32")
+        return blockmap
+
 
 _provider = None
 
