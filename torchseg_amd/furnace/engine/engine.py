@@ -17,7 +17,6 @@ Changed for MI355X / modern launchers:
   * HSA_ENABLE_IPC_MODE_LEGACY=0 is exported before RCCL starts (dmabuf IPC).
 """
 import argparse
-import logging
 import os
 import os.path as osp
 import time

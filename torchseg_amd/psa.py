@@ -12,7 +12,6 @@ consumes it; any other consumer simply materialises the softmax.
 import torch
 from torch.overrides import TorchFunctionMode
 
-from . import _lib as L
 from . import kernels as K
 
 
