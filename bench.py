@@ -280,6 +280,14 @@ def main():
             out["roofline"]["measured_over"] = ("instrumented eager warm-up step (hipGraph replay has no host-side "
                                                 "launches to bracket)") if use_graph else "timed region"
             out["kernels_last_warmup_step"] = all_kernels
+        if args.dtype == "bf16" and args.size == 1024:
+            # whole-step HBM roofline of SURVEY.md 8(d): ~3.4 GB of algorithmic traffic per image in bf16 (our
+            # kernels 2.16 GB + the convolutions' operands once each + pools) => 2350 img/s per GPU at 8 TB/s
+            gb_per_img = 3.4
+            per_gpu = value / world
+            out["step_roofline"] = {"bound": "hbm", "algo_GB_per_img": gb_per_img,
+                                    "achieved": round(per_gpu * gb_per_img, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(per_gpu * gb_per_img / HBM_PEAK_GBS, 4), "target_frac": 0.70}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if world > 1 or force_coll:
