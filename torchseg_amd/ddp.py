@@ -148,11 +148,13 @@ class Reducer(object):
         if not todo:
             return
         on_gpu = bucket.flat.is_cuda
+        if on_gpu:
+            from .optim import _same_dense_order
         fast = []
         for i in todo:
             p, v = bucket.params[i], bucket.views[i]
             g = p.grad
-            if on_gpu and g.dtype == torch.float32 and g.stride() == v.stride():
+            if on_gpu and g.dtype == torch.float32 and _same_dense_order(g, v):
                 fast.append(i)
             else:
                 v.copy_(g)
