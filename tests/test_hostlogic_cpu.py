@@ -1,0 +1,71 @@
+"""CPU: host-side logic that needs no kernel — module re-classing and eligibility, the layout predicates the
+optimizer / DDP gather rely on, bucket views, FusedSGD's torch-compatible group keys."""
+import torch
+import torch.nn as nn
+
+
+def test_conv_module_swaps_select_only_the_intended_layers_and_pass_through_on_cpu():
+    from torchseg_amd.convwrw import WrwConv2d, install_conv_wrw
+    from torchseg_amd.stemconv import StemConv2d, install_stem_conv
+    torch.manual_seed(0)
+    net = nn.Sequential(
+        nn.Conv2d(3, 64, 7, 2, 3, bias=False),          # image stem            -> StemConv2d
+        nn.Conv2d(64, 64, 3, 1, 1, bias=False),         # layer1-style 3x3      -> WrwConv2d
+        nn.Conv2d(64, 64, 3, 2, 1, bias=False),         # stride 2              -> untouched
+        nn.Conv2d(64, 64, 3, 1, 2, dilation=2, bias=False),   # dilated          -> untouched
+        nn.Conv2d(64, 64, 3, 1, 1, bias=True),          # biased                -> untouched
+        nn.Conv2d(3, 64, 7, 2, 3, bias=True),           # biased stem           -> untouched
+    )
+    ref = [m.weight.detach().clone() for m in net]
+    keys = list(net.state_dict().keys())
+    assert install_stem_conv(net) == 1 and install_conv_wrw(net) == 1
+    assert [type(m) for m in net] == [StemConv2d, WrwConv2d, nn.Conv2d, nn.Conv2d, nn.Conv2d, nn.Conv2d]
+    assert list(net.state_dict().keys()) == keys                       # same parameters, same names
+    assert all(torch.equal(m.weight, w) for m, w in zip(net, ref))
+    x = torch.randn(1, 3, 32, 32)
+    y0 = nn.functional.conv2d(x, ref[0], None, 2, 3)
+    y1 = net[0](x)                                                      # CPU tensor: the stock convolution
+    assert torch.equal(y0, y1)
+    h = torch.randn(1, 64, 8, 8, requires_grad=True)
+    z = net[1](h)
+    assert torch.equal(z, nn.functional.conv2d(h, ref[1], None, 1, 1))
+    z.sum().backward()
+    assert net[1].weight.grad is not None and h.grad is not None
+
+
+def test_same_dense_order_predicate():
+    from torchseg_amd.optim import _same_dense_order
+    a = torch.randn(8, 4, 3, 3)
+    assert _same_dense_order(a, a.clone())
+    assert not _same_dense_order(a, a.contiguous(memory_format=torch.channels_last))
+    w = torch.randn(8, 4, 1, 1)
+    assert _same_dense_order(w, w.contiguous(memory_format=torch.channels_last))      # 1x1: identical memory order
+    assert _same_dense_order(w.contiguous(memory_format=torch.channels_last), w)
+    assert not _same_dense_order(w, torch.randn(8, 4, 1, 2)[..., :1])                  # not dense
+
+
+def test_bucket_views_follow_the_parameter_layout():
+    from torchseg_amd.ddp import _Bucket
+    p0 = nn.Parameter(torch.randn(6, 4, 3, 3))
+    p1 = nn.Parameter(torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+    p2 = nn.Parameter(torch.randn(7))
+    b = _Bucket([p0, p1, p2], torch.device("cpu"))
+    assert all(o % 4 == 0 for o in b.offsets)                          # 16-byte aligned slots
+    v0, v1, v2 = b.view(0), b.view(1), b.view(2)
+    assert v0.stride() == p0.stride() and v1.stride() == p1.stride() and v2.shape == p2.shape
+    v1.copy_(p1.detach())
+    flat = b.flat[b.offsets[1]:b.offsets[1] + p1.numel()]
+    assert torch.equal(flat, p1.detach().permute(0, 2, 3, 1).reshape(-1))   # the slot holds the parameter's memory order
+    v0.fill_(1.0); v2.fill_(2.0)
+    assert abs(float(b.flat.double().sum()) - (float(v1.double().sum()) + p0.numel() + 2.0 * p2.numel())) < 1e-4   # no overlap
+
+
+def test_fused_sgd_group_keys_match_torch_sgd():
+    from torchseg_amd.optim import FusedSGD
+    p = [nn.Parameter(torch.randn(3))]
+    ours = FusedSGD(p, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    theirs = torch.optim.SGD(p, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    assert set(theirs.param_groups[0].keys()) <= set(ours.param_groups[0].keys())
+    theirs.load_state_dict(ours.state_dict())
+    ours.load_state_dict(theirs.state_dict())
+    assert ours.param_groups[0]["momentum"] == 0.9 and ours.param_groups[0]["nesterov"] is False
