@@ -216,6 +216,11 @@ int tsg_conv3x3_wrw_supported(int dtype, int Cin, int Cout, int kh, int kw, int 
 size_t tsg_conv3x3_wrw_ws_bytes(void);
 int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
                     void* ws, size_t ws_bytes, void* stream);
+/* Same result through the second kernel variant: tiles stay pixel-major in LDS and the K = pixel fragments
+ * come from gfx950's transposing LDS read (ds_read_b64_tr_b16); bit-identical output is not guaranteed
+ * between the variants (different summation order), each is deterministic run to run. */
+int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward

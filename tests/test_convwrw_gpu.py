@@ -9,7 +9,7 @@ from oracle import conv_ref
 pytestmark = pytest.mark.gpu
 
 
-def _check(cuda, B, H, W, seed=0):
+def _check(cuda, B, H, W, seed=0, variant="tr"):
     from torchseg_amd import kernels as K
     kp = K.provider()
     g = torch.Generator().manual_seed(seed)
@@ -17,7 +17,7 @@ def _check(cuda, B, H, W, seed=0):
     dy = torch.randn(B, 64, H, W, generator=g)
     xb = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
     dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
-    dw = kp.conv3x3_wrw(xb, dyb)
+    dw = kp.conv3x3_wrw(xb, dyb, variant=variant)
     assert dw.shape == (64, 64, 3, 3) and dw.dtype == torch.float32
     want = conv_ref.conv2d_wgrad_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(dy), ksize=3, stride=1, pad=1)
     rel = ((dw.double().cpu() - want).norm() / want.norm()).item()
@@ -25,16 +25,18 @@ def _check(cuda, B, H, W, seed=0):
     return dw
 
 
+@pytest.mark.parametrize("variant", ["tr", "v1"])
 @pytest.mark.parametrize("shape", [(1, 8, 32), (2, 6, 40), (1, 3, 5), (3, 17, 70), (2, 64, 64)])
-def test_conv3x3_wrw_vs_oracle(cuda, shape):
-    _check(cuda, *shape)
+def test_conv3x3_wrw_vs_oracle(cuda, shape, variant):
+    _check(cuda, *shape, variant=variant)
 
 
 def test_conv3x3_wrw_layer1_size_and_determinism(cuda):
     """ResNet-18 layer1 geometry at BASELINE config 2 (256 x 256 maps; B = 4 keeps the fp64 oracle to seconds)."""
-    a = _check(cuda, 4, 256, 256, seed=5)
-    b = _check(cuda, 4, 256, 256, seed=5)
-    assert torch.equal(a, b)
+    for variant in ("tr", "v1"):
+        a = _check(cuda, 4, 256, 256, seed=5, variant=variant)
+        b = _check(cuda, 4, 256, 256, seed=5, variant=variant)
+        assert torch.equal(a, b), variant
 
 
 def test_wrw_conv_module_matches_stock_autocast(cuda):

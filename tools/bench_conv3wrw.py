@@ -24,9 +24,10 @@ def timeit(fn, n=30):
     return s.elapsed_time(e) / n * 1e3
 
 
-t = timeit(lambda: kp.conv3x3_wrw(x, dy))
 nbytes = (x.numel() + dy.numel()) * 2
-print("conv3x3 wrw ours   %.1f us  %.0f GB/s algorithmic" % (t, nbytes / t / 1e3))
+for variant in ("tr", "v1"):
+    t = timeit(lambda: kp.conv3x3_wrw(x, dy, variant=variant))
+    print("conv3x3 wrw ours (%s) %.1f us  %.0f GB/s algorithmic" % (variant, t, nbytes / t / 1e3))
 t2 = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                         [False, True, False]), 20)
 print("conv3x3 wrw MIOpen %.1f us (incl. its zero fill / cast)" % t2)

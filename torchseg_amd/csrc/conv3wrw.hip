@@ -155,6 +155,115 @@ __global__ __launch_bounds__(256) void conv3_wrw_k(const bf16_t* __restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------- variant 2: transposing LDS reads
+// Same GEMM, but the tiles stay pixel-major in LDS exactly as they come from HBM (16-byte copies, no unpacking)
+// and the K = pixel fragments are produced by gfx950's ds_read_b64_tr_b16.  Measured semantics
+// (tools/probes/tr_probe.hip): in a 16-lane group lane i contributes the 4 bf16 at its own 8-byte-aligned address,
+// S[i][0..3]; lane l receives S[4 j + (l >> 2)][l & 3], j = 0..3.  Pointing source lane 4 j + r at
+// (pixel k0 + j, channels c0 + 4 r ..) therefore hands lane 4 r + c the channel c0 + 4 r + c at pixels k0 .. k0 + 3:
+// two reads make one MFMA fragment, and a tap shift is a pixel offset (no alignment copies).
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef v4i16 __attribute__((address_space(3))) lds_v4i16;
+
+constexpr int T3_RBE = 96;                          // bf16 elements per pixel row in LDS: 64 channels + 32 pad (192 B:
+                                                    // two 16-lane groups of a transposing read hit 64 distinct banks)
+constexpr int T3_PC = W3_TW + 2;                    // 34 patch columns
+constexpr int T3_NPX = W3_PR * T3_PC;               // 204 patch pixels
+constexpr int T3_DY = W3_TH * W3_TW * T3_RBE;       // elements of the dy tile
+constexpr int T3_XU = (T3_NPX * 8 + 255) / 256;     // 7 x chunks (16 B) per thread
+constexpr size_t T3_LDS = (size_t)(T3_DY + T3_NPX * T3_RBE) * sizeof(bf16_t);   // 63,744 B
+
+__global__ __launch_bounds__(256) void conv3_wrw_tr_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                      float* __restrict__ part, W3Geom g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  bf16_t* dyL = reinterpret_cast<bf16_t*>(lds);       // [128 pixels][T3_RBE]
+  bf16_t* xL = dyL + T3_DY;                           // [204 pixels][T3_RBE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wh = wave & 1;            // oc half, ci half
+  const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
+
+  // staging: chunk = (pixel, 8-channel part); thread -> part tid & 7, pixel (tid >> 3) + 32 u
+  const int spart = tid & 7, spix = tid >> 3;
+  int xr[T3_XU], xc[T3_XU];                           // patch row / column of x chunk u (row < 0: none)
+#pragma unroll
+  for (int u = 0; u < T3_XU; ++u) {
+    const int pp = spix + 32 * u;
+    xr[u] = pp < T3_NPX ? pp / T3_PC : -1;
+    xc[u] = pp % T3_PC;
+  }
+  // fragment bases (elements): row offset of this lane's source pixel + its 4-channel group
+  const int fbase = (8 * half + (i16 >> 2)) * T3_RBE + 16 * sub + 4 * (i16 & 3);
+  const lds_v4i16* afr = (const lds_v4i16*)(dyL + fbase + 32 * wm);
+  const lds_v4i16* bfr = (const lds_v4i16*)(xL + fbase + 32 * wh);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  uint4 rd[W3_TH];
+  uint4 rx[T3_XU];
+  auto fetch = [&](int tile) {
+    const int ow0 = (tile % g.tiles_w) * W3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
+    const int b = tile / (g.tiles_w * g.tiles_h);
+    const int64_t org = (((int64_t)b * g.H + oh0) * g.W + ow0) * W3_C;
+    const bf16_t* dt = dy + org + (int64_t)spix * W3_C + spart * 8;
+#pragma unroll
+    for (int u = 0; u < W3_TH; ++u)
+      rd[u] = (oh0 + u < g.H && ow0 + spix < g.W) ? *reinterpret_cast<const uint4*>(dt + (int64_t)u * g.W * W3_C)
+                                                  : make_uint4(0, 0, 0, 0);
+    const bf16_t* xo = x + org + spart * 8;
+#pragma unroll
+    for (int u = 0; u < T3_XU; ++u) {
+      const int ih = oh0 - 1 + xr[u], iw = ow0 - 1 + xc[u];
+      rx[u] = (xr[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                  ? *reinterpret_cast<const uint4*>(xo + ((int64_t)(xr[u] - 1) * g.W + xc[u] - 1) * W3_C)
+                  : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < g.ntiles) fetch(tile);
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();                                  // the previous tile's fragment reads are done
+#pragma unroll
+    for (int u = 0; u < W3_TH; ++u)
+      *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = rd[u];
+#pragma unroll
+    for (int u = 0; u < T3_XU; ++u)
+      if (u < T3_XU - 1 || xr[u] >= 0)
+        *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = rx[u];
+    __syncthreads();
+    if (tile + (int)gridDim.x < g.ntiles) fetch(tile + gridDim.x);       // in flight during the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                  // 16 pixels: tile row ks >> 1, columns 16 (ks & 1) + 8 half ..
+      union { v4i16 q[2]; bf16x8 v; } fa;
+      fa.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
+      fa.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int px = ((ks >> 1) + kh) * T3_PC + (ks & 1) * 16 + kw;   // patch pixel of the fragment's first K
+          union { v4i16 q[2]; bf16x8 v; } fb;
+          fb.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 0) * (T3_RBE / 4)));
+          fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4) * (T3_RBE / 4)));
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
+        }
+    }
+  }
+  // acc[t][r]: oc = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, column = t * 64 + 32 wh + (lane & 31)
+  float* out = part + (int64_t)blockIdx.x * W3_C * W3_N;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[oc * W3_N + t * W3_C + 32 * wh + (lane & 31)] = acc[t][r];
+    }
+}
+
 // dw[flat] = sum over the per-block partials (fixed order, fp64); 64 consecutive entries per block
 __global__ __launch_bounds__(256) void conv3_wrw_fold(const float* __restrict__ part, int nparts, int64_t stride,
                                                       float* __restrict__ dw) {
@@ -193,8 +302,8 @@ int tsg_conv3x3_wrw_supported(int dtype, int Cin, int Cout, int kh, int kw, int 
 
 size_t tsg_conv3x3_wrw_ws_bytes(void) { return (size_t)W3_NPART * W3_C * W3_N * sizeof(float); }
 
-int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
-                    size_t ws_bytes, void* stream) {
+static int conv3_wrw_common(int variant, const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
+                            void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !ws) return TSG_E_NULL;
   if (B <= 0 || H <= 0 || W <= 0) return TSG_E_SHAPE;
   const int64_t th = (H + W3_TH - 1) / W3_TH, tw = (W + W3_TW - 1) / W3_TW;
@@ -207,12 +316,30 @@ int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t
   TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)W3_LDS));
   const int grid = g.ntiles < W3_NPART ? g.ntiles : W3_NPART;
-  hipLaunchKernelGGL(conv3_wrw_k, dim3(grid), dim3(256), W3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy, (float*)ws, g);
+  if (variant == 1) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_tr_k),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
+    hipLaunchKernelGGL(conv3_wrw_tr_k, dim3(grid), dim3(256), T3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (float*)ws, g);
+  } else {
+    hipLaunchKernelGGL(conv3_wrw_k, dim3(grid), dim3(256), W3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy, (float*)ws,
+                       g);
+  }
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv3_wrw_fold, dim3(W3_C * W3_N / 64), dim3(256), 0, st, (const float*)ws, grid,
                      (int64_t)W3_C * W3_N, dw);
   TSG_CHECK_LAUNCH();
   return 0;
+}
+
+int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
+                    size_t ws_bytes, void* stream) {
+  return conv3_wrw_common(0, x, dy, dw, B, H, W, ws, ws_bytes, stream);
+}
+
+int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
+                       size_t ws_bytes, void* stream) {
+  return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

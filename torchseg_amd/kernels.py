@@ -6,6 +6,7 @@ multi-process CPU tests can drive the same host logic with a stand-in provider
 that lives under tests/ — the package itself never falls back to anything.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -452,8 +453,12 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_wrw_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                        weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_wrw(self, x, dy):
-        """x, dy [B,64,H,W] bf16 channels_last -> dw fp32 [64,64,3,3] channels_last"""
+    def conv3x3_wrw(self, x, dy, variant=None):
+        """x, dy [B,64,H,W] bf16 channels_last -> dw fp32 [64,64,3,3] channels_last.
+        variant "tr" (default, TSG_CONV_WRW_IMPL) = transposing-LDS-read kernel, "v1" = transposed-staging kernel."""
+        if variant is None:
+            variant = os.environ.get("TSG_CONV_WRW_IMPL", "tr")
+        fn = self.lib.tsg_conv3x3_wrw_tr if variant == "tr" else self.lib.tsg_conv3x3_wrw
         for t in (x, dy):
             if not t.is_contiguous(memory_format=torch.channels_last) or t.dtype != torch.bfloat16:
                 raise ValueError("conv3x3_wrw expects bf16 channels_last tensors")
@@ -464,8 +469,8 @@ class HipKernels:
         ws = getattr(self, "_c3_ws", None)
         if ws is None or ws.device != x.device:
             ws = self._c3_ws = torch.empty(self.lib.tsg_conv3x3_wrw_ws_bytes(), dtype=torch.uint8, device=x.device)
-        L.check(self.lib.tsg_conv3x3_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
-                                         L.stream_ptr(x)), "tsg_conv3x3_wrw")
+        L.check(fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
+                "tsg_conv3x3_wrw")
         return dw
 
     # ---- evaluation metric ----------------------------------------------------
