@@ -4,7 +4,7 @@ The four `conv3x3(64, 64)` of layer1 (furnace/base_model/resnet.py:24-29,36-53) 
 activations of the context path ([16, 64, 256, 256] at BASELINE config 2).  MIOpen computes their
 weight gradient as a split-K implicit GEMM framed by a zero fill and a cast (244 µs each for
 268 MB of operands, tools/bench_conv3wrw.py); `tsg_conv3x3_wrw` streams the two operands once
-(154 µs, fp32 result instead of a bf16-rounded one).  Forward and the data
+(≈ 95–108 µs through the transposing LDS read, fp32 result instead of a bf16-rounded one).  Forward and the data
 gradient stay on MIOpen: the module is re-classed to `WrwConv2d`, whose autograd function calls
 `aten::convolution_backward` for dx only.
 
