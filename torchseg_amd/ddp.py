@@ -31,7 +31,8 @@ upsample overrides.  Controlled by env so train.py needs no edit:
                         but on MI355X streaming the bf16 logits at ~4-5 TB/s is as fast as re-interpolating them)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
   TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
-  TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw)
+  TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw;
+                        TSG_CONV_WRW_IMPL=tr|v1 picks the kernel variant, default tr)
 """
 import os
 
