@@ -69,6 +69,9 @@ int tsg_bn_stats(const void* x, int dtype, int layout,
  * Used before the cross-GPU all-reduce (syncbn.py:75 ReduceAddCoalesced). */
 int tsg_bn_collapse(const float* partial, int S, int64_t C, float* sums,
                     void* stream);
+/* The forward exchange message in one launch: msg[0..2C) as tsg_bn_collapse, msg[2C] = count / 4096,
+ * msg[2C+1] = count % 4096 (the local element count as two fp32 words that stay exact under SUM). */
+int tsg_bn_collapse_count(const float* partial, int S, int64_t C, float* msg, int64_t count, void* stream);
 
 /* Per-channel constants are folded into two small device arrays so the
  * streaming kernels touch 2-5 floats per channel:

@@ -30,10 +30,13 @@ class OracleProvider:
         part = torch.stack([x64.sum(self._axes(x)), (x64 * x64).sum(self._axes(x))]).float().unsqueeze(0)
         return part.contiguous(), 1
 
-    def bn_collapse(self, partial, S, C, out):
+    def bn_collapse(self, partial, S, C, out, count=None):
         s, q = self._sums(partial, S, C)
         out[:C].copy_(s.float())
         out[C:2 * C].copy_(q.float())
+        if count is not None:
+            out[2 * C] = float(count // 4096)
+            out[2 * C + 1] = float(count % 4096)
 
     def _pack(self, mean, invstd, gamma, beta):
         g = gamma if gamma is not None else torch.ones_like(mean)

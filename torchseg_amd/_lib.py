@@ -39,6 +39,7 @@ _PROTOS = {
     "tsg_bn_partial_ws_bytes": (_sz, [_i, _i64, _i64, _i64]),
     "tsg_bn_stats": (_i, [_p, _i, _i, _i64, _i64, _i64, _p, _ip, _p]),
     "tsg_bn_collapse": (_i, [_p, _i, _i64, _p, _p]),
+    "tsg_bn_collapse_count": (_i, [_p, _i, _i64, _p, _i64, _p]),
     "tsg_bn_finalize": (_i, [_p, _i, _i64, _d, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tsg_bn_affine": (_i, [_p, _p, _p, _p, _i64, _p, _p]),
     "tsg_bn_apply_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p]),

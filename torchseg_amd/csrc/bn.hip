@@ -604,7 +604,12 @@ __device__ __forceinline__ double bn_count(double count, const float* cd) {
 }
 
 __global__ __launch_bounds__(kTc * kTs) void bn_collapse_k(const float* __restrict__ partial, int S,
-                                                          int64_t C, float* __restrict__ sums) {
+                                                          int64_t C, float* __restrict__ sums, int with_count,
+                                                          float count_hi, float count_lo) {
+  if (with_count && blockIdx.x == 0 && threadIdx.x == 0) {      // the exactly summable element count of the message
+    sums[2 * C] = count_hi;
+    sums[2 * C + 1] = count_lo;
+  }
   double t1, t2; bool owner; int64_t c;
   tail_sums(partial, S, C, t1, t2, owner, c);
   if (!owner) return;
@@ -832,7 +837,16 @@ int tsg_bn_collapse(const float* partial, int S, int64_t C, float* sums, void* s
   if (!partial || !sums) return TSG_E_NULL;
   if (S <= 0 || C <= 0) return TSG_E_SHAPE;
   hipLaunchKernelGGL(bn_collapse_k, dim3(ceil_div_i(C, kTc)), dim3(kTc * kTs), 0, (hipStream_t)stream,
-                     partial, S, C, sums);
+                     partial, S, C, sums, 0, 0.f, 0.f);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_bn_collapse_count(const float* partial, int S, int64_t C, float* msg, int64_t count, void* stream) {
+  if (!partial || !msg) return TSG_E_NULL;
+  if (S <= 0 || C <= 0 || count < 0) return TSG_E_SHAPE;
+  hipLaunchKernelGGL(bn_collapse_k, dim3(ceil_div_i(C, kTc)), dim3(kTc * kTs), 0, (hipStream_t)stream,
+                     partial, S, C, msg, 1, (float)(count / 4096), (float)(count % 4096));
   TSG_CHECK_LAUNCH();
   return 0;
 }

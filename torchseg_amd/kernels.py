@@ -80,9 +80,14 @@ class HipKernels:
                                  partial.data_ptr(), C.byref(rows), L.stream_ptr(x)), "tsg_bn_stats")
         return partial, rows.value
 
-    def bn_collapse(self, partial, S, Cc, out):
-        L.check(self.lib.tsg_bn_collapse(partial.data_ptr(), S, Cc, out.data_ptr(),
-                                         L.stream_ptr(partial)), "tsg_bn_collapse")
+    def bn_collapse(self, partial, S, Cc, out, count=None):
+        """out[0:2C] = per-channel sums; with `count` also out[2C:2C+2] = the element count as two exact fp32 words"""
+        if count is None:
+            L.check(self.lib.tsg_bn_collapse(partial.data_ptr(), S, Cc, out.data_ptr(),
+                                             L.stream_ptr(partial)), "tsg_bn_collapse")
+        else:
+            L.check(self.lib.tsg_bn_collapse_count(partial.data_ptr(), S, Cc, out.data_ptr(), int(count),
+                                                   L.stream_ptr(partial)), "tsg_bn_collapse_count")
 
     def bn_finalize(self, partial, S, Cc, count, count_dev, eps, momentum, gamma, beta,
                     running_mean, running_var, nbt):

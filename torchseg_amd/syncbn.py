@@ -22,22 +22,10 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 from . import kernels as K
 
-_count_cache = {}
-
 # Set by the DDP wrapper when the model runs channels_last: an NCHW activation
 # (only conv stems produce one) then leaves the BN already converted to
 # channels_last through the mixed-layout kernels.
 PREFER_CHANNELS_LAST_OUTPUT = False
-
-
-def _count_words(n, device):
-    """Device tensor [n // 4096, n % 4096] (fp32): an exactly summable count."""
-    key = (n, device)
-    t = _count_cache.get(key)
-    if t is None:
-        t = torch.tensor([float(n // 4096), float(n % 4096)], dtype=torch.float32, device=device)
-        _count_cache[key] = t
-    return t
 
 
 def _world(group):
@@ -88,8 +76,7 @@ def _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world):
     momentum = 0.0 if mod.momentum is None else float(mod.momentum)
     if world > 1:
         msg = torch.empty(2 * C + 2, dtype=torch.float32, device=x.device)
-        kp.bn_collapse(partial, S, C, msg)
-        msg[2 * C:].copy_(_count_words(n_local, x.device))
+        kp.bn_collapse(partial, S, C, msg, count=n_local)      # sums and the exactly summable count in one launch
         dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
         count_dev = msg[2 * C:]
         _, invstd, fp = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum,
