@@ -108,44 +108,103 @@ class GraphedStep(object):
         return self.loss
 
 
-def cpu_baseline(size=512, batch=2, steps=1):
-    """The oracle (CPU port of the reference path: plain nn.BatchNorm2d + the
-    loss_opr restatement) timed on this host's cores.  Bounded sample: BASELINE
-    configs[0]'s shape (2 x 512 x 512); at the headline 1024 x 1024 one CPU step of
-    batch 2 takes ~2 minutes (measured 0.016 img/s on a 256-thread host), far beyond
-    the 10-30 s budget of this leg."""
+def _cpu_leg(size, batch, cores, budget_s, max_steps):
+    """img/s of the oracle network (1 untimed warm-up step, then steps until `budget_s` or `max_steps`)."""
     from oracle.ohem_ref import ProbOhemCrossEntropy2d as OracleOhem
-    from torchseg_amd.workloads import ensure_furnace_on_path
-    ensure_furnace_on_path()
     from engine.lr_policy import PolyLR
-    cores = min(os.cpu_count() or 1, 64)       # torch's CPU conv stops scaling (and oversubscribes) beyond this
-    torch.set_num_threads(cores)
     dev = torch.device("cpu")
     model, opt, base_lr = build_model(dev, batch, size, OracleOhem, nn.BatchNorm2d)
     model.train()
     imgs, gts = synthetic_batch(dev, batch, size)
     pol = PolyLR(base_lr, 0.9, 80000)
-    train_step(model, opt, imgs, gts, pol, 0, 1)                       # warm-up
+    train_step(model, opt, imgs, gts, pol, 0, 1)                       # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
     done = 0
-    while done < 5 and (done < steps or time.perf_counter() - t0 < 10.0):   # ~10-20 s of CPU work
+    while done < max_steps and (done < 1 or time.perf_counter() - t0 < budget_s):
         train_step(model, opt, imgs, gts, pol, done + 1, 1)
         done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(batch * done / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{done} steps (after 1 warm-up) of batch {batch} at {size}x{size} (BASELINE configs[0] shape), "
-                      f"fp32, torch CPU, oracle BiSeNet-R18 (nn.BatchNorm2d + loss_opr restatement)"}
+    return round(batch * done / dt, 3), done
+
+
+def cpu_baseline(headline=True):
+    """The oracle (CPU port of the reference path: the reference's BiSeNet-R18 architecture with plain
+    nn.BatchNorm2d + the loss_opr.py restatement + torch.optim.SGD, fp32) timed on this host's cores.  Bounded
+    sample, ~10-30 s of CPU work: `value` is the headline 1024 x 1024 shape with the batch reduced to 2 (batch 1
+    is not a legal training batch: the global-context BN sees [B,128,1,1]); BASELINE configs[0]'s own 2 x 512 x 512
+    shape is reported next to it.  The reference's train.py itself cannot run (apex, cv2, .next()), and
+    /root/reference does not exist on the GPU box, hence kind = "port"."""
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    cores = min(os.cpu_count() or 1, 64)       # torch's CPU conv stops scaling (and oversubscribes) beyond this
+    torch.set_num_threads(cores)
+    v512, n512 = _cpu_leg(512, 2, cores, 6.0, 5)
+    out = {"value": v512, "unit": "img/s", "cores": cores, "kind": "port",
+           "sample": f"{n512} steps (after 1 warm-up) of batch 2 at 512x512 (BASELINE configs[0] shape), fp32, "
+                     f"torch CPU, oracle BiSeNet-R18 (nn.BatchNorm2d + loss_opr restatement)"}
+    if headline:
+        v1024, n1024 = _cpu_leg(1024, 2, cores, 15.0, 3)
+        out = {"value": v1024, "unit": "img/s", "cores": cores, "kind": "port",
+               "sample": f"{n1024} steps (after 1 warm-up) of batch 2 at 1024x1024 (the headline crop of BASELINE "
+                         f"configs[1]; batch reduced from 16 to bound the sample), fp32, torch CPU, oracle "
+                         f"BiSeNet-R18 (nn.BatchNorm2d + loss_opr restatement + torch.optim.SGD)",
+               "configs0": {"value": v512, "unit": "img/s", "sample": out["sample"]}}
+    return out
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  Re-executes this file under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1, a free port) exactly as the driver's
+    multi-GPU command line does, and passes rank 0's JSON line through as the last line of stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank):
+    """--launch-check: rendezvous only (gloo when there is no GPU), so that the launcher logic is testable on a CPU
+    box: every rank joins, the world size is all-reduced, rank 0 prints it."""
+    backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, init_method="env://")
+    one = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(one)
+    n = dist.get_world_size()
+    ok = int(one.item()) == n
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": ok, "n_gpus": n, "backend": backend}), flush=True)
+    return 0 if ok else 1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # SURVEY 8(d): >= 20 warm-up + >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-headline", type=int, default=1,
+                    help="also time ONE CPU step at the headline 1024x1024 shape (batch 2; about a minute of host time)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous of --gpus N ranks only, no GPU work (CPU-testable)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("TSG_GRAPH", "0")),
                     help="EXPERIMENTAL: replay zero_grad+forward+backward from a hipGraph (default off)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
@@ -155,12 +214,15 @@ def main():
                     help="torch.backends.cudnn.benchmark (train.py:35); 0 = immediate mode on the shipped MIOpen find-db (same speed, 100 s faster start)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))             # plain `python bench.py --gpus N`
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        sys.exit(launch_check(world, rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's banner off stdout (one JSON line contract)
@@ -169,6 +231,8 @@ def main():
     use_shipped_miopen_db(rank=rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an AMD GPU (the HIP path has no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_coll = os.environ.get("TSG_FORCE_COLLECTIVES", "0") == "1"     # 1-rank run of the N>1 code path
@@ -258,6 +322,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    n_ranks = dist.get_world_size() if dist.is_initialized() else 1
+    assert n_ranks == world == args.gpus, (n_ranks, world, args.gpus)
 
     out = None
     if rank == 0:
@@ -265,7 +331,7 @@ def main():
         value = global_batch * args.steps / dt
         out = {
             "metric": "training images/sec (1024x1024) BiSeNet-R18",
-            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "img/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
@@ -289,7 +355,7 @@ def main():
                                     "achieved": round(per_gpu * gb_per_img, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(per_gpu * gb_per_img / HBM_PEAK_GBS, 4), "target_frac": 0.70}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(headline=bool(args.cpu_headline))
     if world > 1 or force_coll:
         dist.destroy_process_group()
     if rank == 0:
