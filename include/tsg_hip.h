@@ -249,8 +249,10 @@ int tsg_ohem_make_plan(int64_t B, int C, int64_t HW, float thresh,
 /* Forward.  Writes nll[P] (= lse - x_t, 0 for ignored pixels), lse[P],
  * loss[1] (fp32 mean over kept pixels, NaN when none) and
  * sel[8] = {thr (float bits), n_kept, num_valid, branch, denominator (float
- * bits), 0, 0, 0}; branch 0: thr == thresh, 1: thr == k-th smallest p_t,
- * 2: no hard-example mining applied (loss_opr.py:78-80, :85).
+ * bits), n_bad, 0, 0}; branch 0: thr == thresh, 1: thr == k-th smallest p_t,
+ * 2: no hard-example mining applied (loss_opr.py:78-80, :85).  n_bad counts labels that are neither
+ * ignore_label nor in [0, C): the reference device-asserts on them (prob[target], loss_opr.py:82-83); here they
+ * are dropped like ignored pixels, never used as an index, and reported so the host can raise.
  * min_kept / thresh / ignore_label as in loss_opr.py:49-56.
  * weight (class weights, loss_opr.py:57-63) may be NULL. */
 int tsg_ohem_fwd(const void* logits, int dtype, const void* labels, int ltype,
@@ -318,8 +320,8 @@ int tsg_focal_bwd(const void* pred, int dtype, const void* target, int ltype,
  * F.interpolate(..., mode='bilinear', align_corners=True) call sites
  * (bisenet network.py:82-84,93-94,164-166; pspnet network.py:46-49,103-105)
  * i.e. aten::upsample_bilinear2d / _backward.  x [NC, IH, IW] -> y [NC, OH, OW]
- * planar; `add` (may be NULL) is added to the result ("upsample+fuse",
- * bisenet network.py:91-95).
+ * planar; `add` (may be NULL, shaped like y) is added to the result (dfn
+ * network.py:130-133: `last_fm + F.interpolate(fm)`).
  * ---------------------------------------------------------------------- */
 int tsg_upsample_bilinear_ac_fwd(const void* x, const void* add, void* y,
                                  int dtype, int64_t NC, int IH, int IW,
@@ -335,6 +337,16 @@ int tsg_upsample_bilinear_ac_nhwc_fwd(const void* x, const void* add, void* y,
 int tsg_upsample_bilinear_ac_nhwc_bwd(const void* dy, void* dx, int dtype,
                                       int64_t N, int C, int IH, int IW,
                                       int OH, int OW, void* stream);
+/* "upsample+fuse" the way the reference orders it (bisenet network.py:91-95: `fm += last_fm`, then
+ * F.interpolate(fm, ...)): y = up(round_T(x + x2)), x2 shaped like x.  The sum is formed while the taps are read and
+ * never written to HBM; it is rounded to the element type exactly as the eager in-place add would have stored it.
+ * Backward: both addends receive tsg_upsample_bilinear_ac{,_nhwc}_bwd(dy). */
+int tsg_upsample_bilinear_ac_presum_fwd(const void* x, const void* x2, void* y,
+                                        int dtype, int64_t NC, int IH, int IW,
+                                        int OH, int OW, void* stream);
+int tsg_upsample_bilinear_ac_nhwc_presum_fwd(const void* x, const void* x2, void* y,
+                                             int dtype, int64_t N, int C, int IH, int IW,
+                                             int OH, int OW, void* stream);
 /* nearest (floor(dst*in/out)) variant used for label maps. */
 int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes,
                              int64_t NC, int IH, int IW, int OH, int OW,

@@ -104,3 +104,61 @@ class OracleProvider:
         d = self._mask(dy, x, y, bp, relu)
         dx = self._bc(bp[0], x) * d + self._bc(bp[3], x) * (x.float() - self._bc(bp[2], x)) + self._bc(bp[4], x)
         return dx.to(x.dtype), (d.to(x.dtype) if want_dres else None)
+
+    # ---- plain-CE / upsample stand-ins: only what tests/test_fusion_cpu.py needs to drive the HOST logic of
+    # torchseg_amd.fusion (pattern recognition, deferred values, autograd wiring) without a GPU ----------------
+    calls = None          # optional list: names of the provider methods that ran
+
+    def _note(self, name):
+        if self.calls is not None:
+            self.calls.append(name)
+
+    def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
+        assert min_kept == 0, "the CPU stand-in only implements the plain-CE mode"
+        self._note("ohem_fwd")
+        B, C = logits.shape[:2]
+        x = logits.double().reshape(B, C, -1)
+        lab = labels.reshape(B, -1).long()
+        valid = (lab != ignore_label) & (lab >= 0) & (lab < C)
+        n_bad = int(((lab != ignore_label) & ~valid).sum())
+        t = torch.where(valid, lab, torch.zeros_like(lab))
+        lse = torch.logsumexp(x, 1)
+        nll = (lse - x.gather(1, t.unsqueeze(1)).squeeze(1)) * valid
+        w = weight.double()[t] * valid if weight is not None else valid.double()
+        denom = w.sum()
+        loss = ((w * nll).sum() / denom).float().reshape(1)
+        sel = torch.zeros(8, dtype=torch.int32)
+        sel[1] = sel[2] = int(valid.sum())
+        sel[3] = 2
+        sel[4:5].view(torch.float32)[0] = float(denom)
+        sel[5] = n_bad
+        return loss, nll.float().reshape(-1), lse.float().reshape(-1), sel
+
+    def ohem_bwd(self, logits, labels, ignore_label, weight, nll, lse, sel, gscale):
+        self._note("ohem_bwd")
+        B, C = logits.shape[:2]
+        x = logits.double().reshape(B, C, -1)
+        lab = labels.reshape(B, -1).long()
+        valid = (lab != ignore_label) & (lab >= 0) & (lab < C)
+        t = torch.where(valid, lab, torch.zeros_like(lab))
+        p = torch.softmax(x, 1)
+        p.scatter_add_(1, t.unsqueeze(1), -torch.ones_like(p[:, :1]))
+        w = weight.double()[t] * valid if weight is not None else valid.double()
+        denom = float(sel[4:5].view(torch.float32)[0])
+        return (p * (w * float(gscale[0]) / denom).unsqueeze(1)).reshape(logits.shape).to(logits.dtype)
+
+    def upsample_presum_fwd(self, x, x2, OH, OW):
+        self._note("upsample_presum_fwd")
+        return torch.nn.functional.interpolate(x + x2, size=(OH, OW), mode="bilinear", align_corners=True)
+
+    def _up_bwd(self, dy, IH, IW):
+        N, C = dy.shape[:2]
+        return torch.ops.aten.upsample_bilinear2d_backward(dy, [dy.shape[2], dy.shape[3]], [N, C, IH, IW], True, None, None)
+
+    def upsample_bwd(self, dy, IH, IW):
+        self._note("upsample_bwd")
+        return self._up_bwd(dy, IH, IW)
+
+    def upsample_bwd_nhwc(self, dy, IH, IW):
+        self._note("upsample_bwd")
+        return self._up_bwd(dy, IH, IW)

@@ -61,8 +61,19 @@ def test_family_step_matches_cpu(cuda, kind):
     net = _build(kind, SyncBatchNorm, True)
     net.load_state_dict(ref.state_dict())
     net = DistributedDataParallel(net.to(cuda), compute_dtype=torch.float32)
-    if kind == "psanet":
-        assert net.fuse_psa, "PSANet must run its attention through tsg_psa_*"
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    calls = {"ohem_fwd": 0, "psa_fwd": 0}
+
+    def counted(name):
+        fn = getattr(kp, name)
+
+        def f(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return f
+    for name in calls:
+        setattr(kp, name, counted(name))
     stock = _build(kind, nn.BatchNorm2d, False)
     stock.load_state_dict(ref.state_dict())
     stock = stock.to(cuda)
@@ -70,8 +81,15 @@ def test_family_step_matches_cpu(cuda, kind):
     dbatch = [t.to(cuda) for t in batch]
     loss_ref = ref(*batch)
     loss_ref.backward()
-    loss = net(*dbatch)
-    loss.backward()
+    try:
+        loss = net(*dbatch)
+        loss.backward()
+    finally:
+        for name in calls:
+            delattr(kp, name)
+    # the plain nn.CrossEntropyLoss heads (a5) and the PSA contraction (a9) must have run on the HIP kernels
+    assert calls["ohem_fwd"] == (4 if kind == "dfn" else 2), calls
+    assert calls["psa_fwd"] == (2 if kind == "psanet" else 0), calls
     stock(*dbatch).backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())

@@ -1,0 +1,131 @@
+"""Host logic of torchseg_amd.fusion.FuseMode on CPU: which call patterns of the unchanged network.py files are
+recognised, that everything else sees ordinary tensors, and that autograd through the fused forms equals eager.
+The kernels are the tests/-only stand-in provider; the HIP kernels behind the same calls are covered by -m gpu."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def standin(monkeypatch):
+    from _cpu_provider import OracleProvider
+    from torchseg_amd import fusion, kernels as K
+    prov = OracleProvider()
+    prov.calls = []
+    old = K._set_provider_for_tests(prov)
+    monkeypatch.setattr(fusion, "_is_map", lambda t: isinstance(t, torch.Tensor) and t.dim() == 4
+                        and t.dtype in (torch.float32, torch.bfloat16))
+    monkeypatch.setattr(fusion, "_TARGET_ON_DEVICE", False)
+    yield prov
+    K._set_provider_for_tests(old)
+
+
+def _data(C=7, ignore=-1):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, C, 6, 5, generator=g)
+    y = torch.randint(0, C, (2, 6, 5), generator=g)
+    y[:, :2] = ignore
+    return x, y
+
+
+@pytest.mark.parametrize("via_log_softmax", [False, True])
+@pytest.mark.parametrize("ignore", [-1, 255])
+def test_plain_ce_heads_are_routed_to_the_kernels(standin, via_log_softmax, ignore):
+    """dfn train.py:48-49 (CE on logits) and pspnet network.py:50-56 (CE on log_softmax) both end in tsg_ohem_*."""
+    from torchseg_amd.fusion import FuseMode
+    x, y = _data(ignore=ignore)
+    crit = nn.CrossEntropyLoss(reduction='mean', ignore_index=ignore)
+    xr = x.clone().requires_grad_(True)
+    ref = crit(F.log_softmax(xr * 1.5, dim=1) if via_log_softmax else xr * 1.5, y)
+    ref.backward()
+    xf = x.clone().requires_grad_(True)
+    with FuseMode():
+        z = xf * 1.5
+        out = crit(F.log_softmax(z, dim=1) if via_log_softmax else z, y)
+    out.backward()
+    assert standin.calls == ["ohem_fwd", "ohem_bwd"]
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(xf.grad, xr.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_log_softmax_used_by_anything_else_is_the_real_tensor(standin):
+    from torchseg_amd.fusion import DeferredLogSoftmax, FuseMode, materialize
+    x, _ = _data()
+    xf = x.clone().requires_grad_(True)
+    with FuseMode():
+        z = F.log_softmax(xf * 1.0, dim=1)
+        assert isinstance(z, DeferredLogSoftmax)
+        e = torch.exp(z)                               # evaluator.py:263 does exp(log_softmax)
+        s = z.sum()
+    assert isinstance(e, torch.Tensor) and isinstance(s, torch.Tensor)
+    torch.testing.assert_close(e, torch.softmax(x, 1))
+    assert isinstance(materialize(z), torch.Tensor) and standin.calls == []
+    with FuseMode(), torch.no_grad():
+        assert isinstance(F.log_softmax(x, dim=1), torch.Tensor)       # eval path: not deferred at all
+
+
+def test_unsupported_ce_arguments_fall_through_to_torch(standin):
+    from torchseg_amd.fusion import FuseMode
+    x, y = _data(ignore=-100)
+    with FuseMode():
+        a = F.cross_entropy(x, y, reduction='sum')
+        b = F.cross_entropy(x, y, label_smoothing=0.1)
+    assert standin.calls == []
+    torch.testing.assert_close(a, F.cross_entropy(x, y, reduction='sum'))
+    torch.testing.assert_close(b, F.cross_entropy(x, y, label_smoothing=0.1))
+
+
+def test_iadd_then_interpolate_is_one_kernel(standin):
+    """bisenet network.py:91-95: fm = arm(fm); fm += last_fm; last_fm = F.interpolate(fm, ...)."""
+    from torchseg_amd.fusion import FuseMode
+    g = torch.Generator().manual_seed(1)
+    a0, b0 = torch.randn(2, 8, 4, 4, generator=g), torch.randn(2, 8, 4, 4, generator=g)
+
+    def run(fused):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        fm = a * 2.0
+        last = b * 1.0
+        fm += last
+        out = F.interpolate(fm, size=(8, 8), mode='bilinear', align_corners=True)
+        (out * out).sum().backward()
+        return out, a.grad, b.grad
+
+    ref = run(False)
+    with FuseMode():
+        got = run(True)
+    assert standin.calls == ["upsample_presum_fwd", "upsample_bwd"]
+    for r, o in zip(ref, got):
+        torch.testing.assert_close(o, r, rtol=1e-5, atol=1e-6)
+
+
+def test_iadd_followed_by_anything_else_is_an_ordinary_in_place_add(standin):
+    from torchseg_amd.fusion import DeferredSum, FuseMode
+    a = torch.ones(1, 8, 2, 2, requires_grad=True)
+    with FuseMode():
+        fm = a * 2.0
+        alias = fm
+        fm += torch.ones(1, 8, 2, 2)
+        assert isinstance(fm, DeferredSum)
+        out = F.relu(fm)                               # not interpolate -> the add happens, in place
+    assert standin.calls == []
+    assert torch.equal(out, torch.full((1, 8, 2, 2), 3.0)) and torch.equal(alias, out)
+    with FuseMode():                                   # leaves / no-grad tensors are never deferred
+        p = torch.zeros(1, 8, 2, 2)
+        p += 1
+        assert isinstance(p, torch.Tensor)
+
+
+def test_bad_labels_are_reported_not_indexed(standin, monkeypatch):
+    from torchseg_amd import losses
+    x, y = _data(C=7, ignore=255)
+    y[0, 3, 3] = 9                                     # neither ignore nor a class
+    loss, sel = losses.cross_entropy_2d(x, y, ignore_index=255, return_selection=True)
+    assert int(sel[5]) == 1 and torch.isfinite(loss)
+    with pytest.raises(Exception, match="neither ignore_label nor a class"):
+        losses.check_labels(sel)

@@ -120,3 +120,76 @@ def test_bilinear_channels_last(cuda, c, ih, iw, oh, ow, dtype):
     else:
         np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref, rtol=8e-3, atol=8e-3)
         np.testing.assert_allclose(xd.grad.float().cpu().numpy(), dx_ref, rtol=1e-2, atol=1e-2 * np.abs(dx_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("shape", [(2, 128, 32, 32, 64, 64), (2, 128, 64, 64, 128, 128), (1, 16, 5, 7, 13, 9)])
+def test_presum_upsample_matches_add_then_interpolate(cuda, dtype, channels_last, shape):
+    """SURVEY 8 row a8 as the reference orders it (bisenet network.py:91-95): `fm += last_fm` then F.interpolate.
+    Oracle: round_T(a + b) -> numpy bilinear; both addends get the transposed operator applied to dy."""
+    from torchseg_amd.fusion import upsample_presum
+    n, c, ih, iw, oh, ow = shape
+    g = torch.Generator().manual_seed(ih * ow)
+    a = torch.randn(n, c, ih, iw, generator=g).to(dtype)
+    b = torch.randn(n, c, ih, iw, generator=g).to(dtype)
+    dy = torch.randn(n, c, oh, ow, generator=g).to(dtype)
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    ad = a.to(cuda).contiguous(memory_format=fmt).requires_grad_(True)
+    bd = b.to(cuda).contiguous(memory_format=fmt).requires_grad_(True)
+    y = upsample_presum(ad, bd, size=(oh, ow))
+    assert y.is_contiguous(memory_format=fmt)
+    y.backward(dy.to(cuda).contiguous(memory_format=fmt))
+    s = (a.float() + b.float()).to(dtype).float().numpy()          # what the eager in-place add stores
+    y_ref = R.upsample_bilinear_ac(s, oh, ow)
+    d_ref = R.upsample_bilinear_ac_backward(dy.float().numpy(), ih, iw)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ad.grad.cpu().numpy(), d_ref, rtol=1e-4, atol=1e-4 * max(1.0, oh / ih))
+    else:
+        np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref, rtol=8e-3, atol=8e-3)
+        np.testing.assert_allclose(ad.grad.float().cpu().numpy(), d_ref, rtol=1e-2, atol=1e-2 * np.abs(d_ref).max())
+    assert torch.equal(ad.grad, bd.grad)
+
+
+def test_iadd_interpolate_pattern_is_fused_under_the_ddp_wrapper(cuda):
+    """An unchanged network.py's `fm += last_fm; F.interpolate(fm, ...)`: no aten add kernel, one presum launch,
+    numbers equal to eager on the CPU."""
+    import torch.nn as nn
+    from torchseg_amd import kernels as K
+    from torchseg_amd.ddp import DistributedDataParallel
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Conv2d(8, 8, 1)
+            self.c2 = nn.Conv2d(8, 8, 1)
+
+        def forward(self, x):
+            fm = self.c1(x)
+            last_fm = self.c2(x)
+            fm += last_fm
+            return F.interpolate(fm, size=(24, 24), mode='bilinear', align_corners=True).square().mean()
+
+    torch.manual_seed(2)
+    ref = Net()
+    net = Net()
+    net.load_state_dict(ref.state_dict())
+    net = DistributedDataParallel(net.to(cuda), compute_dtype=torch.float32, channels_last=False)
+    assert net.fuse_add_up
+    x = torch.randn(2, 8, 12, 12)
+    lr = ref(x)
+    lr.backward()
+    kp = K.provider()
+    calls = []
+    orig = kp.upsample_presum_fwd
+    kp.upsample_presum_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        l = net(x.to(cuda))
+        l.backward()
+    finally:
+        del kp.upsample_presum_fwd
+    assert calls == [1]
+    assert abs(l.item() - lr.item()) <= 1e-5 * max(1.0, abs(lr.item()))
+    for (n, p), (_, q) in zip(net.module.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-6, msg=n)

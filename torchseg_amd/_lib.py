@@ -87,6 +87,8 @@ _PROTOS = {
     "tsg_upsample_bilinear_ac_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_upsample_bilinear_ac_nhwc_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
     "tsg_upsample_bilinear_ac_nhwc_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
+    "tsg_upsample_bilinear_ac_presum_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "tsg_upsample_bilinear_ac_nhwc_presum_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
     "tsg_upsample_nearest_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
     "tsg_psa_ws_bytes": (_sz, [_i, _i, _i64, _i64, _i64, _i64]),
     "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),

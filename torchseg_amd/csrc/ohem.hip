@@ -40,14 +40,14 @@ struct SelState {
   int64_t krem;         // remaining 1-based rank inside the current prefix
   int64_t lo_d;         // lower bound of the current prefix in d-space
   uint32_t thr_bits;    // final threshold (float bits)
-  int32_t pad1;
+  int32_t n_bad;        // labels outside [0, C) other than ignore_label (the reference device-asserts on them)
   double sum;           // sum of w*nll over kept
   double wsum;          // sum of w over kept (denominator when weighted)
 };
 
 struct BlkPart {
   float sum_le, sum_valid, wsum_le, wsum_valid;
-  int32_t cnt_le_all, cnt_le_valid, cnt_valid, pad;
+  int32_t cnt_le_all, cnt_le_valid, cnt_valid, cnt_bad;  // cnt_bad: labels that are neither ignore_label nor in [0, C)
 };
 
 // ---- workspace carving ------------------------------------------------------
@@ -101,6 +101,14 @@ static void level_plan(int64_t range, int* levels, int* shift, int* bins) {
 
 __device__ __forceinline__ float prob_of_nll(float nll) { return expf(-nll); }
 
+// A label takes part in the loss iff it is not ignore_label AND names a class.  The reference indexes
+// prob[target] / weight[target] with it (loss_opr.py:82-83,98), which device-asserts on anything else; here such a
+// pixel is dropped like an ignored one and counted (sel[5]), so no kernel ever indexes weight[] / the class loop
+// with an unchecked value.
+__device__ __forceinline__ bool label_is_class(int64_t lab, int64_t ignore_label, int C) {
+  return lab != ignore_label && (uint64_t)lab < (uint64_t)C;
+}
+
 template <int LT> struct Lab;
 template <> struct Lab<TSG_I64> {
   typedef int64_t type;
@@ -124,7 +132,7 @@ template <typename T> struct PixVec<T, 1> {
 // prepared, see ohem_decide0) and their deterministic block fold
 struct PassAcc {
   float sum_le = 0.f, sum_valid = 0.f, wsum_le = 0.f, wsum_valid = 0.f;
-  int cnt_le_all = 0, cnt_le_valid = 0, cnt_valid = 0;
+  int cnt_le_all = 0, cnt_le_valid = 0, cnt_valid = 0, cnt_bad = 0;
 };
 
 __device__ __forceinline__ void account(PassAcc& a, bool valid, float nl, float w, float thresh,
@@ -146,7 +154,7 @@ __device__ __forceinline__ void account(PassAcc& a, bool valid, float nl, float 
 __device__ __forceinline__ void fold_block(PassAcc& a, const uint32_t* lh, int bins0,
                                            uint32_t* __restrict__ hist0, BlkPart* __restrict__ part) {
   __shared__ float fsm[4 * (kT / 64)];
-  __shared__ int ism[3 * (kT / 64)];
+  __shared__ int ism[4 * (kT / 64)];
   const int tid = threadIdx.x;
   __syncthreads();
   for (int i = tid; i < bins0; i += kT) {
@@ -156,10 +164,11 @@ __device__ __forceinline__ void fold_block(PassAcc& a, const uint32_t* lh, int b
   a.sum_le = wave_sum(a.sum_le); a.sum_valid = wave_sum(a.sum_valid);
   a.wsum_le = wave_sum(a.wsum_le); a.wsum_valid = wave_sum(a.wsum_valid);
   a.cnt_le_all = wave_sum(a.cnt_le_all); a.cnt_le_valid = wave_sum(a.cnt_le_valid); a.cnt_valid = wave_sum(a.cnt_valid);
+  a.cnt_bad = wave_sum(a.cnt_bad);
   const int lane = tid & 63, wv = tid >> 6;
   if (lane == 0) {
     fsm[wv * 4 + 0] = a.sum_le; fsm[wv * 4 + 1] = a.sum_valid; fsm[wv * 4 + 2] = a.wsum_le; fsm[wv * 4 + 3] = a.wsum_valid;
-    ism[wv * 3 + 0] = a.cnt_le_all; ism[wv * 3 + 1] = a.cnt_le_valid; ism[wv * 3 + 2] = a.cnt_valid;
+    ism[wv * 4 + 0] = a.cnt_le_all; ism[wv * 4 + 1] = a.cnt_le_valid; ism[wv * 4 + 2] = a.cnt_valid; ism[wv * 4 + 3] = a.cnt_bad;
   }
   __syncthreads();
   if (tid == 0) {
@@ -167,7 +176,7 @@ __device__ __forceinline__ void fold_block(PassAcc& a, const uint32_t* lh, int b
     for (int i = 0; i < kT / 64; ++i) {
       bp.sum_le += fsm[i * 4 + 0]; bp.sum_valid += fsm[i * 4 + 1];
       bp.wsum_le += fsm[i * 4 + 2]; bp.wsum_valid += fsm[i * 4 + 3];
-      bp.cnt_le_all += ism[i * 3 + 0]; bp.cnt_le_valid += ism[i * 3 + 1]; bp.cnt_valid += ism[i * 3 + 2];
+      bp.cnt_le_all += ism[i * 4 + 0]; bp.cnt_le_valid += ism[i * 4 + 1]; bp.cnt_valid += ism[i * 4 + 2]; bp.cnt_bad += ism[i * 4 + 3];
     }
     part[blockIdx.x] = bp;
   }
@@ -199,7 +208,8 @@ __global__ __launch_bounds__(kT) void ohem_pass_a(
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int64_t lab = Lab<LT>::get(labels, p0 + j);
-      valid[j] = lab != ignore_label;
+      valid[j] = label_is_class(lab, ignore_label, C);
+      if (!valid[j] && lab != ignore_label) acc.cnt_bad++;
       t[j] = valid[j] ? (int)lab : 0;  // loss_opr.py:72
     }
     float m[V], s[V], xt[V];
@@ -278,12 +288,17 @@ __global__ __launch_bounds__(kT) void ohem_decide0(
   __shared__ long long lsm[3][kT / 64];
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   long long c0 = 0, c1 = 0, c2 = 0;
+  int nbad = 0;
   // fixed assignment of partials to threads, fixed combine order => deterministic
   for (int i = threadIdx.x; i < grid; i += kT) {
     const BlkPart bp = part[i];
     a0 += bp.sum_le; a1 += bp.sum_valid; a2 += bp.wsum_le; a3 += bp.wsum_valid;
     c0 += bp.cnt_le_all; c1 += bp.cnt_le_valid; c2 += bp.cnt_valid;
+    nbad += bp.cnt_bad;
   }
+  if (threadIdx.x == 0) st->n_bad = 0;
+  __syncthreads();
+  if (nbad) atomicAdd(&st->n_bad, nbad);   // integer: order-independent
   a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
   c0 = (long long)wave_sum((double)c0); c1 = (long long)wave_sum((double)c1); c2 = (long long)wave_sum((double)c2);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -363,7 +378,7 @@ __global__ void sel_decide(const uint32_t* __restrict__ hist, int bins, int shif
 // pass C: re-sum nll over valid & p <= thr (k-th value branch only)
 template <int LT>
 __global__ __launch_bounds__(kT) void ohem_pass_c(
-    const float* __restrict__ nll, const void* __restrict__ labels, int64_t P,
+    const float* __restrict__ nll, const void* __restrict__ labels, int64_t P, int C,
     int64_t ignore_label, const float* __restrict__ weight, const SelState* __restrict__ st,
     float* __restrict__ csum, float* __restrict__ cwsum, int32_t* __restrict__ ccnt) {
   if (st->branch != 1) return;
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(kT) void ohem_pass_c(
   int cnt = 0;
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < P; i += (int64_t)gridDim.x * kT) {
     const int64_t lab = Lab<LT>::get(labels, i);
-    if (lab != ignore_label) {
+    if (label_is_class(lab, ignore_label, C)) {
       const float nl = nll[i];
       if (prob_of_nll(nl) <= thr) {
         const float w = weight ? weight[lab] : 1.f;
@@ -417,6 +432,7 @@ __global__ __launch_bounds__(kT) void ohem_finish(
     sel[1] = (int32_t)(st->n_kept > 0x7fffffffLL ? 0x7fffffff : st->n_kept);
     sel[2] = (int32_t)(st->num_valid > 0x7fffffffLL ? 0x7fffffff : st->num_valid);
     sel[3] = st->branch;
+    sel[5] = st->n_bad;
     // denominator as float for the backward pass
     reinterpret_cast<float*>(sel)[4] = (float)st->wsum;
   }
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(kT) void ohem_bwd_k(
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int64_t lab = Lab<LT>::get(labels, p0 + j);
-      const bool valid = lab != ignore_label;
+      const bool valid = label_is_class(lab, ignore_label, C);
       t[j] = valid ? (int)lab : -1;
       bool kept = valid;
       if (valid && branch != 2) kept = prob_of_nll(nll[p0 + j]) <= thr;
@@ -544,7 +560,9 @@ __global__ __launch_bounds__(kT) void ohem_up_pass_a(
       const int oy = band * kFwdBand + u;
       int64_t lab = ignore_label;
       if (oy < oy_end) lab = Lab<LT>::get(labels, (b * OH + oy) * (int64_t)OW + ox);
-      lab_s[u * kT + tid] = (lab != ignore_label) ? (uint8_t)lab : (uint8_t)255;
+      const bool is_cls = label_is_class(lab, ignore_label, C);
+      if (!is_cls && lab != ignore_label) acc.cnt_bad++;
+      lab_s[u * kT + tid] = is_cls ? (uint8_t)lab : (uint8_t)255;
     }
     for (int oy = band * kFwdBand; oy < oy_end; ++oy) {
       int y0, y1; float ly;
@@ -655,7 +673,7 @@ __global__ __launch_bounds__(kT) void ohem_up_bwd_v(
       const int64_t lab = in ? Lab<LT>::get(labels, gp) : ignore_label;
       const float nl = nll[gp];
       const float ls = lse[gp];
-      const bool valid = lab != ignore_label;
+      const bool valid = label_is_class(lab, ignore_label, C);
       bool kept = valid;
       if (valid && branch != 2) kept = prob_of_nll(nl) <= thr;
       coef_s[u * kT + tid] = kept ? g * (weight ? weight[lab] : 1.f) : 0.f;
@@ -781,10 +799,10 @@ static int ohem_select_tail(const tsg_ohem_plan& pl, OhemWs& w, const void* labe
     TSG_CHECK_LAUNCH();
   }
   if (ltype == TSG_I64)
-    hipLaunchKernelGGL((ohem_pass_c<TSG_I64>), dim3(pl.grid), dim3(kT), 0, st, nll, labels, pl.P,
+    hipLaunchKernelGGL((ohem_pass_c<TSG_I64>), dim3(pl.grid), dim3(kT), 0, st, nll, labels, pl.P, pl.C,
                        ignore_label, weight, w.st, w.csum, w.cwsum, w.ccnt);
   else
-    hipLaunchKernelGGL((ohem_pass_c<TSG_U8>), dim3(pl.grid), dim3(kT), 0, st, nll, labels, pl.P,
+    hipLaunchKernelGGL((ohem_pass_c<TSG_U8>), dim3(pl.grid), dim3(kT), 0, st, nll, labels, pl.P, pl.C,
                        ignore_label, weight, w.st, w.csum, w.cwsum, w.ccnt);
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(ohem_finish, dim3(1), dim3(kT), 0, st, w.csum, w.cwsum, w.ccnt, pl.grid,

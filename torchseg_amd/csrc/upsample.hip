@@ -28,13 +28,23 @@ template <typename T> struct OutVec<T, 1> {
   __device__ __forceinline__ void store(T* p) const { st1<T>(p, v[0]); }
 };
 
+// value of an element of type T nearest to v (what an eager `fm += last_fm` would have stored)
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// ADD modes of the forward kernels: 0 none; 1 `add` has the OUTPUT shape, y = up(x) + add (dfn network.py:130-133);
+// 2 `add` has the SOURCE shape, y = up(x + add) with the sum rounded to T exactly like the eager in-place add it
+// replaces (bisenet network.py:91-95: `fm += last_fm` then F.interpolate) -- the sum is never written to HBM.
+enum { kAddNone = 0, kAddOut = 1, kAddSrc = 2 };
+
 // Forward, separable form.  One thread owns V consecutive output columns and a
 // band of RB output rows.  H0/H1 hold the horizontally interpolated source rows
 // y0 / y1 for its columns; they are refreshed only when y0 advances (every
 // ~1/scale output rows), so the per-output work is 2 FMAs + the 16-B store:
 //   top = hx*x[y0][x0] + lx*x[y0][x1] ; bot = (same on y1) ; y = hy*top + ly*bot
 // (identical operations and order to the 4-tap formula above).
-template <typename T, int V, bool ADD, int RB>
+template <typename T, int V, int ADD, int RB>
 __global__ __launch_bounds__(kT) void up_fwd(const T* __restrict__ x, const T* __restrict__ add,
                                              T* __restrict__ y, int64_t NC, int IH, int IW, int OH,
                                              int OW, float sy, float sx) {
@@ -51,6 +61,10 @@ __global__ __launch_bounds__(kT) void up_fwd(const T* __restrict__ x, const T* _
 #pragma unroll
     for (int j = 0; j < V; ++j) src_index(sx, vx * V + j, IW, x0[j], x1[j], lx[j]);
     const T* src = x + nc * IH * (int64_t)IW;
+    const T* src2 = ADD == kAddSrc ? add + nc * IH * (int64_t)IW : nullptr;
+    auto tap = [&](int64_t off) -> float {
+      return ADD == kAddSrc ? round_as<T>(ld1<T>(src + off) + ld1<T>(src2 + off)) : ld1<T>(src + off);
+    };
     float h0[V], h1[V];
     int cy0 = -1, cy1 = -1;
     const int oy_end = (band + 1) * RB < OH ? (band + 1) * RB : OH;
@@ -62,9 +76,9 @@ __global__ __launch_bounds__(kT) void up_fwd(const T* __restrict__ x, const T* _
 #pragma unroll
           for (int j = 0; j < V; ++j) h0[j] = h1[j];
         } else {
-          const T* r = src + (int64_t)y0 * IW;
+          const int64_t r = (int64_t)y0 * IW;
 #pragma unroll
-          for (int j = 0; j < V; ++j) h0[j] = (1.f - lx[j]) * ld1<T>(r + x0[j]) + lx[j] * ld1<T>(r + x1[j]);
+          for (int j = 0; j < V; ++j) h0[j] = (1.f - lx[j]) * tap(r + x0[j]) + lx[j] * tap(r + x1[j]);
         }
         cy0 = y0;
         cy1 = -1;
@@ -74,20 +88,20 @@ __global__ __launch_bounds__(kT) void up_fwd(const T* __restrict__ x, const T* _
 #pragma unroll
           for (int j = 0; j < V; ++j) h1[j] = h0[j];
         } else {
-          const T* r = src + (int64_t)y1 * IW;
+          const int64_t r = (int64_t)y1 * IW;
 #pragma unroll
-          for (int j = 0; j < V; ++j) h1[j] = (1.f - lx[j]) * ld1<T>(r + x0[j]) + lx[j] * ld1<T>(r + x1[j]);
+          for (int j = 0; j < V; ++j) h1[j] = (1.f - lx[j]) * tap(r + x0[j]) + lx[j] * tap(r + x1[j]);
         }
         cy1 = y1;
       }
       const float hy = 1.f - ly;
       const int64_t ooff = (nc * OH + oy) * (int64_t)OW + (int64_t)vx * V;
       OutVec<T, V> o, a;
-      if (ADD) a.load(add + ooff);
+      if (ADD == kAddOut) a.load(add + ooff);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float v = hy * h0[j] + ly * h1[j];
-        if (ADD) v += a.v[j];
+        if (ADD == kAddOut) v += a.v[j];
         o.v[j] = v;
       }
       o.store(y + ooff);
@@ -250,7 +264,7 @@ __global__ void up_bwd_tiled(const T* __restrict__ dy, T* __restrict__ dx, int I
 // ---- channels_last (NHWC) variants for feature maps (C % V == 0) ---------------
 // A thread owns V adjacent channels of one pixel: every tap is one 16-byte load,
 // so neither direction needs LDS.  x [N, IH, IW, C] -> y [N, OH, OW, C].
-template <typename T, int V, bool ADD>
+template <typename T, int V, int ADD>
 __global__ __launch_bounds__(kT) void up_fwd_nhwc(const T* __restrict__ x, const T* __restrict__ add,
                                                   T* __restrict__ y, int64_t N, int C, int IH, int IW,
                                                   int OH, int OW, float sy, float sx) {
@@ -272,11 +286,24 @@ __global__ __launch_bounds__(kT) void up_fwd_nhwc(const T* __restrict__ x, const
     p01.load(b + ((int64_t)y0 * IW + x1) * C);
     p10.load(b + ((int64_t)y1 * IW + x0) * C);
     p11.load(b + ((int64_t)y1 * IW + x1) * C);
-    if (ADD) a.load(add + i * V);
+    if (ADD == kAddOut) a.load(add + i * V);
+    if (ADD == kAddSrc) {
+      const T* b2 = add + n * IH * (int64_t)IW * C + g * V;
+      OutVec<T, V> q00, q01, q10, q11;
+      q00.load(b2 + ((int64_t)y0 * IW + x0) * C);
+      q01.load(b2 + ((int64_t)y0 * IW + x1) * C);
+      q10.load(b2 + ((int64_t)y1 * IW + x0) * C);
+      q11.load(b2 + ((int64_t)y1 * IW + x1) * C);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        p00.v[j] = round_as<T>(p00.v[j] + q00.v[j]); p01.v[j] = round_as<T>(p01.v[j] + q01.v[j]);
+        p10.v[j] = round_as<T>(p10.v[j] + q10.v[j]); p11.v[j] = round_as<T>(p11.v[j] + q11.v[j]);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float v = hy * (hx * p00.v[j] + lx * p01.v[j]) + ly * (hx * p10.v[j] + lx * p11.v[j]);
-      if (ADD) v += a.v[j];
+      if (ADD == kAddOut) v += a.v[j];
       o.v[j] = v;
     }
     o.store(y + i * V);
@@ -354,29 +381,37 @@ using namespace tsg;
 
 extern "C" {
 
-int tsg_upsample_bilinear_ac_fwd(const void* x, const void* add, void* y, int dtype, int64_t NC,
-                                 int IH, int IW, int OH, int OW, void* stream) {
-  if (!x || !y) return TSG_E_NULL;
+static int up_fwd_launch(const void* x, const void* add, int add_mode, void* y, int dtype, int64_t NC,
+                         int IH, int IW, int OH, int OW, void* stream) {
+  if (!x || !y || (add_mode != kAddNone && !add)) return TSG_E_NULL;
   if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
   if (NC <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return TSG_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
   const int native = dtype == TSG_BF16 ? 8 : 4;
-  const bool vec = (OW % native == 0) && aligned16(y) && (!add || aligned16(add));
+  const bool vec = (OW % native == 0) && aligned16(y) && (add_mode != kAddOut || aligned16(add));
   const int V = vec ? native : 1;
   const int grid = grid_for(NC * ((OH + 15) / 16) * (int64_t)(OW / V));
 #define GO(T, VV, A) hipLaunchKernelGGL((up_fwd<T, VV, A, 16>), dim3(grid), dim3(kT), 0, st, (const T*)x, \
                                         (const T*)add, (T*)y, NC, IH, IW, OH, OW, sy, sx)
-  if (dtype == TSG_F32) {
-    if (vec) { if (add) GO(float, 4, true); else GO(float, 4, false); }
-    else     { if (add) GO(float, 1, true); else GO(float, 1, false); }
-  } else {
-    if (vec) { if (add) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); }
-    else     { if (add) GO(bf16_t, 1, true); else GO(bf16_t, 1, false); }
-  }
+#define GO3(T, VV) do { if (add_mode == kAddOut) GO(T, VV, kAddOut); else if (add_mode == kAddSrc) GO(T, VV, kAddSrc); \
+                        else GO(T, VV, kAddNone); } while (0)
+  if (dtype == TSG_F32) { if (vec) GO3(float, 4); else GO3(float, 1); }
+  else                  { if (vec) GO3(bf16_t, 8); else GO3(bf16_t, 1); }
+#undef GO3
 #undef GO
   TSG_CHECK_LAUNCH();
   return 0;
+}
+
+int tsg_upsample_bilinear_ac_fwd(const void* x, const void* add, void* y, int dtype, int64_t NC,
+                                 int IH, int IW, int OH, int OW, void* stream) {
+  return up_fwd_launch(x, add, add ? kAddOut : kAddNone, y, dtype, NC, IH, IW, OH, OW, stream);
+}
+
+int tsg_upsample_bilinear_ac_presum_fwd(const void* x, const void* x2, void* y, int dtype, int64_t NC,
+                                        int IH, int IW, int OH, int OW, void* stream) {
+  return up_fwd_launch(x, x2, kAddSrc, y, dtype, NC, IH, IW, OH, OW, stream);
 }
 
 int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype, int64_t NC, int IH, int IW,
@@ -426,9 +461,9 @@ int tsg_upsample_bilinear_ac_bwd(const void* dy, void* dx, int dtype, int64_t NC
   return 0;
 }
 
-int tsg_upsample_bilinear_ac_nhwc_fwd(const void* x, const void* add, void* y, int dtype, int64_t N,
-                                      int C, int IH, int IW, int OH, int OW, void* stream) {
-  if (!x || !y) return TSG_E_NULL;
+static int up_fwd_nhwc_launch(const void* x, const void* add, int add_mode, void* y, int dtype, int64_t N,
+                              int C, int IH, int IW, int OH, int OW, void* stream) {
+  if (!x || !y || (add_mode != kAddNone && !add)) return TSG_E_NULL;
   if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
   const int V = dtype == TSG_BF16 ? 8 : 4;
   if (N <= 0 || C <= 0 || C % V || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return TSG_E_SHAPE;
@@ -438,11 +473,23 @@ int tsg_upsample_bilinear_ac_nhwc_fwd(const void* x, const void* add, void* y, i
   const int grid = grid_for(N * OH * (int64_t)OW * (C / V));
 #define GO(T, VV, A) hipLaunchKernelGGL((up_fwd_nhwc<T, VV, A>), dim3(grid), dim3(kT), 0, st, (const T*)x, \
                                         (const T*)add, (T*)y, N, C, IH, IW, OH, OW, sy, sx)
-  if (dtype == TSG_F32) { if (add) GO(float, 4, true); else GO(float, 4, false); }
-  else { if (add) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); }
+#define GO3(T, VV) do { if (add_mode == kAddOut) GO(T, VV, kAddOut); else if (add_mode == kAddSrc) GO(T, VV, kAddSrc); \
+                        else GO(T, VV, kAddNone); } while (0)
+  if (dtype == TSG_F32) GO3(float, 4); else GO3(bf16_t, 8);
+#undef GO3
 #undef GO
   TSG_CHECK_LAUNCH();
   return 0;
+}
+
+int tsg_upsample_bilinear_ac_nhwc_fwd(const void* x, const void* add, void* y, int dtype, int64_t N,
+                                      int C, int IH, int IW, int OH, int OW, void* stream) {
+  return up_fwd_nhwc_launch(x, add, add ? kAddOut : kAddNone, y, dtype, N, C, IH, IW, OH, OW, stream);
+}
+
+int tsg_upsample_bilinear_ac_nhwc_presum_fwd(const void* x, const void* x2, void* y, int dtype, int64_t N,
+                                             int C, int IH, int IW, int OH, int OW, void* stream) {
+  return up_fwd_nhwc_launch(x, x2, kAddSrc, y, dtype, N, C, IH, IW, OH, OW, stream);
 }
 
 int tsg_upsample_bilinear_ac_nhwc_bwd(const void* dy, void* dx, int dtype, int64_t N, int C, int IH,

@@ -27,6 +27,9 @@ model in channels_last where MIOpen is faster on MI355X, and installs the aten
 upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_DTYPE=bf16|fp32   (default bf16 on GPU)    TSG_CHANNELS_LAST=1|0 (default 1 on GPU)
   TSG_FUSE_PSA=1|0      (default: on when the model has a PointwiseSpatialAttention block)
+  TSG_FUSE_LOSS=1|0     (default 1 on GPU: nn.CrossEntropyLoss / F.cross_entropy heads, also behind F.log_softmax, run
+                        on tsg_ohem_* in plain-CE mode; fusion.py)
+  TSG_FUSE_ADD_UP=1|0   (default 1 on GPU: `fm += last_fm` followed by F.interpolate is one kernel; fusion.py)
   TSG_FUSE_HEAD=1|0     (default 0: F.interpolate(x >= 4) feeding our criterion is fused into it; parity-tested,
                         but on MI355X streaming the bf16 logits at ~4-5 TB/s is as fast as re-interpolating them)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
@@ -269,12 +272,17 @@ class DistributedDataParallel(nn.Module):
             apply_channels_last(self.module)
             from . import syncbn
             syncbn.PREFER_CHANNELS_LAST_OUTPUT = True
+        # An unchanged reference network.py reaches the fused operators through fusion.FuseMode; our own workload
+        # builders call them directly and say so (`tsg_native_fusions`), which spares them the mode's Python dispatch.
+        native = bool(getattr(module, "tsg_native_fusions", False))
         self.fuse_psa = False
+        self.fuse_loss = self.on_gpu and _env_flag("TSG_FUSE_LOSS", not native)
+        self.fuse_add_up = self.on_gpu and _env_flag("TSG_FUSE_ADD_UP", not native)
         if self.on_gpu:
             from .upsample import install_aten_overrides
             install_aten_overrides()
             from .psa import model_has_psa
-            self.fuse_psa = _env_flag("TSG_FUSE_PSA", model_has_psa(module))
+            self.fuse_psa = _env_flag("TSG_FUSE_PSA", model_has_psa(module) and not native)
             if _env_flag("TSG_FUSE_HEAD", False):
                 from .upsample import install_deferred_interpolate
                 install_deferred_interpolate()
@@ -302,7 +310,8 @@ class DistributedDataParallel(nn.Module):
         with contextlib.ExitStack() as stack:
             if self.on_gpu and self.compute_dtype != torch.float32:
                 stack.enter_context(torch.autocast("cuda", dtype=self.compute_dtype))
-            if self.fuse_psa:
-                from .psa import FusePsaMode
-                stack.enter_context(FusePsaMode())
+            if self.fuse_psa or self.fuse_loss or self.fuse_add_up:
+                from .fusion import FuseMode, materialize
+                stack.enter_context(FuseMode(psa=self.fuse_psa, loss=self.fuse_loss, add_up=self.fuse_add_up))
+                return materialize(self.module(*inputs, **kwargs))
             return self.module(*inputs, **kwargs)

@@ -1,0 +1,192 @@
+"""The TorchFunctionMode our DistributedDataParallel wrapper enters around an UNCHANGED network.py
+forward (SURVEY.md 8b "the one choke point we own").  The reference's model files call ATen directly, so
+the operator fusions of the hot path have to be recognised at the torch-function level:
+
+  * a5  `nn.CrossEntropyLoss(ignore_index=...)` / `F.cross_entropy` on [B,C,H,W] logits (dfn train.py:48-49,
+        network.py:140-143) and the same criterion applied to `F.log_softmax(x, dim=1)` (pspnet / psanet
+        network.py:50-56) -> the OHEM kernels in plain-CE mode (`tsg_ohem_fwd/bwd`, min_kept = 0).  CE of a
+        log-softmaxed input equals CE of the logits (log_softmax is idempotent), so the deferred log_softmax is
+        never evaluated on the training path: the full-resolution logits are read once forward, once backward.
+  * a8  `fm += last_fm` followed by `F.interpolate(fm, ..., 'bilinear', align_corners=True)` (bisenet
+        network.py:91-95) -> one upsample kernel that sums the two maps while it reads the taps
+        (`tsg_upsample_bilinear_ac*_presum_fwd`); and `last_fm + F.interpolate(fm)` (dfn network.py:130-133)
+        stays `tsg_upsample_bilinear_ac*_fwd(x, add)`.
+  * a9  `torch.bmm(x, torch.softmax(a, dim=1))` (psanet network.py:125-126,135-136) -> `tsg_psa_*` (psa.py).
+
+Every deferred value materialises itself (with the eager semantics, including the in-place update of `fm`) the
+moment anything other than its fusing consumer touches it, so code outside the recognised patterns is unaffected.
+"""
+import torch
+import torch.nn.functional as F
+from torch.overrides import TorchFunctionMode
+
+from . import kernels as K
+
+_FLOATS = (torch.float32, torch.bfloat16)
+_TARGET_ON_DEVICE = True      # tests/ flip this (together with _is_map) to drive the host logic on CPU
+
+
+class _Deferred(object):
+    """A value that has not been computed yet; any torch function applied to it computes it first."""
+
+    _value = None
+
+    def materialize(self):
+        raise NotImplementedError
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return func(*_unwrap(args), **_unwrap(kwargs or {}))
+
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+
+def _unwrap(v):
+    if isinstance(v, _Deferred):
+        return v.materialize()
+    if isinstance(v, (list, tuple)):
+        return type(v)(_unwrap(u) for u in v)
+    if isinstance(v, dict):
+        return {k: _unwrap(u) for k, u in v.items()}
+    return v
+
+
+def materialize(v):
+    """Public form of _unwrap (the DDP wrapper applies it to whatever the wrapped forward returns)."""
+    from .psa import _DeferredColSoftmax
+    from .upsample import DeferredUpsample
+    if isinstance(v, (_DeferredColSoftmax, DeferredUpsample)):
+        return v.materialize()
+    if isinstance(v, (list, tuple)):
+        return type(v)(materialize(u) for u in v)
+    return _unwrap(v)
+
+
+class DeferredLogSoftmax(_Deferred):
+    """F.log_softmax(x, dim=1) of a [B,C,H,W] tensor, pending."""
+
+    def __init__(self, x):
+        self.x = x
+
+    def materialize(self):
+        if self._value is None:
+            self._value = torch._log_softmax(self.x, 1, False) if self.x.dtype == torch.float32 \
+                else torch.log_softmax(self.x, 1)
+        return self._value
+
+
+class DeferredSum(_Deferred):
+    """`a += b` of two same-shaped [N,C,H,W] maps, pending.  Materialising performs the in-place add on `a`."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self.a.add_(self.b)
+        return self._value
+
+
+class _PresumUpFn(torch.autograd.Function):
+    """up(a + b); both addends get the same gradient (one gather kernel)."""
+
+    @staticmethod
+    def forward(ctx, a, b, OH, OW):
+        from .upsample import _is_cl_dense, _vec_ok
+        ctx.in_hw = (a.shape[2], a.shape[3])
+        if _is_cl_dense(a) and _vec_ok(a):
+            b = b.contiguous(memory_format=torch.channels_last)
+        else:
+            a, b = a.contiguous(), b.contiguous()
+        return K.provider().upsample_presum_fwd(a, b, OH, OW)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .upsample import _backward_any_layout
+        d = _backward_any_layout(dy, *ctx.in_hw)
+        return d, d, None, None
+
+
+def upsample_presum(a, b, size=None, scale_factor=None):
+    """F.interpolate(a + b, bilinear, align_corners=True) without materialising the sum (a8)."""
+    from .upsample import _out_size
+    OH, OW = _out_size(a, size, scale_factor)
+    return _PresumUpFn.apply(a, b, OH, OW)
+
+
+def _is_map(t):
+    return isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 4 and t.dtype in _FLOATS
+
+
+_LOG_SOFTMAX_FUNCS = (F.log_softmax, torch.log_softmax, torch.Tensor.log_softmax)
+_IADD_FUNCS = (torch.Tensor.__iadd__, torch.Tensor.add_)
+_ADD_FUNCS = (torch.Tensor.__add__, torch.Tensor.__radd__, torch.Tensor.add, torch.add)
+
+
+def _ce_args(args, kwargs):
+    """Normalised (input, target, weight, ignore_index) of an F.cross_entropy / F.nll_loss call, or None when the
+    call uses something the kernels do not implement (then the stock op runs, on materialised inputs)."""
+    names = ("input", "target", "weight", "size_average", "ignore_index", "reduce", "reduction", "label_smoothing")
+    a = dict(zip(names, args))
+    a.update(kwargs)
+    if a.get("size_average") is not None or a.get("reduce") is not None or a.get("reduction", "mean") != "mean":
+        return None
+    if a.get("label_smoothing", 0.0) != 0.0:
+        return None
+    inp, tgt, w = a.get("input"), a.get("target"), a.get("weight")
+    x = inp.x if isinstance(inp, DeferredLogSoftmax) else inp
+    if not _is_map(x) or not isinstance(tgt, torch.Tensor) or tgt.dim() != 3 or (_TARGET_ON_DEVICE and not tgt.is_cuda):
+        return None
+    if tgt.dtype not in (torch.int64, torch.uint8) or tuple(tgt.shape) != (x.shape[0], x.shape[2], x.shape[3]):
+        return None
+    if w is not None and (not isinstance(w, torch.Tensor) or w.numel() != x.shape[1]):
+        return None
+    return x, tgt, w, int(a.get("ignore_index", -100))
+
+
+class FuseMode(TorchFunctionMode):
+    """See the module docstring.  `psa`: defer column softmaxes for the PSA contraction; `loss`: plain CE heads on
+    the HIP kernels; `add_up`: `+=` -> interpolate fusion."""
+
+    def __init__(self, psa=False, loss=True, add_up=True):
+        super().__init__()
+        self.psa, self.loss, self.add_up = bool(psa), bool(loss), bool(add_up)
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if self.psa:
+            from .psa import _SOFTMAX_FUNCS, _DeferredColSoftmax
+            if func in _SOFTMAX_FUNCS and args and isinstance(args[0], torch.Tensor):
+                dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
+                a = args[0]
+                if dim == 1 and a.dim() == 3 and a.is_cuda and kwargs.get("dtype") is None and a.dtype in _FLOATS:
+                    return _DeferredColSoftmax(a)
+        if self.loss:
+            if func in _LOG_SOFTMAX_FUNCS and args and _is_map(args[0]) and torch.is_grad_enabled() \
+                    and args[0].requires_grad:
+                dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
+                if dim == 1 and kwargs.get("dtype") is None:
+                    return DeferredLogSoftmax(args[0])
+            if func is F.cross_entropy or (func is F.nll_loss and args and isinstance(args[0], DeferredLogSoftmax)):
+                ce = _ce_args(args, kwargs)
+                if ce is not None:
+                    from .losses import cross_entropy_2d
+                    x, tgt, w, ignore = ce
+                    return cross_entropy_2d(x, tgt, ignore_index=ignore, weight=w)
+        if self.add_up:
+            if func in _IADD_FUNCS and len(args) == 2 and not kwargs and _is_map(args[0]) and _is_map(args[1]) \
+                    and args[0].shape == args[1].shape and args[0].dtype == args[1].dtype \
+                    and args[0].grad_fn is not None and torch.is_grad_enabled():
+                return DeferredSum(args[0], args[1])
+            if func is F.interpolate and args and isinstance(args[0], DeferredSum):
+                s = args[0]
+                if s._value is None and kwargs.get("mode") == "bilinear" and kwargs.get("align_corners") \
+                        and not kwargs.get("antialias", False):
+                    return upsample_presum(s.a, s.b, size=kwargs.get("size"), scale_factor=kwargs.get("scale_factor"))
+        return func(*args, **kwargs)

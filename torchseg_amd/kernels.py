@@ -374,6 +374,25 @@ class HipKernels:
                                                       L.stream_ptr(x)), "tsg_upsample_bilinear_ac_fwd")
         return y
 
+    def upsample_presum_fwd(self, x, x2, OH, OW):
+        """up(x + x2) for two same-shaped tensors, both NCHW-contiguous or both channels_last-dense"""
+        N, Cc, IH, IW = x.shape
+        if x2.shape != x.shape or x2.dtype != x.dtype or x2.stride() != x.stride():
+            raise L.TsgError("upsample_presum_fwd: the two addends must share shape, dtype and strides")
+        if x.is_contiguous():
+            y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device)
+            L.check(self.lib.tsg_upsample_bilinear_ac_presum_fwd(x.data_ptr(), x2.data_ptr(), y.data_ptr(),
+                                                                 L.dtype_code(x), N * Cc, IH, IW, OH, OW,
+                                                                 L.stream_ptr(x)), "tsg_upsample_bilinear_ac_presum_fwd")
+            return y
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            raise L.TsgError("upsample_presum_fwd: dense NCHW or channels_last tensors only")
+        y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_upsample_bilinear_ac_nhwc_presum_fwd(x.data_ptr(), x2.data_ptr(), y.data_ptr(),
+                                                                  L.dtype_code(x), N, Cc, IH, IW, OH, OW,
+                                                                  L.stream_ptr(x)), "tsg_upsample_bilinear_ac_nhwc_presum_fwd")
+        return y
+
     def upsample_bwd(self, dy, IH, IW):
         _require_contiguous(dy)
         N, Cc, OH, OW = dy.shape
@@ -575,6 +594,7 @@ _ALGO_BYTES = {
     "ohem_up_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "ohem_up_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "upsample_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
+    "upsample_presum_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "upsample_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "upsample_fwd_nhwc": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "upsample_bwd_nhwc": lambda a, r: _nbytes(a[0]) + _nbytes(r),

@@ -89,6 +89,60 @@ def ohem_cross_entropy(pred, target, ignore_label=255, thresh=0.7, min_kept=0, w
     return (loss, sel) if return_selection else loss
 
 
+def check_labels(sel, what="labels"):
+    """Raise if the last criterion call saw labels that are neither the ignore value nor a class index (sel[5],
+    see tsg_ohem_fwd).  The reference device-asserts in that situation; this check synchronises, so the criteria call
+    it only under TSG_CHECK_LABELS=1 (or call it yourself once per epoch on `criterion.last_selection`)."""
+    n_bad = int(sel[5].item())
+    if n_bad:
+        raise K.L.TsgError(f"{what}: {n_bad} label values are neither ignore_label nor a class index in [0, C)")
+
+
+def _maybe_check_labels(sel):
+    import os
+    if os.environ.get("TSG_CHECK_LABELS", "0") == "1":
+        check_labels(sel)
+
+
+def cross_entropy_2d(pred, target, ignore_index=-100, weight=None, return_selection=False):
+    """`F.cross_entropy(pred, target, weight, ignore_index=, reduction='mean')` for pred [B,C,H,W] / target [B,H,W]
+    on the OHEM kernels in plain-CE mode (min_kept = 0 => branch 2 of tsg_ohem_fwd: every non-ignored pixel is
+    kept; SURVEY.md 8 row a5).  One read of the logits forward, one read + one write backward, fp32 accumulation;
+    mean over the non-ignored pixels (weighted mean with `weight`), NaN when there are none, like torch."""
+    if weight is not None:
+        weight = weight.to(device=pred.device, dtype=torch.float32).contiguous()
+    out = ohem_cross_entropy(pred, target, ignore_label=ignore_index, thresh=1.0, min_kept=0, weight=weight,
+                             return_selection=True)
+    _maybe_check_labels(out[1])
+    return out if return_selection else out[0]
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """Drop-in for the `nn.CrossEntropyLoss(reduction='mean', ignore_index=...)` the reference builds for its plain
+    heads (dfn train.py:48-49; pspnet / psanet train.py:48-49) on HIP tensors.  The unchanged train.py keeps
+    constructing nn.CrossEntropyLoss: torchseg_amd.fusion.FuseMode routes that call here as well."""
+
+    def __init__(self, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction='mean',
+                 label_smoothing=0.0):
+        super().__init__()
+        if size_average is not None or reduce is not None or reduction != 'mean' or label_smoothing != 0.0:
+            raise NotImplementedError("only reduction='mean' without label smoothing (the reference's only use)")
+        self.ignore_index = int(ignore_index)
+        if weight is not None:
+            self.register_buffer("weight", torch.as_tensor(weight, dtype=torch.float32))
+        else:
+            self.weight = None
+        self.last_selection = None
+
+    def forward(self, pred, target):
+        from .fusion import DeferredLogSoftmax
+        if isinstance(pred, DeferredLogSoftmax):
+            pred = pred.x                        # CE(log_softmax(x)) == CE(x)
+        loss, sel = cross_entropy_2d(pred, target, self.ignore_index, self.weight, return_selection=True)
+        self.last_selection = sel
+        return loss
+
+
 class ProbOhemCrossEntropy2d(nn.Module):
     """Drop-in for seg_opr.loss_opr.ProbOhemCrossEntropy2d (loss_opr.py:48-98).
 
@@ -119,6 +173,7 @@ class ProbOhemCrossEntropy2d(nn.Module):
         loss, sel = ohem_cross_entropy(pred, target, self.ignore_label, self.thresh, self.min_kept,
                                        w, return_selection=True)
         self.last_selection = sel
+        _maybe_check_labels(sel)
         return loss
 
 

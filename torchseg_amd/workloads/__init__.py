@@ -12,3 +12,42 @@ def ensure_furnace_on_path():
     """What the reference's config.py:49-54 does with <TorchSeg>/furnace."""
     if _FURNACE not in sys.path:
         sys.path.insert(0, _FURNACE)
+
+
+# ---- the fusions of torchseg_amd/fusion.py, called explicitly -----------------------------------------------
+# An UNCHANGED reference network.py gets them through the TorchFunctionMode our DDP wrapper enters; the builders in
+# this package mark themselves `tsg_native_fusions = True` and call the fused operators directly on HIP tensors,
+# which keeps ~2 us of Python dispatch per torch call out of the benchmarked step.  On CPU tensors (the oracle
+# network of the parity tests and of bench.py's cpu_baseline) they are literally the reference's statements.
+
+def add_then_upsample(fm, last_fm, size):
+    """bisenet network.py:92-94: `fm += last_fm; F.interpolate(fm, size, 'bilinear', align_corners=True)`."""
+    if fm.is_cuda:
+        from ..fusion import upsample_presum
+        return upsample_presum(fm, last_fm, size=size)
+    import torch.nn.functional as F
+    fm += last_fm
+    return F.interpolate(fm, size=size, mode='bilinear', align_corners=True)
+
+
+def head_loss(criterion, logits, label, log_softmax=False):
+    """`criterion(logits, label)` (dfn network.py:140-143) or `criterion(F.log_softmax(logits, 1), label)` (pspnet /
+    psanet network.py:50-56).  A plain nn.CrossEntropyLoss on HIP logits runs on the CE kernels straight from the
+    logits (CE(log_softmax(x)) == CE(x)); anything else is evaluated as written."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    if (logits.is_cuda and type(criterion) is nn.CrossEntropyLoss and criterion.reduction == 'mean'
+            and criterion.label_smoothing == 0.0 and logits.dim() == 4):
+        from ..losses import cross_entropy_2d
+        return cross_entropy_2d(logits, label, ignore_index=criterion.ignore_index, weight=criterion.weight)
+    return criterion(F.log_softmax(logits, dim=1) if log_softmax else logits, label)
+
+
+def softmax_bmm(x, a):
+    """psanet network.py:125-126: torch.bmm(x, torch.softmax(a, dim=1))."""
+    import torch
+    if x.is_cuda:
+        from ..psa import psa_attention, psa_supported
+        if psa_supported(x, a):
+            return psa_attention(x, a)
+    return torch.bmm(x, torch.softmax(a, dim=1))

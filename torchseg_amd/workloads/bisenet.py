@@ -10,7 +10,7 @@ initialises both identically (tests/test_dropin_cpu.py checks both).
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ensure_furnace_on_path
+from . import add_then_upsample, ensure_furnace_on_path
 
 ensure_furnace_on_path()
 from base_model import resnet18  # noqa: E402
@@ -56,6 +56,8 @@ class BiSeNetHead(nn.Module):
 
 
 class BiSeNet(nn.Module):
+    tsg_native_fusions = True      # calls the fused operators itself (workloads/__init__.py)
+
     def __init__(self, out_planes, is_training, criterion, pretrained_model=None,
                  norm_layer=nn.BatchNorm2d, bn_eps=1e-5, bn_momentum=0.1):
         super(BiSeNet, self).__init__()
@@ -87,9 +89,7 @@ class BiSeNet(nn.Module):
         last_fm = _up(self.global_context(c5), size=c5.shape[2:])
         outs = []
         for fm, nxt, arm, refine in zip((c5, c4), (c4, c3), self.arms, self.refines):
-            fm = arm(fm)
-            fm = fm + last_fm
-            last_fm = refine(_up(fm, size=nxt.shape[2:]))
+            last_fm = refine(add_then_upsample(arm(fm), last_fm, nxt.shape[2:]))   # network.py:91-95
             outs.append(last_fm)
         outs.append(self.ffm(spatial_out, last_fm))
         return outs

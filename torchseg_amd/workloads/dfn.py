@@ -7,7 +7,7 @@ parameters (border_aft_rrbs.0.*) are never used in forward."""
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ensure_furnace_on_path
+from . import ensure_furnace_on_path, head_loss
 
 ensure_furnace_on_path()
 from base_model import resnet101  # noqa: E402
@@ -30,6 +30,8 @@ class DFNHead(nn.Module):
 
 
 class DFN(nn.Module):
+    tsg_native_fusions = True      # calls the fused operators itself (workloads/__init__.py)
+
     def __init__(self, out_planes, criterion, aux_criterion, alpha, pretrained_model=None,
                  norm_layer=nn.BatchNorm2d, bn_eps=1e-5, bn_momentum=0.1, backbone=resnet101):
         super(DFN, self).__init__()
@@ -83,12 +85,16 @@ class DFN(nn.Module):
                                                      self.border_heads)):
             fm = pre(fm)
             if last_fm is not None:
-                last_fm = aft(last_fm + _up(fm, scale=2 ** i))
+                if fm.is_cuda:            # dfn network.py:130-133 as one kernel: up(fm) + last_fm
+                    from ..upsample import upsample_bilinear_ac
+                    last_fm = aft(upsample_bilinear_ac(fm, scale_factor=2 ** i, add=last_fm))
+                else:
+                    last_fm = aft(last_fm + _up(fm, scale=2 ** i))
             else:
                 last_fm = fm
             border_out.append(head(last_fm))
         if label is not None and aux_label is not None:
-            loss = sum(self.criterion(p, label) for p in pred_out)
+            loss = sum(head_loss(self.criterion, p, label) for p in pred_out)       # network.py:140-143
             aux = sum(self.aux_criterion(b, aux_label) for b in border_out)
             return loss + self.alpha * aux                                      # network.py:150-152
         return F.log_softmax(pred_out[-1], dim=1)

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ensure_furnace_on_path
+from . import ensure_furnace_on_path, head_loss, softmax_bmm
 
 ensure_furnace_on_path()
 from base_model import resnet50, resnet101  # noqa: E402
@@ -80,7 +80,7 @@ class PointwiseSpatialAttention(nn.Module):
         rx = reduction(x)
         a = attention(rx)
         b, c, h, w = a.size()
-        fm = torch.bmm(rx.view(b, self.inner_channel, -1), torch.softmax(a.view(b, c, -1), dim=1))
+        fm = softmax_bmm(rx.view(b, self.inner_channel, -1), a.view(b, c, -1))     # network.py:125-126
         return fm.view(b, self.inner_channel, h, w)
 
     def forward(self, x):
@@ -91,6 +91,8 @@ class PointwiseSpatialAttention(nn.Module):
 
 
 class _DilatedSegNet(nn.Module):
+    tsg_native_fusions = True      # calls the fused operators itself (workloads/__init__.py)
+
     def __init__(self, out_planes, criterion, backbone, head_cls, head_attr, pretrained_model=None,
                  norm_layer=nn.BatchNorm2d, bn_eps=1e-5, bn_momentum=0.1):
         super(_DilatedSegNet, self).__init__()
@@ -108,11 +110,11 @@ class _DilatedSegNet(nn.Module):
 
     def forward(self, data, label=None):
         blocks = self.backbone(data)
-        fm = F.log_softmax(_up(getattr(self, self._head_attr)(blocks[-1]), scale=8), dim=1)
-        aux = F.log_softmax(_up(self.aux_layer(blocks[-2]), scale=8), dim=1)
-        if label is not None:
-            return self.criterion(fm, label) + 0.4 * self.criterion(aux, label)   # network.py:53-57
-        return fm
+        fm = _up(getattr(self, self._head_attr)(blocks[-1]), scale=8)
+        if label is not None:                                                     # network.py:46-57
+            aux = _up(self.aux_layer(blocks[-2]), scale=8)
+            return head_loss(self.criterion, fm, label, True) + 0.4 * head_loss(self.criterion, aux, label, True)
+        return F.log_softmax(fm, dim=1)
 
 
 def PSPNet(out_planes, criterion, pretrained_model=None, norm_layer=nn.BatchNorm2d, depth=50, **kw):
