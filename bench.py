@@ -357,6 +357,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(headline=bool(args.cpu_headline))
     if world > 1 or force_coll:
+        from torchseg_amd import comm as tsg_comm
+        tsg_comm.shutdown()
         dist.destroy_process_group()
     if rank == 0:
         # RCCL writes its version banner through C stdio, which is block-buffered when stdout is a

@@ -39,6 +39,8 @@ enum { TSG_I64 = 0, TSG_U8 = 1 };
 #define TSG_E_ALIGN   (-4)
 #define TSG_E_NULL    (-5)
 #define TSG_E_WS      (-6)
+#define TSG_E_COMM_LIB   (-7)    /* librccl.so missing or lacking a symbol */
+#define TSG_E_COMM_BASE  (-100)  /* RCCL failure r is reported as TSG_E_COMM_BASE - r (tsg_comm_error_string) */
 
 int tsg_version(void);
 
@@ -425,6 +427,51 @@ int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* grads, const 
  * train.py:98-99).  Same block map as tsg_sgd_multi_step_dev (tsg_sgd_multi_blockmap). */
 int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* numel, int nseg,
                        const int* blockmap_dev, int64_t nblocks, float scale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Collectives of the hot path — replace the exchange steps of the reference's SyncBN / DDP:
+ * furnace/legacy/sync_bn/syncbn.py:75-78 (ReduceAddCoalesced / Broadcast of [sum x, sum x^2]),
+ * furnace/legacy/sync_bn/comm.py:57-132 (the master/slave pipes carrying them), and the
+ * torch.distributed all_reduce / all_gather / broadcast calls inside apex.parallel.SyncBatchNorm /
+ * DistributedDataParallel (train.py:24-25,98-99).
+ *
+ * A tsg_comm is the one piece of state the library holds: an RCCL communicator (one rank per GPU) plus,
+ * optionally, peer-mapped mailboxes for the one-shot small-message all-reduce.  Every collective is enqueued on
+ * the CALLER's stream (no internal stream, no host synchronisation), in place, SUM.  librccl.so is resolved with
+ * dlopen at first use — the copy the host framework already loaded if there is one.
+ * ---------------------------------------------------------------------- */
+typedef struct tsg_comm tsg_comm;
+
+/* Optional: load librccl from an explicit path (NULL = default search). */
+int tsg_comm_init_library(const char* librccl_path);
+/* Bootstrap: rank 0 fills `id_out` (tsg_comm_unique_id_bytes() bytes) and hands it to the other ranks by any
+ * means (the Python host uses the torch.distributed store); every rank then calls tsg_comm_create with it.
+ * unique_id == NULL creates a communicator WITHOUT RCCL, usable only for the mailbox path below. */
+int tsg_comm_unique_id_bytes(void);
+int tsg_comm_get_unique_id(void* id_out);
+int tsg_comm_create(const void* unique_id, int rank, int world, int device, tsg_comm** out);
+int tsg_comm_destroy(tsg_comm* c);
+int tsg_comm_rank(const tsg_comm* c);
+int tsg_comm_world(const tsg_comm* c);
+/* buf[count] <- sum over ranks (dtype TSG_F32 / TSG_BF16). */
+int tsg_comm_allreduce(tsg_comm* c, void* buf, int64_t count, int dtype, void* stream);
+/* recv[world * count_per_rank] <- concatenation of every rank's send[count_per_rank]. */
+int tsg_comm_allgather(tsg_comm* c, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream);
+/* buf[count] <- root's buf (parameter broadcast at wrap time, apex DDP). */
+int tsg_comm_broadcast(tsg_comm* c, void* buf, int64_t count, int dtype, int root, void* stream);
+const char* tsg_comm_error_string(int code);
+
+/* One-shot all-reduce for the SyncBN statistics messages (2C+2 floats, 105-390 per step):
+ * every rank stores its vector straight into every peer's mailbox over xGMI, flags it, waits for the peers' flags
+ * and sums the world slots in rank order — one kernel on the compute stream, one hop of latency, bit-identical
+ * results on all ranks.  Setup: each rank calls tsg_comm_xgmi_export (allocates its mailbox for messages of up to
+ * max_floats and returns an IPC handle of tsg_comm_xgmi_handle_bytes() bytes), the handles are all-gathered in rank
+ * order by the host, then tsg_comm_xgmi_attach maps the peers.  tsg_xgmi_small_allreduce uses the mailboxes when they
+ * are attached and count fits; otherwise it is ncclAllReduce on the same stream. */
+size_t tsg_comm_xgmi_handle_bytes(void);
+int tsg_comm_xgmi_export(tsg_comm* c, int64_t max_floats, void* handle_out);
+int tsg_comm_xgmi_attach(tsg_comm* c, const void* all_handles);
+int tsg_xgmi_small_allreduce(tsg_comm* c, float* buf, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -62,3 +62,30 @@ def test_product_path_refuses_cpu_tensors():
         SyncBatchNorm(4)(torch.randn(2, 4, 3, 3))
     with pytest.raises(Exception):
         ProbOhemCrossEntropy2d(255, thresh=0.7, min_kept=1)(torch.randn(1, 3, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+
+
+def test_comm_entry_points_without_gpu():
+    """tsg_comm_*: librccl resolves at run time, argument validation happens before any RCCL call, and RCCL failures
+    come back in their own error range with RCCL's message (no GPU here: no communicator can exist)."""
+    import torch  # noqa: F401  (puts the framework's librccl.so into the process, the copy the library must reuse)
+    from torchseg_amd import _lib
+    lib = _lib.lib()
+    assert lib.tsg_comm_init_library(None) == 0
+    assert lib.tsg_comm_unique_id_bytes() == 128
+    assert lib.tsg_comm_xgmi_handle_bytes() == 64
+    assert lib.tsg_comm_get_unique_id(None) == -5
+    h = ctypes.c_void_p()
+    assert lib.tsg_comm_create(None, 0, 0, 0, ctypes.byref(h)) == -3          # world < 1
+    assert lib.tsg_comm_create(None, 2, 2, 0, ctypes.byref(h)) == -3          # rank >= world
+    assert lib.tsg_comm_allreduce(None, None, 4, 0, None) == -5
+    assert lib.tsg_comm_allgather(None, None, None, 4, 0, None) == -5
+    assert lib.tsg_comm_broadcast(None, None, 4, 0, 0, None) == -5
+    assert lib.tsg_xgmi_small_allreduce(None, None, 4, None) == -5
+    assert b"librccl" in lib.tsg_comm_error_string(-7)
+    if not torch.cuda.is_available():
+        buf = ctypes.create_string_buffer(128)
+        rc = lib.tsg_comm_get_unique_id(buf)
+        assert rc <= -100 and len(lib.tsg_comm_error_string(rc)) > 0
+        import pytest
+        with pytest.raises(_lib.TsgError, match="RCCL error"):
+            _lib.check(rc, "tsg_comm_get_unique_id")

@@ -1,0 +1,129 @@
+"""GPU tests of the tsg_comm_* C-ABI (RCCL on the caller's stream) and of the one-shot mailbox all-reduce.
+
+Only 1-GPU boxes exist for these tests, so: (1) the RCCL entry points run on a 1-rank communicator bootstrapped
+exactly like the N-rank one (unique id through the torch.distributed store), on a non-default stream; (2) the
+mailbox protocol (peer stores, flags, parity double-buffering, rank-ordered sum) runs between TWO PROCESSES that
+share the one GPU through hipIpc handles, which exercises everything except the xGMI wire itself."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rccl_worker(port, q):
+    try:
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        from torchseg_amd import comm
+        c = comm.get(None, like=torch.empty(1, device="cuda"))
+        assert c is not None and c.world == 1 and c.has_rccl
+        side = torch.cuda.Stream()
+        x = torch.arange(1030, dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(side):
+            y = x * 2                                   # producer on the side stream ...
+            c.all_reduce(y)                             # ... collective on the same stream, no handshake
+            c.small_all_reduce(y)
+            c.broadcast(y, 0)
+            out = torch.empty_like(y)
+            c.all_gather(y, out)
+            z = out + 1                                 # ... consumer
+            b = torch.ones(64, dtype=torch.bfloat16, device="cuda")
+            c.all_reduce(b)
+        side.synchronize()
+        ok = torch.equal(z, x * 2 + 1) and torch.equal(b.float(), torch.ones(64, device="cuda"))
+        comm.shutdown()
+        dist.destroy_process_group()
+        q.put(("ok" if ok else "wrong values", None))
+    except Exception as e:                               # noqa: BLE001
+        import traceback
+        q.put(("exc", traceback.format_exc()))
+
+
+def test_rccl_entry_points_on_the_callers_stream(cuda):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, info = q.get(timeout=240)
+    p.join(60)
+    assert status == "ok", info
+
+
+def _mailbox_worker(rank, world, port, q, iters):
+    try:
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)       # bootstrap only
+        from torchseg_amd.comm import Comm
+        c = Comm(None, device=0, rccl=False, xgmi=True)
+        assert c.one_shot
+        g = torch.Generator().manual_seed(123)                             # same stream of test vectors on every rank
+        results = []
+        for it in range(iters):
+            n = [2 * 64 + 2, 2 * 128 + 2, 2 * 512 + 2, 5, 2 * 2048 + 2][it % 5]
+            base = torch.randn(world, n, generator=g)
+            mine = base[rank].clone().cuda()
+            c.small_all_reduce(mine)
+            if it % 7 == 0:
+                torch.cuda.synchronize()                                   # ranks drift apart in between
+            results.append((mine, base))
+        torch.cuda.synchronize()
+        bad = 0
+        outs = []
+        for mine, base in results:
+            ref = base[0].clone()
+            for r in range(1, world):
+                ref += base[r]                                             # rank order, fp32: bit-exact expectation
+            bad += int(not torch.equal(mine.cpu(), ref))
+            outs.append(mine.cpu())
+        digest = torch.cat(outs).view(torch.int32).sum(dtype=torch.int64).item()
+        dist.barrier()
+        c.destroy()
+        dist.destroy_process_group()
+        q.put((rank, bad, digest, None))
+    except Exception:                                                      # noqa: BLE001
+        import traceback
+        q.put((rank, -1, 0, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_shot_mailbox_allreduce_between_processes_sharing_the_gpu(cuda, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mailbox_worker, args=(r, world, port, q, 200)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=300))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    for rank, bad, digest, info in res:
+        assert bad == 0, (rank, bad, info)
+    assert len({d for _, _, d, _ in res}) == 1           # every rank holds bit-identical sums

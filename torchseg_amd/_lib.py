@@ -15,7 +15,8 @@ NCHW, NHWC = 0, 1
 I64, U8 = 0, 1
 
 _ERR = {-1: "unsupported dtype", -2: "unsupported layout", -3: "bad shape",
-        -4: "misaligned pointer", -5: "null pointer", -6: "workspace too small"}
+        -4: "misaligned pointer", -5: "null pointer", -6: "workspace too small",
+        -7: "librccl.so could not be loaded"}
 
 
 class TsgError(RuntimeError):
@@ -93,6 +94,21 @@ _PROTOS = {
     "tsg_psa_ws_bytes": (_sz, [_i, _i, _i64, _i64, _i64, _i64]),
     "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_psa_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_comm_init_library": (_i, [C.c_char_p]),
+    "tsg_comm_unique_id_bytes": (_i, []),
+    "tsg_comm_get_unique_id": (_i, [_p]),
+    "tsg_comm_create": (_i, [_p, _i, _i, _i, C.POINTER(_p)]),
+    "tsg_comm_destroy": (_i, [_p]),
+    "tsg_comm_rank": (_i, [_p]),
+    "tsg_comm_world": (_i, [_p]),
+    "tsg_comm_allreduce": (_i, [_p, _p, _i64, _i, _p]),
+    "tsg_comm_allgather": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "tsg_comm_broadcast": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "tsg_comm_error_string": (C.c_char_p, [_i]),
+    "tsg_comm_xgmi_handle_bytes": (_sz, []),
+    "tsg_comm_xgmi_export": (_i, [_p, _i64, _p]),
+    "tsg_comm_xgmi_attach": (_i, [_p, _p]),
+    "tsg_xgmi_small_allreduce": (_i, [_p, _p, _i64, _p]),
     "tsg_sgd_step_dev": (_i, [_p, _p, _p, _i64, _p, _f, _f, _f, _f, _p]),
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
 }
@@ -122,6 +138,8 @@ def lib():
 def check(rc, what):
     if rc == 0:
         return
+    if rc <= -100:
+        raise TsgError(f"{what}: RCCL error {-100 - rc} ({lib().tsg_comm_error_string(rc).decode()})")
     if rc < 0:
         raise TsgError(f"{what}: invalid argument ({_ERR.get(rc, rc)})")
     raise TsgError(f"{what}: hipError_t {rc}")

@@ -40,6 +40,17 @@ def _world(group):
     return 1
 
 
+def _exchange(msg, group):
+    """All-reduce(SUM) of a statistics message across the ranks of `group`: on HIP tensors one tsg_comm call on the
+    compute stream (RCCL, or the one-shot xGMI mailbox kernel), on CPU tensors torch.distributed (gloo tests)."""
+    from . import comm
+    c = comm.get(group, like=msg)
+    if c is not None:
+        c.small_all_reduce(msg)
+    else:
+        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+
+
 def _dense(x):
     """Return (x_dense, layout tuple): copies only when x is neither NCHW- nor NHWC-dense."""
     lay = K.bn_layout(x)
@@ -77,7 +88,7 @@ def _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world):
     if world > 1:
         msg = torch.empty(2 * C + 2, dtype=torch.float32, device=x.device)
         kp.bn_collapse(partial, S, C, msg, count=n_local)      # sums and the exactly summable count in one launch
-        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+        _exchange(msg, group)
         count_dev = msg[2 * C:]
         _, invstd, fp = kp.bn_finalize(msg, 1, C, 0.0, count_dev, float(mod.eps), momentum,
                                        gamma, beta, rm, rv, nbt)
@@ -93,7 +104,7 @@ def _backward_pack(kp, partial, S, C, n_local, invstd, fp, count_dev, use_batch_
         sums = torch.empty(2 * C, dtype=torch.float32, device=device)
         kp.bn_collapse(partial, S, C, sums)
         dgamma, dbeta, _ = kp.bn_bwd_coeffs(sums, 1, C, 1.0, None, True, invstd, fp, True, False)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        _exchange(sums, group)
         _, _, bp = kp.bn_bwd_coeffs(sums, 1, C, 0.0, count_dev, True, invstd, fp, False, True)
         return dgamma, dbeta, bp
     return kp.bn_bwd_coeffs(partial, S, C, float(n_local), None, use_batch_stats, invstd, fp, True, True)
