@@ -84,8 +84,12 @@ def test_comm_entry_points_without_gpu():
     assert b"librccl" in lib.tsg_comm_error_string(-7)
     if not torch.cuda.is_available():
         buf = ctypes.create_string_buffer(128)
-        rc = lib.tsg_comm_get_unique_id(buf)
-        assert rc <= -100 and len(lib.tsg_comm_error_string(rc)) > 0
-        import pytest
-        with pytest.raises(_lib.TsgError, match="RCCL error"):
-            _lib.check(rc, "tsg_comm_get_unique_id")
+        rc = lib.tsg_comm_get_unique_id(buf)        # RCCL builds differ: some hand out an id without a device
+        assert rc == 0 or rc <= -100
+        if rc:
+            import pytest
+            assert len(lib.tsg_comm_error_string(rc)) > 0
+            with pytest.raises(_lib.TsgError, match="RCCL error"):
+                _lib.check(rc, "tsg_comm_get_unique_id")
+        else:
+            assert any(buf.raw)
