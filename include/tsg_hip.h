@@ -297,6 +297,12 @@ int tsg_ohem_up_bwd(const void* z, int dtype, const void* labels, int ltype,
                     const float* gscale, void* dz,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* prob[P] = the target-class probability the selection ranks (mask_prob of loss_opr.py:81-83): exp(-nll) evaluated
+ * by the same device expression the OHEM kernels use, 1 for ignored pixels.  With it the selection contract is
+ * checkable bit for bit: thr == sort(prob)[k-1] and kept == valid & (prob <= thr). */
+int tsg_ohem_target_prob(const float* nll, const void* labels, int ltype, int64_t P, int C,
+                         int64_t ignore_label, float* prob, void* stream);
+
 /* Exact k-th order statistic of non-negative floats by radix select on their
  * IEEE bit patterns — what torch.sort(mask_prob)[k-1] returns
  * (loss_opr.py:86-88).  out[0] receives the value.  k is 1-based. */

@@ -165,3 +165,23 @@ def test_ddp_bucket_gather_multi_tensor_copy(cuda):
         # the slots hold the gradients in the parameters' memory order
         off = bucket.offsets[1]
         assert torch.equal(bucket.flat[off:off + params[1].numel()], grads[1].permute(0, 2, 3, 1).reshape(-1))
+    # the averaging factor (1 / world) travels with the copy: fresh gradients are scaled while gathered, gradients
+    # accumulated in place in the views (zero_grad(set_to_none=False)) are scaled in place, holes stay zero
+    fresh = [torch.randn(*p.shape, generator=g).to(cuda) for p in params]
+    fresh[1] = fresh[1].contiguous(memory_format=torch.channels_last)
+    for i, p in enumerate(params):
+        if i == 4:
+            p.grad, bucket.ready[i] = None, False
+        elif i == 3:
+            p.grad.copy_(fresh[i])                       # stays the bucket view: accumulated in place
+            bucket.ready[i] = True
+        else:
+            p.grad, bucket.ready[i] = fresh[i].clone(memory_format=torch.preserve_format), True
+    Reducer._gather(bucket, 0.125)
+    torch.cuda.synchronize()
+    for i, p in enumerate(params):
+        if i == 4:
+            assert float(bucket.views[i].abs().sum()) == 0.0
+        else:
+            assert p.grad.data_ptr() == bucket.views[i].data_ptr()
+            assert torch.equal(p.grad, fresh[i] * 0.125)     # power-of-two scale: exact

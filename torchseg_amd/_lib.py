@@ -79,6 +79,7 @@ _PROTOS = {
     "tsg_ohem_up_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _i, _i, _i, _i, _i64, _f, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tsg_ohem_up_bwd_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "tsg_ohem_up_bwd": (_i, [_p, _i, _p, _i, _i64, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "tsg_ohem_target_prob": (_i, [_p, _p, _i, _i64, _i, _i64, _p, _p]),
     "tsg_kth_ws_bytes": (_sz, [_i64]),
     "tsg_kth_value": (_i, [_p, _i64, _i64, _p, _p, _sz, _p]),
     "tsg_focal_ws_bytes": (_sz, [_i64]),

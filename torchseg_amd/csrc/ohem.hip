@@ -811,6 +811,15 @@ static int ohem_select_tail(const tsg_ohem_plan& pl, OhemWs& w, const void* labe
   return 0;
 }
 
+// mask_prob of loss_opr.py:81-83 as the selection kernels see it: the target-class probability recomputed from
+// nll with the SAME device expression (prob_of_nll), 1 for pixels that take no part.
+template <int LT>
+__global__ __launch_bounds__(kT) void target_prob_k(const float* __restrict__ nll, const void* __restrict__ labels,
+                                                    int64_t P, int C, int64_t ignore_label, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < P; i += (int64_t)gridDim.x * kT)
+    out[i] = label_is_class(Lab<LT>::get(labels, i), ignore_label, C) ? prob_of_nll(nll[i]) : 1.f;
+}
+
 extern "C" {
 
 int tsg_ohem_make_plan(int64_t B, int C, int64_t HW, float thresh, tsg_ohem_plan* plan) {
@@ -999,6 +1008,20 @@ __global__ void kth_init(SelState* st, int64_t k) {
   st->branch = 1; st->krem = k; st->lo_d = 0;
 }
 __global__ void kth_out(const SelState* st, float* out) { out[0] = __uint_as_float(st->thr_bits); }
+
+int tsg_ohem_target_prob(const float* nll, const void* labels, int ltype, int64_t P, int C, int64_t ignore_label,
+                         float* prob, void* stream) {
+  if (!nll || !labels || !prob) return TSG_E_NULL;
+  if (P <= 0 || C <= 0) return TSG_E_SHAPE;
+  if (ltype != TSG_I64 && ltype != TSG_U8) return TSG_E_DTYPE;
+  const int grid = (int)((P + kT - 1) / kT < 4096 ? (P + kT - 1) / kT : 4096);
+  if (ltype == TSG_I64)
+    hipLaunchKernelGGL((target_prob_k<TSG_I64>), dim3(grid), dim3(kT), 0, (hipStream_t)stream, nll, labels, P, C, ignore_label, prob);
+  else
+    hipLaunchKernelGGL((target_prob_k<TSG_U8>), dim3(grid), dim3(kT), 0, (hipStream_t)stream, nll, labels, P, C, ignore_label, prob);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
 
 // level 0 of the standalone select is a refine over the whole range
 int tsg_kth_value(const float* v, int64_t n, int64_t k, float* out, void* ws, size_t ws_bytes,

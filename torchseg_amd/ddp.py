@@ -137,9 +137,10 @@ class Reducer(object):
                 self._launch(bucket)
 
     @staticmethod
-    def _gather(bucket):
-        """Move the gradients autograd produced this pass into the flat buffer (one multi-tensor launch per 128
-        tensors on the GPU) and make `param.grad` the bucket views."""
+    def _gather(bucket, scale=1.0):
+        """Move the gradients autograd produced this pass into the flat buffer, multiplied by `scale` (the 1/world of
+        the average, folded into the copy so that no separate pass over the 54-361 MB of gradients is needed after
+        the all-reduce), one multi-tensor launch per 128 tensors on the GPU, and make `param.grad` the bucket views."""
         if bucket.views is None:
             bucket.views = [bucket.view(i) for i in range(len(bucket.params))]
         todo = []
@@ -149,6 +150,8 @@ class Reducer(object):
                 v.zero_()                                # planned parameter without a gradient this pass
             elif p.grad.data_ptr() != v.data_ptr():
                 todo.append(i)
+            elif scale != 1.0:
+                v.mul_(scale)                            # accumulated in place (zero_grad(set_to_none=False))
         if not todo:
             return
         on_gpu = bucket.flat.is_cuda
@@ -162,6 +165,8 @@ class Reducer(object):
                 fast.append(i)
             else:
                 v.copy_(g)
+                if scale != 1.0:
+                    v.mul_(scale)
                 p.grad = v
         if fast:
             from . import kernels as K
@@ -169,21 +174,15 @@ class Reducer(object):
             for c0 in range(0, len(fast), kp.SGD_MAX_SEGS):
                 idx = tuple(fast[c0:c0 + kp.SGD_MAX_SEGS])
                 srcs = [bucket.params[i].grad for i in idx]
-                bucket.maps[idx] = kp.multi_copy(srcs, [bucket.views[i] for i in idx], bucket.maps.get(idx))
+                bucket.maps[idx] = kp.multi_copy(srcs, [bucket.views[i] for i in idx], bucket.maps.get(idx), scale)
             for i in fast:
                 bucket.params[i].grad = bucket.views[i]
 
     def _launch(self, bucket):
-        self._gather(bucket)
-        if self.prediv != 1.0:
-            bucket.flat.div_(self.prediv)
+        # averaging = pre-division by the world size inside the gather copy; apex's gradient_predivide_factor only
+        # chooses where the same division happens (overflow control for fp16 buckets), irrelevant for fp32 buckets
+        self._gather(bucket, 1.0 / self.world if self.average else 1.0)
         bucket.work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-    def _scale(self, bucket):
-        if self.average:
-            post = self.world / self.prediv
-            if post != 1.0:
-                bucket.flat.div_(post)
 
     def _build_plan(self):
         device = self._order[0].device if self._order else torch.device("cpu")
@@ -226,7 +225,6 @@ class Reducer(object):
         for bucket in self.buckets:
             bucket.work.wait()       # stream-level fence on HIP, blocking on gloo
             bucket.work = None
-            self._scale(bucket)
             bucket.pending = len(bucket.params)
             bucket.ready = [False] * len(bucket.params)
 

@@ -335,6 +335,15 @@ class HipKernels:
                                          dz.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(z)), "tsg_ohem_up_bwd")
         return dz
 
+    def ohem_target_prob(self, nll, labels, C_, ignore_label):
+        """mask_prob (loss_opr.py:81-83) from the forward's nll, with the kernels' own exp: fp32 [P]"""
+        _require_contiguous(nll, labels)
+        out = torch.empty_like(nll)
+        L.check(self.lib.tsg_ohem_target_prob(nll.data_ptr(), labels.data_ptr(), _label_code(labels), nll.numel(),
+                                              int(C_), int(ignore_label), out.data_ptr(), L.stream_ptr(nll)),
+                "tsg_ohem_target_prob")
+        return out
+
     def kth_value(self, v, k):
         n = v.numel()
         wsb = self.lib.tsg_kth_ws_bytes(n)

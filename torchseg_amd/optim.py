@@ -34,21 +34,22 @@ class FusedSGD(torch.optim.Optimizer):
                                       nesterov=False, maximize=False, foreach=None, differentiable=False,
                                       fused=None))
         self._lr_dev = None
-        self._lr_host = None
+        self._last_lrs = None
         self._plans = {}
 
     def _sync_lr(self, device):
-        """One [n_groups] device vector of learning rates, refreshed only when a group's lr changed."""
+        """One [n_groups] device vector of learning rates, refreshed only when a group's lr changed.  Every refresh
+        stages the values in a FRESH pinned tensor: torch's host allocator does not hand a pinned block out again
+        before the asynchronous copy that reads it has executed, so the host may run any number of iterations ahead
+        without overwriting a staging buffer that an earlier, still queued H2D copy will read."""
         lrs = [float(g["lr"]) for g in self.param_groups]
-        if self._lr_dev is None:
-            self._lr_dev = torch.tensor(lrs, dtype=torch.float32, device=device)
-            self._lr_host = torch.tensor(lrs, dtype=torch.float32).pin_memory() if device.type == "cuda" else None
+        if self._lr_dev is None or self._lr_dev.numel() != len(lrs) or self._lr_dev.device != device:
+            self._lr_dev = torch.tensor(lrs, dtype=torch.float32, device=device)     # also after add_param_group
         elif lrs != self._last_lrs:
-            if self._lr_host is not None:
-                self._lr_host.copy_(torch.tensor(lrs, dtype=torch.float32))
-                self._lr_dev.copy_(self._lr_host, non_blocking=True)
-            else:
-                self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32))
+            host = torch.tensor(lrs, dtype=torch.float32)
+            if device.type == "cuda":
+                host = host.pin_memory()
+            self._lr_dev.copy_(host, non_blocking=True)
         self._last_lrs = lrs
 
     def refresh_lr(self):
@@ -106,10 +107,11 @@ class FusedSGD(torch.optim.Optimizer):
         for c0 in range(0, len(segs), cap):
             chunk = segs[c0:c0 + cap]
             numel = tuple(t[0].numel() for t in chunk)
-            key = (c0, numel)
+            groups = tuple(t[3] for t in chunk)
+            key = (c0, numel, groups, len(self.param_groups))   # the plan stores the group of every segment
             plan = self._plans.get(key)
             if plan is None:                        # static per model: sizes, groups, block map
-                plan = (np.array(numel, dtype=np.int64), np.array([t[3] for t in chunk], dtype=np.int32),
+                plan = (np.array(numel, dtype=np.int64), np.array(groups, dtype=np.int32),
                         kp.sgd_multi_blockmap(numel, first.device))
                 self._plans[key] = plan
             ptrs = np.array([[t[0].data_ptr() for t in chunk], [t[1].data_ptr() for t in chunk],

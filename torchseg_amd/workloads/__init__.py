@@ -20,9 +20,12 @@ def ensure_furnace_on_path():
 # which keeps ~2 us of Python dispatch per torch call out of the benchmarked step.  On CPU tensors (the oracle
 # network of the parity tests and of bench.py's cpu_baseline) they are literally the reference's statements.
 
+NATIVE_FUSIONS = True      # tests switch this off to obtain the literal statements on HIP tensors too (stock baselines)
+
+
 def add_then_upsample(fm, last_fm, size):
     """bisenet network.py:92-94: `fm += last_fm; F.interpolate(fm, size, 'bilinear', align_corners=True)`."""
-    if fm.is_cuda:
+    if fm.is_cuda and NATIVE_FUSIONS:
         from ..fusion import upsample_presum
         return upsample_presum(fm, last_fm, size=size)
     import torch.nn.functional as F
@@ -36,7 +39,7 @@ def head_loss(criterion, logits, label, log_softmax=False):
     logits (CE(log_softmax(x)) == CE(x)); anything else is evaluated as written."""
     import torch.nn as nn
     import torch.nn.functional as F
-    if (logits.is_cuda and type(criterion) is nn.CrossEntropyLoss and criterion.reduction == 'mean'
+    if (NATIVE_FUSIONS and logits.is_cuda and type(criterion) is nn.CrossEntropyLoss and criterion.reduction == 'mean'
             and criterion.label_smoothing == 0.0 and logits.dim() == 4):
         from ..losses import cross_entropy_2d
         return cross_entropy_2d(logits, label, ignore_index=criterion.ignore_index, weight=criterion.weight)
@@ -46,7 +49,7 @@ def head_loss(criterion, logits, label, log_softmax=False):
 def softmax_bmm(x, a):
     """psanet network.py:125-126: torch.bmm(x, torch.softmax(a, dim=1))."""
     import torch
-    if x.is_cuda:
+    if x.is_cuda and NATIVE_FUSIONS:
         from ..psa import psa_attention, psa_supported
         if psa_supported(x, a):
             return psa_attention(x, a)

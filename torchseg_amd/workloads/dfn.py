@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ensure_furnace_on_path, head_loss
+from .. import workloads as _w
 
 ensure_furnace_on_path()
 from base_model import resnet101  # noqa: E402
@@ -85,7 +86,7 @@ class DFN(nn.Module):
                                                      self.border_heads)):
             fm = pre(fm)
             if last_fm is not None:
-                if fm.is_cuda:            # dfn network.py:130-133 as one kernel: up(fm) + last_fm
+                if fm.is_cuda and _w.NATIVE_FUSIONS:            # dfn network.py:130-133 as one kernel: up(fm) + last_fm
                     from ..upsample import upsample_bilinear_ac
                     last_fm = aft(upsample_bilinear_ac(fm, scale_factor=2 ** i, add=last_fm))
                 else:
