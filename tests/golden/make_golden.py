@@ -106,6 +106,7 @@ def main():
         print(name, "focal", loss.item())
     np.savez_compressed(os.path.join(HERE, "focal_golden.npz"), **out)
     metric_golden()
+    syncbn_golden()
 
 
 def metric_golden():
@@ -136,5 +137,52 @@ def metric_golden():
     np.savez_compressed(os.path.join(HERE, "metric_golden.npz"), **out)
 
 
+def syncbn_golden():
+    """_SyncBatchNorm._compute_mean_std (furnace/legacy/sync_bn/syncbn.py:86-98) executed verbatim: the one piece of the
+    reference's SyncBN arithmetic that is plain Python (mean, inv_std, running statistics with the UNBIASED variance from
+    the cross-GPU sum / square-sum / count).  The method is cut out of the file by its indentation and bound to a bare
+    object, because the module itself cannot be imported (it pulls in the CUDA-only extension, functions.py:14-16)."""
+    import textwrap
+    lines = open(os.path.join(REF, "furnace/legacy/sync_bn/syncbn.py")).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.strip().startswith("def _compute_mean_std"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].strip() and not lines[i].startswith("        "))
+    ns = {}
+    exec(compile(textwrap.dedent("\n".join(lines[start:end])), "ref_syncbn_compute_mean_std.py", "exec"), ns)
+    fn = ns["_compute_mean_std"]
+
+    class Bare(object):
+        pass
+
+    rng = np.random.RandomState(11)
+    out = {}
+    for name, (C, ranks, shape, eps, momentum) in {"c64_1rank": (64, 1, (16, 12, 10), 1e-5, 0.1),
+                                                    "c128_3ranks": (128, 3, (4, 7, 5), 1e-5, 0.1),
+                                                    "c19_2ranks_1x1": (19, 2, (2, 1, 1), 1e-3, 0.01),
+                                                    "c8_8ranks": (8, 8, (2, 9, 3), 1e-5, 0.9)}.items():
+        xs = [rng.standard_normal((shape[0] + r, C) + shape[1:]) * (1.0 + 0.3 * r) + 0.2 * r for r in range(ranks)]
+        ax = (0, 2, 3)
+        sum_ = torch.from_numpy(sum(x.sum(ax) for x in xs)).float()          # what sum_square + ReduceAddCoalesced deliver
+        ssum = torch.from_numpy(sum((x * x).sum(ax) for x in xs)).float()
+        size = int(sum(x.size // C for x in xs))
+        mod = Bare()
+        mod.momentum, mod.eps = momentum, eps
+        mod.running_mean = torch.from_numpy(rng.standard_normal(C)).float()
+        mod.running_var = torch.from_numpy(rng.rand(C) + 0.5).float()
+        rm0, rv0 = mod.running_mean.clone(), mod.running_var.clone()
+        mean, inv_std = fn(mod, sum_, ssum, size)
+        out[name + "/cfg"] = np.array([C, ranks, size, eps, momentum], dtype=np.float64)
+        for r, x in enumerate(xs):
+            out[name + "/x%d" % r] = x.astype(np.float32)
+        out[name + "/sum"] = sum_.numpy(); out[name + "/ssum"] = ssum.numpy()
+        out[name + "/rm0"] = rm0.numpy(); out[name + "/rv0"] = rv0.numpy()
+        out[name + "/mean"] = mean.numpy(); out[name + "/inv_std"] = inv_std.numpy()
+        out[name + "/rm1"] = mod.running_mean.numpy(); out[name + "/rv1"] = mod.running_var.numpy()
+        print(name, "size", size, "mean[0]", float(mean[0]), "inv_std[0]", float(inv_std[0]))
+    np.savez_compressed(os.path.join(HERE, "syncbn_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "syncbn":
+        syncbn_golden()
+    else:
+        main()

@@ -295,6 +295,271 @@ static int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// psa_mm: the bf16 contraction of all three PSA products with the softmax fused in (no P workspace):
+//   C[M,N] = sum_k Aop[m,k] * Bop[k,n],   256 x 64 x 64 block tiles, 4 waves stacked along M (64 x 64 each),
+//   v_mfma_f32_32x32x16_bf16, double-buffered LDS, one barrier per K tile (tile t+1 is written after the barrier
+//   from registers whose loads were issued one iteration earlier, then the loads of tile t+2 are re-issued).
+// Operand images in LDS:
+//   "NT"  global [rows][K], K contiguous  -> LDS [rows][72] (144-B rows: ds_read_b128 fragments, conflict-free)
+//   "TR"  global [K][cols], cols contiguous (the layout A [K,N] and X [Cx,K] / dOut [Cx,N] have for the products that
+//         contract over their ROW index) -> LDS [64 k][cols + 32] exactly as it comes from HBM (16-B copies); the
+//         k-major MFMA fragments come out of ds_read_b64_tr_b16 (lane mapping as in conv3wrw.hip).  Row strides
+//         (cols * 2 + 64) B are odd multiples of 64 B: the 4 rows x 64 B a half-wave touches fall on distinct banks.
+// B transforms (the fused softmax):  EXPB 1: B is a TR tile of A, element -> exp(a - lse[n])   (forward)
+//                                    EXPB 2: B is an NT tile of A, element -> exp(a - lse[k])   (dX)
+// Epilogues (through LDS, 16-B global accesses): EPI 0 store bf16; EPI 1 dA = exp(Araw[m][n] - lse[n]) * (acc - delta[n]).
+//   forward  out[c][j] = sum_i X[c][i] P[i][j]       A = X    NT   B = A     TR  EXPB 1
+//   dX       dX[c][i]  = sum_j dOut[c][j] P[i][j]    A = dOut NT   B = A     NT  EXPB 2
+//   dA       dP[i][j]  = sum_c X[c][i] dOut[c][j]    A = X    TR   B = dOut  TR  EPI 1
+// ---------------------------------------------------------------------------
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef v4i16 __attribute__((address_space(3))) lds_v4i16;
+
+constexpr int MM_BM = 256, MM_BN = 64, MM_BK = 64, MM_T = 256;
+constexpr int MM_NT_ROW = 72;                       // elements per NT row (64 + 8 pad)
+constexpr int MM_A_TR_ROW = MM_BM + 32;             // 288 elements = 576 B
+constexpr int MM_B_TR_ROW = MM_BN + 32;             // 96 elements  = 192 B
+constexpr int MM_A_ELEMS = MM_BM * MM_NT_ROW;       // 18432 (>= 64 * 288 = 18432: the TR image has the same size)
+constexpr int MM_B_ELEMS = MM_BK * MM_B_TR_ROW;     // 6144  (>= 64 * 72 = 4608 for the NT image)
+constexpr int MM_STAGE = MM_A_ELEMS + MM_B_ELEMS;   // elements per stage
+constexpr size_t MM_LDS = (size_t)2 * MM_STAGE * sizeof(bf16_t);   // 98,304 B
+constexpr int MM_EPI_ROW = 68;                      // fp32 words per epilogue row (64 + 4 pad)
+static_assert((size_t)MM_BM * MM_EPI_ROW * 4 <= MM_LDS, "epilogue image must fit the tile buffers");
+
+struct MmArgs {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;
+  int64_t M, N, K;                  // C is [M, N] row-major; NT operands are [rows, K], TR operands [K, cols]
+  int64_t sA, sB, sC;               // batch strides (elements)
+  const float* lse; int64_t sL;     // EXPB / EPI 1: log-sum-exp per softmax column
+  const bf16_t* Araw; int64_t sR;   // EPI 1: raw attention logits [M, N]
+  const float* delta; int64_t sD;   // EPI 1
+  int tiles_m, tiles_n;             // tile grid per batch
+  int per_xcd;                      // ceil(tiles / 8): block -> tile remap keeps the M tiles of one N tile on one XCD
+  int64_t batch;
+};
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <bool A_TR, bool B_TR, int EXPB, int EPI>
+__global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
+  constexpr float kLog2e = 1.4426950408889634f;
+
+  // block -> (batch, tile): consecutive block ids go round-robin over the 8 XCDs; give every XCD a contiguous run of
+  // tiles (M fastest), so the 2-15 M tiles that share a B tile read it through one L2
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
+  const int64_t t = (int64_t)(blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+  if (t >= tiles) return;
+  const int tm = (int)(t % g.tiles_m);
+  const int tn = (int)((t / g.tiles_m) % g.tiles_n);
+  const int64_t b = t / ((int64_t)g.tiles_m * g.tiles_n);
+  const int64_t m0 = (int64_t)tm * MM_BM, n0 = (int64_t)tn * MM_BN;
+  const bf16_t* Ag = g.A + b * g.sA;
+  const bf16_t* Bg = g.B + b * g.sB;
+  const float* lse = (EXPB || EPI == 1) ? g.lse + b * g.sL : nullptr;
+
+  // ---- staging maps: 16-byte chunks.  A tile = 2048 chunks (8 per thread), B tile = 512 chunks (2 per thread)
+  //   NT image [rows][8 chunks]: chunk id c -> row c >> 3, k-chunk c & 7
+  //   TR image [64 k][cols / 8 chunks]: chunk id c -> k row c / (cols / 8), column chunk c % (cols / 8)
+  uint4 ra[8], rb[2];
+  float bl[2][8];                                       // EXPB 1: lse * log2e of the thread's B columns (fixed per block)
+  if (EXPB == 1) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + MM_T * q;
+      const int64_t n = n0 + (c & 7) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bl[q][e] = (n + e < g.N) ? lse[n + e] * kLog2e : 0.f;
+    }
+  }
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = tid + MM_T * q;
+      if (A_TR) {
+        const int64_t k = k0 + (c >> 5), m = m0 + (c & 31) * 8;
+        ra[q] = (k < g.K && m < g.M) ? ld16(Ag + k * g.M + m) : make_uint4(0, 0, 0, 0);
+      } else {
+        const int64_t m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
+        ra[q] = (k < g.K && m < g.M) ? ld16(Ag + m * g.K + k) : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + MM_T * q;
+      if (B_TR) {
+        const int64_t k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
+        rb[q] = (k < g.K && n < g.N) ? ld16(Bg + k * g.N + n) : make_uint4(0, 0, 0, 0);
+      } else {
+        const int64_t n = n0 + (c >> 3), k = k0 + (c & 7) * 8;
+        rb[q] = (k < g.K && n < g.N) ? ld16(Bg + n * g.K + k) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  // exp(a - lse) of one 16-byte chunk, repacked to bf16 (round to nearest even, like the P the reference's bf16 path holds)
+  auto expchunk = [&](uint4 v, const float* l2) -> uint4 {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = exp2_fast(fmaf(__uint_as_float(w[i] << 16), kLog2e, -l2[2 * i]));
+      const float hi = exp2_fast(fmaf(__uint_as_float(w[i] & 0xffff0000u), kLog2e, -l2[2 * i + 1]));
+      w[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  auto stash = [&](int stage, int64_t k0) {
+    bf16_t* sa = lds + (size_t)stage * MM_STAGE;
+    bf16_t* sb = sa + MM_A_ELEMS;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = tid + MM_T * q;
+      const int off = A_TR ? (c >> 5) * MM_A_TR_ROW + (c & 31) * 8 : (c >> 3) * MM_NT_ROW + (c & 7) * 8;
+      *reinterpret_cast<uint4*>(sa + off) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + MM_T * q;
+      uint4 v = rb[q];
+      if (EXPB == 1) {
+        const int64_t k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
+        v = (k < g.K && n < g.N) ? expchunk(v, bl[q]) : make_uint4(0, 0, 0, 0);     // padding must stay 0, not exp(-lse)
+      } else if (EXPB == 2) {
+        const int64_t n = n0 + (c >> 3), k = k0 + (c & 7) * 8;
+        if (k < g.K && n < g.N) {
+          float l2[8];
+          const float4 l0 = *reinterpret_cast<const float4*>(lse + k), l1 = *reinterpret_cast<const float4*>(lse + k + 4);
+          l2[0] = l0.x * kLog2e; l2[1] = l0.y * kLog2e; l2[2] = l0.z * kLog2e; l2[3] = l0.w * kLog2e;
+          l2[4] = l1.x * kLog2e; l2[5] = l1.y * kLog2e; l2[6] = l1.z * kLog2e; l2[7] = l1.w * kLog2e;
+          v = expchunk(v, l2);
+        } else {
+          v = make_uint4(0, 0, 0, 0);
+        }
+      }
+      const int off = B_TR ? (c >> 3) * MM_B_TR_ROW + (c & 7) * 8 : (c >> 3) * MM_NT_ROW + (c & 7) * 8;
+      *reinterpret_cast<uint4*>(sb + off) = v;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment bases (elements).  NT: row = 32 i + (lane & 31), k = 16 ks + 8 half .. +7 (one ds_read_b128).
+  // TR: source row k = 16 ks + 8 half + (i16 >> 2) (+4 for the second read), column = 32 i + 16 sub + 4 (i16 & 3).
+  const int a_nt = (wave * 64 + (lane & 31)) * MM_NT_ROW + half * 8;
+  const int a_tr = (8 * half + (i16 >> 2)) * MM_A_TR_ROW + wave * 64 + 16 * sub + 4 * (i16 & 3);
+  const int b_nt = (lane & 31) * MM_NT_ROW + half * 8;
+  const int b_tr = (8 * half + (i16 >> 2)) * MM_B_TR_ROW + 16 * sub + 4 * (i16 & 3);
+
+  const int nk = (int)((g.K + MM_BK - 1) / MM_BK);
+  fetch(0);
+  stash(0, 0);
+  if (nk > 1) fetch(MM_BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
+    if (kt + 1 < nk) stash((kt + 1) & 1, (int64_t)(kt + 1) * MM_BK);
+    if (kt + 2 < nk) fetch((int64_t)(kt + 2) * MM_BK);
+    const bf16_t* sa = lds + (size_t)(kt & 1) * MM_STAGE;
+    const bf16_t* sb = sa + MM_A_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < MM_BK / 16; ++ks) {
+      union { v4i16 q[2]; bf16x8 v; } fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (A_TR) {
+          const lds_v4i16* p = (const lds_v4i16*)(sa + a_tr + ks * 16 * MM_A_TR_ROW + i * 32);
+          fa[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
+          fa[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (MM_A_TR_ROW / 4)));
+        } else {
+          fa[i].v = *reinterpret_cast<const bf16x8*>(sa + a_nt + i * 32 * MM_NT_ROW + ks * 16);
+        }
+        if (B_TR) {
+          const lds_v4i16* p = (const lds_v4i16*)(sb + b_tr + ks * 16 * MM_B_TR_ROW + i * 32);
+          fb[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
+          fb[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (MM_B_TR_ROW / 4)));
+        } else {
+          fb[i].v = *reinterpret_cast<const bf16x8*>(sb + b_nt + i * 32 * MM_NT_ROW + ks * 16);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue through LDS: acc (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half) -> fp32 image
+  // [256][68], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
+  __syncthreads();
+  float* ep = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        ep[row * MM_EPI_ROW + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  __syncthreads();
+  bf16_t* Cg = g.C + b * g.sC;
+  const int cchunk = tid & 7;
+  const int64_t n = n0 + cchunk * 8;
+  float dl[8], l2[8];
+  if (EPI == 1 && n < g.N) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dl[e] = g.delta[b * g.sD + n + e]; l2[e] = lse[n + e] * kLog2e; }
+  }
+#pragma unroll 4
+  for (int q = 0; q < 8; ++q) {
+    const int row = (tid >> 3) + 32 * q;
+    const int64_t m = m0 + row;
+    if (m >= g.M || n >= g.N) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(ep + row * MM_EPI_ROW + cchunk * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(ep + row * MM_EPI_ROW + cchunk * 8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (EPI == 1) {
+      const uint4 a = ld16(g.Araw + b * g.sR + m * g.N + n);
+      const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // P exactly as the contraction kernels see it: the bf16-rounded exp(a - lse)
+        const float p0 = bf16_to_f32(f32_to_bf16(exp2_fast(fmaf(__uint_as_float(w[e] << 16), kLog2e, -l2[2 * e]))));
+        const float p1 = bf16_to_f32(f32_to_bf16(exp2_fast(fmaf(__uint_as_float(w[e] & 0xffff0000u), kLog2e, -l2[2 * e + 1]))));
+        v[2 * e] = p0 * (v[2 * e] - dl[2 * e]);
+        v[2 * e + 1] = p1 * (v[2 * e + 1] - dl[2 * e + 1]);
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+    *reinterpret_cast<uint4*>(Cg + m * g.N + n) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <bool A_TR, bool B_TR, int EXPB, int EPI>
+static int launch_mm(MmArgs g, hipStream_t st) {
+  if (g.M % 8 || g.N % 8 || g.K % 8) return TSG_E_SHAPE;
+  if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return TSG_E_ALIGN;
+  g.tiles_m = (int)((g.M + MM_BM - 1) / MM_BM);
+  g.tiles_n = (int)((g.N + MM_BN - 1) / MM_BN);
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
+  g.per_xcd = (int)((tiles + 7) / 8);
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<A_TR, B_TR, EXPB, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
+  hipLaunchKernelGGL((psa_mm<A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T), MM_LDS, st, g);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
 static size_t au(size_t v) { return (v + 255) / 256 * 256; }
 
 struct PsaWs {
@@ -320,15 +585,16 @@ static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, 
   w.pm = (float*)take((size_t)B * kChunks * N * 4);
   w.pl = (float*)take((size_t)B * kChunks * N * 4);
   w.lse_tmp = (float*)take((size_t)B * N * 4);
-  w.P_hi = (bf16_t*)take((size_t)B * K * N * 2);
+  // the bf16 path (psa_mm) fuses the softmax into the contractions and needs no operand images at all
+  w.P_hi = f32 ? (bf16_t*)take((size_t)B * K * N * 2) : nullptr;
   w.P_lo = f32 ? (bf16_t*)take((size_t)B * K * N * 2) : nullptr;
-  w.X_hi = (bf16_t*)take((size_t)B * Cx * K * 2);
+  w.X_hi = f32 ? (bf16_t*)take((size_t)B * Cx * K * 2) : nullptr;
   w.X_lo = f32 ? (bf16_t*)take((size_t)B * Cx * K * 2) : nullptr;
   w.D_hi = w.D_lo = w.Dt_hi = w.Dt_lo = nullptr; w.delta = nullptr; w.delta_part = nullptr; w.dP = nullptr;
   if (bwd) {
-    w.D_hi = (bf16_t*)take((size_t)B * Cx * N * 2);
+    w.D_hi = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
     w.D_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
-    w.Dt_hi = (bf16_t*)take((size_t)B * Cx * N * 2);
+    w.Dt_hi = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
     w.Dt_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
     w.delta = (float*)take((size_t)B * N * 4);
     w.delta_part = (float*)take((size_t)B * kDeltaChunks * N * 4);
@@ -398,12 +664,12 @@ int tsg_psa_fwd(const void* X, const void* A, void* out, float* lse, int dtype, 
     g.A = w.X_lo; g.B = w.P_hi;
     if ((e = launch_gemm<float, 0>(g, B, st))) return e;
   } else {
+    if (Cx % 8 != 0 || N % 8 != 0) return TSG_E_SHAPE;
     if ((e = colstat<bf16_t>((const bf16_t*)A, B, K, N, w, lse, st))) return e;
-    hipLaunchKernelGGL((psa_transpose<bf16_t, 1, false>), tgrid, dim3(256), 0, st, (const bf16_t*)A, lse, K, N,
-                       w.P_hi, (bf16_t*)nullptr);
-    TSG_CHECK_LAUNCH();
-    g.A = (const bf16_t*)X; g.B = w.P_hi; g.accumulate = 0;
-    if ((e = launch_gemm<bf16_t, 0>(g, B, st))) return e;
+    MmArgs m = {};
+    m.A = (const bf16_t*)X; m.B = (const bf16_t*)A; m.C = (bf16_t*)out;
+    m.M = Cx; m.N = N; m.K = K; m.sA = Cx * K; m.sB = K * N; m.sC = Cx * N; m.lse = lse; m.sL = N; m.batch = B;
+    if ((e = launch_mm<false, true, 1, 0>(m, st))) return e;
   }
   return 0;
 }
@@ -462,23 +728,19 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
     hipLaunchKernelGGL(psa_da_f32, pgrid, dim3(256), 0, st, (const float*)A, lse, w.dP, w.delta, K, N, (float*)dA);
     TSG_CHECK_LAUNCH();
   } else {
-    hipLaunchKernelGGL((psa_prob<bf16_t, false>), pgrid, dim3(256), 0, st, (const bf16_t*)A, lse, K, N, w.P_hi,
-                       (bf16_t*)nullptr);
-    TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL((psa_delta<bf16_t>), dgrid3, dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta_part);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL(psa_delta_fold, jgrid, dim3(256), 0, st, w.delta_part, N, w.delta);
     TSG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((psa_transpose<bf16_t, 0, false>), xgrid, dim3(256), 0, st, (const bf16_t*)X,
-                       (const float*)nullptr, Cx, K, w.X_hi, (bf16_t*)nullptr);
-    TSG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((psa_transpose<bf16_t, 0, false>), dgrid, dim3(256), 0, st, (const bf16_t*)dout,
-                       (const float*)nullptr, Cx, N, w.Dt_hi, (bf16_t*)nullptr);
-    TSG_CHECK_LAUNCH();
-    gx.A = (const bf16_t*)dout; gx.B = w.P_hi; gx.accumulate = 0;
-    if ((e = launch_gemm<bf16_t, 0>(gx, B, st))) return e;
-    ga.C = dA; ga.A = w.X_hi; ga.B = w.Dt_hi; ga.P = w.P_hi; ga.delta = w.delta; ga.sP = K * N; ga.sD = N;
-    if ((e = launch_gemm<bf16_t, 1>(ga, B, st))) return e;
+    MmArgs mx = {};   // dX[c][i] = sum_j dOut[c][j] * exp(A[i][j] - lse[j])
+    mx.A = (const bf16_t*)dout; mx.B = (const bf16_t*)A; mx.C = (bf16_t*)dX;
+    mx.M = Cx; mx.N = K; mx.K = N; mx.sA = Cx * N; mx.sB = K * N; mx.sC = Cx * K; mx.lse = lse; mx.sL = N; mx.batch = B;
+    if ((e = launch_mm<false, false, 2, 0>(mx, st))) return e;
+    MmArgs ma = {};   // dA[i][j] = P[i][j] * (sum_c X[c][i] * dOut[c][j] - delta[j])
+    ma.A = (const bf16_t*)X; ma.B = (const bf16_t*)dout; ma.C = (bf16_t*)dA;
+    ma.M = K; ma.N = N; ma.K = Cx; ma.sA = Cx * K; ma.sB = Cx * N; ma.sC = K * N;
+    ma.lse = lse; ma.sL = N; ma.Araw = (const bf16_t*)A; ma.sR = K * N; ma.delta = w.delta; ma.sD = N; ma.batch = B;
+    if ((e = launch_mm<true, true, 0, 1>(ma, st))) return e;
   }
   return 0;
 }
