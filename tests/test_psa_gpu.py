@@ -92,3 +92,28 @@ def test_fuse_mode_intercepts_unchanged_call_pattern(cuda):
     ref = torch.bmm(x.detach(), torch.softmax(a.detach(), dim=1))
     torch.testing.assert_close(y.detach(), ref, rtol=1e-4, atol=1e-5)
     assert x.grad is not None and a.grad is not None
+
+
+def test_psa_bf16_full_size_fwd_bwd_vs_cpu_oracle(cuda):
+    """PSANet's real size (Cx 512, 3600 x 3600: 14 full + 1 partial M tile, 56 + 1 N tiles, 56 + 1 K tiles of the fused
+    kernels) in bf16, forward AND both gradients against the CPU oracle (the reference's own softmax + bmm,
+    psanet network.py:125-126, in fp32 on the same bf16-rounded inputs)."""
+    from torchseg_amd.psa import psa_attention
+    g = torch.Generator().manual_seed(11)
+    X = torch.relu(torch.randn(1, 512, 3600, generator=g)).bfloat16()
+    A = (torch.randn(1, 3600, 3600, generator=g) * 2 + torch.arange(3600).view(1, 3600, 1) * 0.001
+         - torch.arange(3600).view(1, 1, 3600) * 0.002).bfloat16()
+    dout = torch.randn(1, 512, 3600, generator=g).bfloat16()
+    Xr, Ar = X.float().requires_grad_(True), A.float().requires_grad_(True)
+    ref = torch.bmm(Xr, torch.softmax(Ar, dim=1))
+    ref.backward(dout.float())
+    Xd, Ad = X.to(cuda).requires_grad_(True), A.to(cuda).requires_grad_(True)
+    out = psa_attention(Xd, Ad)
+    out.backward(dout.to(cuda))
+    for got, want, name in ((out, ref.detach(), "out"), (Xd.grad, Xr.grad, "dX"), (Ad.grad, Ar.grad, "dA")):
+        scale = want.abs().max().item()
+        d = (got.detach().float().cpu() - want)
+        assert d.abs().max().item() <= 2e-2 * scale, (name, d.abs().max().item(), scale)
+        assert (d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item() <= 1e-2, name
+        # the last rows / columns (partial tiles) carry real values
+        assert got[..., -16:].float().abs().sum().item() > 0 and got[..., -16:, :].float().abs().sum().item() > 0
