@@ -95,16 +95,18 @@ class GraphedStep(object):
     after each replay (62 launches), so the reference's per-iteration lr schedule
     (train.py:133-139) needs no special handling."""
 
-    def __init__(self, model, opt, imgs, gts, world):
+    def __init__(self, model, opt, imgs, gts, world, opt_inside=False):
         self.graph = torch.cuda.CUDAGraph()
         self.opt = opt
+        self.opt_inside = bool(opt_inside)     # FusedSGD only: its learning rates live in a device vector (refresh_lr)
         opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.loss = step_body(model, opt, imgs, gts, world, with_optimizer=False)
+            self.loss = step_body(model, opt, imgs, gts, world, with_optimizer=self.opt_inside)
 
     def __call__(self):
         self.graph.replay()
-        self.opt.step()
+        if not self.opt_inside:
+            self.opt.step()
         return self.loss
 
 
@@ -206,7 +208,8 @@ def main():
                     help="also time ONE CPU step at the headline 1024x1024 shape (batch 2; about a minute of host time)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous of --gpus N ranks only, no GPU work (CPU-testable)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("TSG_GRAPH", "0")),
-                    help="EXPERIMENTAL: replay zero_grad+forward+backward from a hipGraph (default off)")
+                    help="1: replay zero_grad+forward+backward from a hipGraph, optimizer eager after each replay; "
+                         "2: the FusedSGD step is captured too (default 0 = eager)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--trace-loss", action="store_true", help="debug: print the loss of every timed step (syncs)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -295,7 +298,7 @@ def main():
     sync()
     graphed = None
     if use_graph:
-        graphed = GraphedStep(model, opt, imgs, gts, world)
+        graphed = GraphedStep(model, opt, imgs, gts, world, opt_inside=args.graph == 2)
         for it in range(2):                                            # untimed replays
             set_lr(opt, pol, n_eager + it)
             loss = graphed()

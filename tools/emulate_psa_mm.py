@@ -4,10 +4,20 @@ LDS epilogue image and the XCD tile remap, for the three instantiations (forward
 exact inputs, so any mismatch against the dense reference is an addressing bug.   python tools/emulate_psa_mm.py"""
 import numpy as np
 
-BM, BN, BK, T = 256, 64, 64, 256
-NT_ROW, A_TR_ROW, B_TR_ROW = 72, BM + 32, BN + 32
-A_ELEMS, B_ELEMS = BM * NT_ROW, BK * B_TR_ROW
+BN, BK, T = 64, 64, 256
+NT_ROW, B_TR_ROW = 72, BN + 32
+B_ELEMS = BK * B_TR_ROW
 EPI_ROW = 68
+BM = 256                       # rebound by main() for every tile configuration
+A_TR_ROW = A_ELEMS = WROWS = MI = None
+
+
+def configure(bm):
+    global BM, A_TR_ROW, A_ELEMS, WROWS, MI
+    BM = bm
+    A_TR_ROW = BM + 32
+    A_ELEMS = max(BM * NT_ROW, BK * A_TR_ROW)
+    WROWS, MI = BM // 4, BM // 128
 
 
 def tr_read(lds, addr):
@@ -39,16 +49,16 @@ def run(Aop, Bop, A_TR, B_TR, M, N, K, btrans=None, epi=None):
         seen.add(t)
         tm, tn = t % tiles_m, (t // tiles_m) % tiles_n
         m0, n0 = tm * BM, tn * BN
-        acc = np.zeros((T, 2, 2, 16))
+        acc = np.zeros((T, MI, 2, 16))
         for k0 in range(0, K, BK):
             sa, sb = np.zeros(A_ELEMS + 64), np.zeros(B_ELEMS + 64)
-            for q in range(8):
+            for q in range(BM // 32):
                 for th in range(T):
                     c = th + T * q
                     if A_TR:
-                        k, m = k0 + (c >> 5), m0 + (c & 31) * 8
+                        k, m = k0 + c // (BM // 8), m0 + (c % (BM // 8)) * 8
                         v = Aop[k, m:m + 8] if (k < K and m < M) else np.zeros(8)
-                        off = (c >> 5) * A_TR_ROW + (c & 31) * 8
+                        off = (c // (BM // 8)) * A_TR_ROW + (c % (BM // 8)) * 8
                     else:
                         m, k = m0 + (c >> 3), k0 + (c & 7) * 8
                         v = Aop[m, k:k + 8] if (k < K and m < M) else np.zeros(8)
@@ -73,20 +83,21 @@ def run(Aop, Bop, A_TR, B_TR, M, N, K, btrans=None, epi=None):
                 hf, sb_, i6 = L >> 5, (L >> 4) & 1, L & 15
                 for ks in range(BK // 16):
                     fa, fb = [], []
-                    for i in range(2):
+                    for i in range(MI):
                         if A_TR:
-                            base = (8 * hf + (i6 >> 2)) * A_TR_ROW + w * 64 + 16 * sb_ + 4 * (i6 & 3) + ks * 16 * A_TR_ROW + i * 32
+                            base = (8 * hf + (i6 >> 2)) * A_TR_ROW + w * WROWS + 16 * sb_ + 4 * (i6 & 3) + ks * 16 * A_TR_ROW + i * 32
                             fa.append(np.concatenate([tr_read(sa, base), tr_read(sa, base + 4 * A_TR_ROW)], 1))
                         else:
-                            base = (w * 64 + (L & 31)) * NT_ROW + hf * 8 + i * 32 * NT_ROW + ks * 16
+                            base = (w * WROWS + (L & 31)) * NT_ROW + hf * 8 + i * 32 * NT_ROW + ks * 16
                             fa.append(np.stack([sa[b:b + 8] for b in base]))
+                    for i in range(2):
                         if B_TR:
                             base = (8 * hf + (i6 >> 2)) * B_TR_ROW + 16 * sb_ + 4 * (i6 & 3) + ks * 16 * B_TR_ROW + i * 32
                             fb.append(np.concatenate([tr_read(sb, base), tr_read(sb, base + 4 * B_TR_ROW)], 1))
                         else:
                             base = (L & 31) * NT_ROW + hf * 8 + i * 32 * NT_ROW + ks * 16
                             fb.append(np.stack([sb[b:b + 8] for b in base]))
-                    for i in range(2):
+                    for i in range(MI):
                         for j in range(2):
                             Am = np.zeros((32, 16)); Bm = np.zeros((16, 32))
                             for l in range(64):
@@ -98,15 +109,15 @@ def run(Aop, Bop, A_TR, B_TR, M, N, K, btrans=None, epi=None):
                                     acc[w * 64 + l, i, j, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
         ep = np.zeros(BM * EPI_ROW)
         for th in range(T):
-            for i in range(2):
+            for i in range(MI):
                 for j in range(2):
                     for r in range(16):
-                        row = wave[th] * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half[th]
+                        row = wave[th] * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half[th]
                         ep[row * EPI_ROW + j * 32 + (lane[th] & 31)] = acc[th, i, j, r]
         for th in range(T):
             cch = th & 7
             n = n0 + cch * 8
-            for q in range(8):
+            for q in range(BM // 32):
                 row = (th >> 3) + 32 * q
                 m = m0 + row
                 if m >= M or n >= N:
@@ -118,6 +129,13 @@ def run(Aop, Bop, A_TR, B_TR, M, N, K, btrans=None, epi=None):
 
 
 def main():
+    for bm in (256, 128):
+        configure(bm)
+        check()
+    print("psa_mm indexing (BM 256 and 128): forward, dX, dA and the multi-tile remap agree with the dense reference")
+
+
+def check():
     rng = np.random.default_rng(0)
     ident = lambda v, n, k: v
     # forward: out[c][j] = sum_i X[c][i] exp(A[i][j] - lse[j]);  M = Cx, N = N, K = K
@@ -140,7 +158,6 @@ def main():
     A2, B2 = rng.standard_normal((K2, M2)), rng.standard_normal((K2, N2))
     C2 = run(A2, B2, True, True, M2, N2, K2, btrans=ident)
     assert np.allclose(C2, A2.T @ B2), "TR x TR, multi-tile"
-    print("psa_mm indexing: forward, dX, dA and the multi-tile remap agree with the dense reference")
 
 
 if __name__ == "__main__":

@@ -19,6 +19,8 @@
 // which keeps the 1e-4 parity bar without an fp32 tensor-core path.
 #include "tsg_common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace tsg {
 
@@ -65,6 +67,78 @@ __global__ __launch_bounds__(256) void psa_colstat2(const float* __restrict__ pm
   float l = 0.f;
   for (int c = 0; c < nchunk; ++c) l += pl[(b * nchunk + c) * N + j] * __expf(pm[(b * nchunk + c) * N + j] - m);
   lse[b * N + j] = m + logf(l);
+}
+
+// Vectorised stage 1 (N % V == 0): a thread owns V adjacent columns (one 16-byte load per row) and a chunk of rows,
+// GR rows in flight at a time; per group one max pass and ONE exp per element (the running sum is rescaled per
+// group, not per element).  120 row chunks x N / V threads keep > 10^5 independent 16-byte loads in flight, which
+// the one-column-per-thread kernel above (1.2 TB/s at 3600^2) could not.
+template <typename T, int V> struct ColVec;
+template <> struct ColVec<bf16_t, 8> : Vec<bf16_t> {};
+template <> struct ColVec<float, 4> : Vec<float> {};
+
+template <typename T, int V, int GR>
+__global__ __launch_bounds__(128) void psa_colstat1_vec(const T* __restrict__ A, int64_t K, int64_t N,
+                                                        int rows_per_chunk, float* __restrict__ pm,
+                                                        float* __restrict__ pl) {
+  const int64_t j = ((int64_t)blockIdx.x * 128 + threadIdx.x) * V;
+  const int chunk = blockIdx.y, nchunk = gridDim.y;
+  const int64_t b = blockIdx.z;
+  if (j >= N) return;
+  const T* a = A + b * K * N + j;
+  int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = r0 + rows_per_chunk;
+  if (r1 > K) r1 = K;
+  float m[V], l[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { m[e] = -INFINITY; l[e] = 0.f; }
+  for (int64_t i = r0; i < r1; i += GR) {
+    ColVec<T, V> v[GR];
+#pragma unroll
+    for (int u = 0; u < GR; ++u)
+      if (i + u < r1) v[u].load(a + (i + u) * N);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float mn = m[e];
+#pragma unroll
+      for (int u = 0; u < GR; ++u)
+        if (i + u < r1) mn = fmaxf(mn, v[u].v[e]);
+      float acc = l[e] * __expf(m[e] - mn);             // exp(-inf - finite) = 0 on the first group
+#pragma unroll
+      for (int u = 0; u < GR; ++u)
+        if (i + u < r1) acc += __expf(v[u].v[e] - mn);
+      m[e] = mn; l[e] = acc;
+    }
+  }
+  float* om = pm + (b * nchunk + chunk) * N + j;
+  float* ol = pl + (b * nchunk + chunk) * N + j;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { om[e] = m[e]; ol[e] = l[e]; }
+}
+
+// Stage 2 for many chunks: block = 64 columns x 4 chunk groups; the per-thread loads are independent, the four
+// group results meet in LDS (fixed order).
+__global__ __launch_bounds__(256) void psa_colstat2_wide(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                         int nchunk, int64_t N, float* __restrict__ lse) {
+  __shared__ float sm[4][64], sl[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + col;
+  const int64_t b = blockIdx.y;
+  const int per = (nchunk + 3) / 4;
+  const int c0 = grp * per, c1 = (c0 + per < nchunk) ? c0 + per : nchunk;
+  float m = -INFINITY, l = 0.f;
+  if (j < N) {
+    for (int c = c0; c < c1; ++c) m = fmaxf(m, pm[(b * nchunk + c) * N + j]);
+    for (int c = c0; c < c1; ++c) l += pl[(b * nchunk + c) * N + j] * __expf(pm[(b * nchunk + c) * N + j] - m);
+  }
+  sm[grp][col] = m; sl[grp][col] = l;
+  __syncthreads();
+  if (grp == 0 && j < N) {
+    float mm = fmaxf(fmaxf(sm[0][col], sm[1][col]), fmaxf(sm[2][col], sm[3][col]));
+    float ll = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ll += (sl[q][col] > 0.f) ? sl[q][col] * __expf(sm[q][col] - mm) : 0.f;
+    lse[b * N + j] = mm + logf(ll);
+  }
 }
 
 __device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
@@ -316,16 +390,24 @@ static int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t st) {
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef v4i16 __attribute__((address_space(3))) lds_v4i16;
 
-constexpr int MM_BM = 256, MM_BN = 64, MM_BK = 64, MM_T = 256;
+constexpr int MM_BN = 64, MM_BK = 64, MM_T = 256;
 constexpr int MM_NT_ROW = 72;                       // elements per NT row (64 + 8 pad)
-constexpr int MM_A_TR_ROW = MM_BM + 32;             // 288 elements = 576 B
 constexpr int MM_B_TR_ROW = MM_BN + 32;             // 96 elements  = 192 B
-constexpr int MM_A_ELEMS = MM_BM * MM_NT_ROW;       // 18432 (>= 64 * 288 = 18432: the TR image has the same size)
 constexpr int MM_B_ELEMS = MM_BK * MM_B_TR_ROW;     // 6144  (>= 64 * 72 = 4608 for the NT image)
-constexpr int MM_STAGE = MM_A_ELEMS + MM_B_ELEMS;   // elements per stage
-constexpr size_t MM_LDS = (size_t)2 * MM_STAGE * sizeof(bf16_t);   // 98,304 B
 constexpr int MM_EPI_ROW = 68;                      // fp32 words per epilogue row (64 + 4 pad)
-static_assert((size_t)MM_BM * MM_EPI_ROW * 4 <= MM_LDS, "epilogue image must fit the tile buffers");
+
+// BM = rows of C per block (256: 64 per wave, 1 block/CU; 128: 32 per wave, 2 blocks/CU), PF = K tiles whose global
+// loads are in flight in registers beyond the one being written to LDS (HBM/L2 latency is ~2 us: with one wave per
+// SIMD a single tile of lead time leaves every iteration waiting for its loads)
+template <int BM> struct MmGeom {
+  static constexpr int A_TR_ROW = BM + 32;                                     // (2 BM + 64) B: odd multiple of 64 B
+  static constexpr int A_ELEMS = (BM * MM_NT_ROW > MM_BK * A_TR_ROW) ? BM * MM_NT_ROW : MM_BK * A_TR_ROW;
+  static constexpr int STAGE = A_ELEMS + MM_B_ELEMS;
+  static constexpr size_t LDS = (size_t)2 * STAGE * sizeof(bf16_t);            // 98,304 B (BM 256) / 65,536 B (BM 128)
+  static constexpr int ACH = BM / 32;                                          // 16-byte A chunks per thread and tile
+  static constexpr int MI = BM / 128;                                          // 32-row MFMA tiles per wave along M
+  static_assert((size_t)BM * MM_EPI_ROW * 4 <= LDS, "epilogue image must fit the tile buffers");
+};
 
 struct MmArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -341,30 +423,32 @@ struct MmArgs {
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <bool A_TR, bool B_TR, int EXPB, int EPI>
-__global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
+template <int BM, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
+__global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
+  typedef MmGeom<BM> G;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
   constexpr float kLog2e = 1.4426950408889634f;
+  constexpr int WROWS = BM / 4;                          // C rows per wave
 
   // block -> (batch, tile): consecutive block ids go round-robin over the 8 XCDs; give every XCD a contiguous run of
-  // tiles (M fastest), so the 2-15 M tiles that share a B tile read it through one L2
+  // tiles (M fastest), so the M tiles that share a B tile read it through one L2
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
   const int64_t t = (int64_t)(blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
   if (t >= tiles) return;
   const int tm = (int)(t % g.tiles_m);
   const int tn = (int)((t / g.tiles_m) % g.tiles_n);
   const int64_t b = t / ((int64_t)g.tiles_m * g.tiles_n);
-  const int64_t m0 = (int64_t)tm * MM_BM, n0 = (int64_t)tn * MM_BN;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * MM_BN;
   const bf16_t* Ag = g.A + b * g.sA;
   const bf16_t* Bg = g.B + b * g.sB;
   const float* lse = (EXPB || EPI == 1) ? g.lse + b * g.sL : nullptr;
 
-  // ---- staging maps: 16-byte chunks.  A tile = 2048 chunks (8 per thread), B tile = 512 chunks (2 per thread)
+  // ---- staging maps: 16-byte chunks.  A tile = BM * 8 chunks (ACH per thread), B tile = 512 chunks (2 per thread)
   //   NT image [rows][8 chunks]: chunk id c -> row c >> 3, k-chunk c & 7
   //   TR image [64 k][cols / 8 chunks]: chunk id c -> k row c / (cols / 8), column chunk c % (cols / 8)
-  uint4 ra[8], rb[2];
+  uint4 ra[PF][G::ACH], rb[PF][2];
   float bl[2][8];                                       // EXPB 1: lse * log2e of the thread's B columns (fixed per block)
   if (EXPB == 1) {
 #pragma unroll
@@ -375,16 +459,16 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
       for (int e = 0; e < 8; ++e) bl[q][e] = (n + e < g.N) ? lse[n + e] * kLog2e : 0.f;
     }
   }
-  auto fetch = [&](int64_t k0) {
+  auto fetch = [&](uint4* qa, uint4* qb, int64_t k0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < G::ACH; ++q) {
       const int c = tid + MM_T * q;
       if (A_TR) {
-        const int64_t k = k0 + (c >> 5), m = m0 + (c & 31) * 8;
-        ra[q] = (k < g.K && m < g.M) ? ld16(Ag + k * g.M + m) : make_uint4(0, 0, 0, 0);
+        const int64_t k = k0 + c / (BM / 8), m = m0 + (c % (BM / 8)) * 8;
+        qa[q] = (k < g.K && m < g.M) ? ld16(Ag + k * g.M + m) : make_uint4(0, 0, 0, 0);
       } else {
         const int64_t m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
-        ra[q] = (k < g.K && m < g.M) ? ld16(Ag + m * g.K + k) : make_uint4(0, 0, 0, 0);
+        qa[q] = (k < g.K && m < g.M) ? ld16(Ag + m * g.K + k) : make_uint4(0, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -392,10 +476,10 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
       const int c = tid + MM_T * q;
       if (B_TR) {
         const int64_t k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
-        rb[q] = (k < g.K && n < g.N) ? ld16(Bg + k * g.N + n) : make_uint4(0, 0, 0, 0);
+        qb[q] = (k < g.K && n < g.N) ? ld16(Bg + k * g.N + n) : make_uint4(0, 0, 0, 0);
       } else {
         const int64_t n = n0 + (c >> 3), k = k0 + (c & 7) * 8;
-        rb[q] = (k < g.K && n < g.N) ? ld16(Bg + n * g.K + k) : make_uint4(0, 0, 0, 0);
+        qb[q] = (k < g.K && n < g.N) ? ld16(Bg + n * g.K + k) : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -410,19 +494,19 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   };
-  auto stash = [&](int stage, int64_t k0) {
-    bf16_t* sa = lds + (size_t)stage * MM_STAGE;
-    bf16_t* sb = sa + MM_A_ELEMS;
+  auto stash = [&](const uint4* qa, const uint4* qb, int stage, int64_t k0) {
+    bf16_t* sa = lds + (size_t)stage * G::STAGE;
+    bf16_t* sb = sa + G::A_ELEMS;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < G::ACH; ++q) {
       const int c = tid + MM_T * q;
-      const int off = A_TR ? (c >> 5) * MM_A_TR_ROW + (c & 31) * 8 : (c >> 3) * MM_NT_ROW + (c & 7) * 8;
-      *reinterpret_cast<uint4*>(sa + off) = ra[q];
+      const int off = A_TR ? (c / (BM / 8)) * G::A_TR_ROW + (c % (BM / 8)) * 8 : (c >> 3) * MM_NT_ROW + (c & 7) * 8;
+      *reinterpret_cast<uint4*>(sa + off) = qa[q];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int c = tid + MM_T * q;
-      uint4 v = rb[q];
+      uint4 v = qb[q];
       if (EXPB == 1) {
         const int64_t k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
         v = (k < g.K && n < g.N) ? expchunk(v, bl[q]) : make_uint4(0, 0, 0, 0);     // padding must stay 0, not exp(-lse)
@@ -443,9 +527,9 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[G::MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < G::MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -453,60 +537,73 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
 
   // fragment bases (elements).  NT: row = 32 i + (lane & 31), k = 16 ks + 8 half .. +7 (one ds_read_b128).
   // TR: source row k = 16 ks + 8 half + (i16 >> 2) (+4 for the second read), column = 32 i + 16 sub + 4 (i16 & 3).
-  const int a_nt = (wave * 64 + (lane & 31)) * MM_NT_ROW + half * 8;
-  const int a_tr = (8 * half + (i16 >> 2)) * MM_A_TR_ROW + wave * 64 + 16 * sub + 4 * (i16 & 3);
+  const int a_nt = (wave * WROWS + (lane & 31)) * MM_NT_ROW + half * 8;
+  const int a_tr = (8 * half + (i16 >> 2)) * G::A_TR_ROW + wave * WROWS + 16 * sub + 4 * (i16 & 3);
   const int b_nt = (lane & 31) * MM_NT_ROW + half * 8;
   const int b_tr = (8 * half + (i16 >> 2)) * MM_B_TR_ROW + 16 * sub + 4 * (i16 & 3);
 
+  // tile t travels in register set t % PF: fetched PF iterations before it is written to LDS
   const int nk = (int)((g.K + MM_BK - 1) / MM_BK);
-  fetch(0);
-  stash(0, 0);
-  if (nk > 1) fetch(MM_BK);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
-    if (kt + 1 < nk) stash((kt + 1) & 1, (int64_t)(kt + 1) * MM_BK);
-    if (kt + 2 < nk) fetch((int64_t)(kt + 2) * MM_BK);
-    const bf16_t* sa = lds + (size_t)(kt & 1) * MM_STAGE;
-    const bf16_t* sb = sa + MM_A_ELEMS;
+  fetch(ra[0], rb[0], 0);
+  stash(ra[0], rb[0], 0, 0);
 #pragma unroll
-    for (int ks = 0; ks < MM_BK / 16; ++ks) {
-      union { v4i16 q[2]; bf16x8 v; } fa[2], fb[2];
+  for (int u = 1; u <= PF; ++u)
+    if (u < nk) fetch(ra[u % PF], rb[u % PF], (int64_t)u * MM_BK);
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (A_TR) {
-          const lds_v4i16* p = (const lds_v4i16*)(sa + a_tr + ks * 16 * MM_A_TR_ROW + i * 32);
-          fa[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
-          fa[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (MM_A_TR_ROW / 4)));
-        } else {
-          fa[i].v = *reinterpret_cast<const bf16x8*>(sa + a_nt + i * 32 * MM_NT_ROW + ks * 16);
+    for (int u = 0; u < PF; ++u) {
+      const int kt = kt0 + u;
+      if (kt >= nk) break;
+      constexpr int dummy = 0; (void)dummy;
+      const int s = (u + 1) % PF;                        // == (kt + 1) % PF: kt0 is a multiple of PF
+      __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
+      if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (int64_t)(kt + 1) * MM_BK);
+      if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (int64_t)(kt + 1 + PF) * MM_BK);
+      const bf16_t* sa = lds + (size_t)(kt & 1) * G::STAGE;
+      const bf16_t* sb = sa + G::A_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < MM_BK / 16; ++ks) {
+        union { v4i16 q[2]; bf16x8 v; } fa[G::MI], fb[2];
+#pragma unroll
+        for (int i = 0; i < G::MI; ++i) {
+          if (A_TR) {
+            const lds_v4i16* p = (const lds_v4i16*)(sa + a_tr + ks * 16 * G::A_TR_ROW + i * 32);
+            fa[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
+            fa[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (G::A_TR_ROW / 4)));
+          } else {
+            fa[i].v = *reinterpret_cast<const bf16x8*>(sa + a_nt + i * 32 * MM_NT_ROW + ks * 16);
+          }
         }
-        if (B_TR) {
-          const lds_v4i16* p = (const lds_v4i16*)(sb + b_tr + ks * 16 * MM_B_TR_ROW + i * 32);
-          fb[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
-          fb[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (MM_B_TR_ROW / 4)));
-        } else {
-          fb[i].v = *reinterpret_cast<const bf16x8*>(sb + b_nt + i * 32 * MM_NT_ROW + ks * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (B_TR) {
+            const lds_v4i16* p = (const lds_v4i16*)(sb + b_tr + ks * 16 * MM_B_TR_ROW + j * 32);
+            fb[j].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
+            fb[j].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (MM_B_TR_ROW / 4)));
+          } else {
+            fb[j].v = *reinterpret_cast<const bf16x8*>(sb + b_nt + j * 32 * MM_NT_ROW + ks * 16);
+          }
         }
+#pragma unroll
+        for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
     }
   }
 
   // ---- epilogue through LDS: acc (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half) -> fp32 image
-  // [256][68], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
+  // [BM][68], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
   __syncthreads();
   float* ep = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < G::MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = wave * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         ep[row * MM_EPI_ROW + j * 32 + (lane & 31)] = acc[i][j][r];
       }
   __syncthreads();
@@ -519,7 +616,7 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
     for (int e = 0; e < 8; ++e) { dl[e] = g.delta[b * g.sD + n + e]; l2[e] = lse[n + e] * kLog2e; }
   }
 #pragma unroll 4
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < BM / 32; ++q) {
     const int row = (tid >> 3) + 32 * q;
     const int64_t m = m0 + row;
     if (m >= g.M || n >= g.N) continue;
@@ -545,19 +642,44 @@ __global__ __launch_bounds__(MM_T) void psa_mm(MmArgs g) {
   }
 }
 
+template <int BM, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
+static int launch_mm_cfg(MmArgs g, hipStream_t st) {
+  g.tiles_m = (int)((g.M + BM - 1) / BM);
+  g.tiles_n = (int)((g.N + MM_BN - 1) / MM_BN);
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
+  g.per_xcd = (int)((tiles + 7) / 8);
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, PF, A_TR, B_TR, EXPB, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MmGeom<BM>::LDS));
+  hipLaunchKernelGGL((psa_mm<BM, PF, A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T),
+                     MmGeom<BM>::LDS, st, g);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (bring-up / tuning knob, read once); default chosen by measurement
+static int mm_cfg() {
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("TSG_PSA_CFG");
+    cfg = 1281;
+    if (e) {
+      if (!strcmp(e, "256x1")) cfg = 2561; else if (!strcmp(e, "256x2")) cfg = 2562;
+      else if (!strcmp(e, "128x1")) cfg = 1281; else if (!strcmp(e, "128x2")) cfg = 1282;
+    }
+  }
+  return cfg;
+}
+
 template <bool A_TR, bool B_TR, int EXPB, int EPI>
 static int launch_mm(MmArgs g, hipStream_t st) {
   if (g.M % 8 || g.N % 8 || g.K % 8) return TSG_E_SHAPE;
   if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return TSG_E_ALIGN;
-  g.tiles_m = (int)((g.M + MM_BM - 1) / MM_BM);
-  g.tiles_n = (int)((g.N + MM_BN - 1) / MM_BN);
-  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
-  g.per_xcd = (int)((tiles + 7) / 8);
-  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<A_TR, B_TR, EXPB, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
-  hipLaunchKernelGGL((psa_mm<A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T), MM_LDS, st, g);
-  TSG_CHECK_LAUNCH();
-  return 0;
+  switch (mm_cfg()) {
+    case 2561: return launch_mm_cfg<256, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 2562: return launch_mm_cfg<256, 2, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 1282: return launch_mm_cfg<128, 2, A_TR, B_TR, EXPB, EPI>(g, st);
+    default:   return launch_mm_cfg<128, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+  }
 }
 
 static size_t au(size_t v) { return (v + 255) / 256 * 256; }
@@ -575,7 +697,7 @@ struct PsaWs {
   size_t total;
 };
 
-constexpr int kChunks = 30;
+constexpr int kChunks = 120;          // row chunks of the column statistics (workspace [B][kChunks][N] x 2)
 
 static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, bool f32, bool bwd) {
   PsaWs w;
@@ -612,12 +734,26 @@ static int egrid(int64_t n) {
 
 template <typename T>
 static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float* lse, hipStream_t st) {
-  const int rpc = (int)((K + kChunks - 1) / kChunks);
-  hipLaunchKernelGGL((psa_colstat1<T>), dim3((unsigned)((N + 255) / 256), kChunks, (unsigned)B), dim3(256), 0, st,
+  constexpr int V = sizeof(T) == 2 ? 8 : 4;
+  if (N % V == 0 && aligned16(A)) {
+    const int rpc = (int)((K + kChunks - 1) / kChunks);
+    const int nch = (int)((K + rpc - 1) / rpc);                        // chunks that actually hold rows
+    const int64_t nv = N / V;
+    hipLaunchKernelGGL((psa_colstat1_vec<T, V, 10>), dim3((unsigned)((nv + 127) / 128), (unsigned)nch, (unsigned)B),
+                       dim3(128), 0, st, A, K, N, rpc, w.pm, w.pl);
+    TSG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(psa_colstat2_wide, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(256), 0, st, w.pm, w.pl,
+                       nch, N, lse);
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
+  const int nch = 30;
+  const int rpc = (int)((K + nch - 1) / nch);
+  hipLaunchKernelGGL((psa_colstat1<T>), dim3((unsigned)((N + 255) / 256), nch, (unsigned)B), dim3(256), 0, st,
                      A, K, N, rpc, w.pm, w.pl);
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(psa_colstat2, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st, w.pm, w.pl,
-                     kChunks, N, lse);
+                     nch, N, lse);
   TSG_CHECK_LAUNCH();
   return 0;
 }
