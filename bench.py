@@ -90,17 +90,31 @@ def train_step(model, opt, imgs, gts, lr_policy, it, world):
 
 
 class GraphedStep(object):
-    """zero_grad -> forward -> backward (incl. collectives) captured once into a hipGraph and
-    replayed, which removes ~1000 host-side launches per step; optimizer.step() stays eager
-    after each replay (62 launches), so the reference's per-iteration lr schedule
-    (train.py:133-139) needs no special handling."""
+    """zero_grad -> forward -> backward (incl. collectives) captured once into a hipGraph and replayed, which removes
+    ~650 host-side launches per step.  With opt_inside (FusedSGD: its learning rates live in a device vector,
+    `refresh_lr`) the optimizer step is part of the graph too; otherwise it runs eagerly after each replay, so the
+    reference's per-iteration lr schedule (train.py:133-139) needs no special handling.
+
+    Warm-up and capture MUST share one stream (`GraphedStep.stream`): an autograd leaf's AccumulateGrad node runs on
+    the stream that was current when the parameter first entered a graph, so a warm-up on any other stream turns
+    every gradient hand-off of the captured backward into a cross-stream fork/join inside the capture.  On ROCm 7.2
+    the instantiated graph then loses ordering between branches (second replay: non-finite BN statistics and
+    gradients; same-stream capture is bit-stable against eager)."""
+
+    stream = None
+
+    @classmethod
+    def capture_stream(cls):
+        if cls.stream is None:
+            cls.stream = torch.cuda.Stream()
+        return cls.stream
 
     def __init__(self, model, opt, imgs, gts, world, opt_inside=False):
         self.graph = torch.cuda.CUDAGraph()
         self.opt = opt
-        self.opt_inside = bool(opt_inside)     # FusedSGD only: its learning rates live in a device vector (refresh_lr)
+        self.opt_inside = bool(opt_inside)
         opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.capture_stream()):
             self.loss = step_body(model, opt, imgs, gts, world, with_optimizer=self.opt_inside)
 
     def __call__(self):
@@ -279,7 +293,7 @@ def main():
     dominant = None
     all_kernels = None
     n_eager = max(args.warmup, 3) if use_graph else args.warmup        # capture needs warmed-up libraries
-    side = torch.cuda.Stream() if use_graph else None
+    side = GraphedStep.capture_stream() if use_graph else None   # warm-up on the stream the capture will use
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():

@@ -52,7 +52,9 @@ del model, opt
 torch.cuda.empty_cache()
 
 model, opt, pol = make()
-side = torch.cuda.Stream() if a.side else torch.cuda.current_stream()
+side = {0: torch.cuda.current_stream(), 1: torch.cuda.Stream(), 2: bench.GraphedStep.capture_stream()}[a.side]
+if a.side == 1:
+    bench.GraphedStep.stream = torch.cuda.Stream()       # capture on a stream other than the warm-up's (the old behaviour)
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for it in range(a.warm):

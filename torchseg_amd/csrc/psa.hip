@@ -127,8 +127,23 @@ __global__ __launch_bounds__(256) void psa_colstat2_wide(const float* __restrict
   const int c0 = grp * per, c1 = (c0 + per < nchunk) ? c0 + per : nchunk;
   float m = -INFINITY, l = 0.f;
   if (j < N) {
-    for (int c = c0; c < c1; ++c) m = fmaxf(m, pm[(b * nchunk + c) * N + j]);
-    for (int c = c0; c < c1; ++c) l += pl[(b * nchunk + c) * N + j] * __expf(pm[(b * nchunk + c) * N + j] - m);
+    // batches of 16 independent loads (a rolled loop waits for every load before issuing the next: 30 x ~600 ns)
+    for (int cb = c0; cb < c1; cb += 16) {
+      float vm[16], vl[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool in = cb + u < c1;
+        vm[u] = in ? pm[(b * nchunk + cb + u) * N + j] : -INFINITY;
+        vl[u] = in ? pl[(b * nchunk + cb + u) * N + j] : 0.f;
+      }
+      float mn = m;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) mn = fmaxf(mn, vm[u]);
+      float acc = (l > 0.f) ? l * __expf(m - mn) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += (vl[u] > 0.f) ? vl[u] * __expf(vm[u] - mn) : 0.f;
+      m = mn; l = acc;
+    }
   }
   sm[grp][col] = m; sl[grp][col] = l;
   __syncthreads();
@@ -417,7 +432,8 @@ struct MmArgs {
   const bf16_t* Araw; int64_t sR;   // EPI 1: raw attention logits [M, N]
   const float* delta; int64_t sD;   // EPI 1
   int tiles_m, tiles_n;             // tile grid per batch
-  int per_xcd;                      // ceil(tiles / 8): block -> tile remap keeps the M tiles of one N tile on one XCD
+  int per_xcd;                      // ceil(tiles / 8): every XCD gets a contiguous run of tiles
+  int m_fastest;                    // tile order inside the run (0: N fastest, the default)
   int64_t batch;
 };
 
@@ -432,13 +448,15 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr int WROWS = BM / 4;                          // C rows per wave
 
-  // block -> (batch, tile): consecutive block ids go round-robin over the 8 XCDs; give every XCD a contiguous run of
-  // tiles (M fastest), so the M tiles that share a B tile read it through one L2
+  // block -> (batch, tile): consecutive block ids go round-robin over the 8 XCDs; give every XCD a contiguous run of tiles
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
   const int64_t t = (int64_t)(blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
   if (t >= tiles) return;
-  const int tm = (int)(t % g.tiles_m);
-  const int tn = (int)((t / g.tiles_m) % g.tiles_n);
+  // N fastest: an XCD's run of tiles shares ONE A slab (BM rows x K, <= 1.8 MB: it stays in that XCD's 4 MB L2 while
+  // the B operand streams past), instead of every XCD cycling through all of A (measured: section 4a of DESIGN.md)
+  int tm, tn;
+  if (g.m_fastest) { tm = (int)(t % g.tiles_m); tn = (int)((t / g.tiles_m) % g.tiles_n); }
+  else             { tn = (int)(t % g.tiles_n); tm = (int)((t / g.tiles_n) % g.tiles_m); }
   const int64_t b = t / ((int64_t)g.tiles_m * g.tiles_n);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * MM_BN;
   const bf16_t* Ag = g.A + b * g.sA;
@@ -648,6 +666,7 @@ static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   g.tiles_n = (int)((g.N + MM_BN - 1) / MM_BN);
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
   g.per_xcd = (int)((tiles + 7) / 8);
+  { const char* o = getenv("TSG_PSA_ORDER"); g.m_fastest = (o && o[0] == 'm') ? 1 : 0; }
   TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, PF, A_TR, B_TR, EXPB, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)MmGeom<BM>::LDS));
   hipLaunchKernelGGL((psa_mm<BM, PF, A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T),
@@ -697,7 +716,7 @@ struct PsaWs {
   size_t total;
 };
 
-constexpr int kChunks = 120;          // row chunks of the column statistics (workspace [B][kChunks][N] x 2)
+constexpr int kChunks = 240;          // row chunks of the column statistics (workspace [B][kChunks][N] x 2)
 
 static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, bool f32, bool bwd) {
   PsaWs w;
@@ -739,7 +758,7 @@ static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float*
     const int rpc = (int)((K + kChunks - 1) / kChunks);
     const int nch = (int)((K + rpc - 1) / rpc);                        // chunks that actually hold rows
     const int64_t nv = N / V;
-    hipLaunchKernelGGL((psa_colstat1_vec<T, V, 10>), dim3((unsigned)((nv + 127) / 128), (unsigned)nch, (unsigned)B),
+    hipLaunchKernelGGL((psa_colstat1_vec<T, V, 15>), dim3((unsigned)((nv + 127) / 128), (unsigned)nch, (unsigned)B),
                        dim3(128), 0, st, A, K, N, rpc, w.pm, w.pl);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL(psa_colstat2_wide, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(256), 0, st, w.pm, w.pl,
