@@ -95,11 +95,13 @@ class GraphedStep(object):
     `refresh_lr`) the optimizer step is part of the graph too; otherwise it runs eagerly after each replay, so the
     reference's per-iteration lr schedule (train.py:133-139) needs no special handling.
 
-    Warm-up and capture MUST share one stream (`GraphedStep.stream`): an autograd leaf's AccumulateGrad node runs on
-    the stream that was current when the parameter first entered a graph, so a warm-up on any other stream turns
-    every gradient hand-off of the captured backward into a cross-stream fork/join inside the capture.  On ROCm 7.2
-    the instantiated graph then loses ordering between branches (second replay: non-finite BN statistics and
-    gradients; same-stream capture is bit-stable against eager)."""
+    Warm-up, capture, replays and the eager optimizer MUST all run on one stream (`GraphedStep.stream`; bench.py wraps
+    the whole graphed section in it).  Measured on ROCm 7.2 at the bench shape (tools/debug_graph4.py):
+    whenever the eager warm-up ran on a stream other than the one the replays and the optimizer later use -- the
+    side-stream warm-up of PyTorch's CUDA-graphs recipe included, even with only the last warm-up step elsewhere -- the
+    SECOND replay produces non-finite output in the MIOpen 1x1 convolution of the global-context branch, then NaN
+    gradients everywhere; with one stream throughout (the default stream or any other) the replayed trajectory equals
+    the eager one.  State left behind by the eager warm-up in the convolution library is bound to the stream it ran on."""
 
     stream = None
 
@@ -293,10 +295,11 @@ def main():
     dominant = None
     all_kernels = None
     n_eager = max(args.warmup, 3) if use_graph else args.warmup        # capture needs warmed-up libraries
-    side = GraphedStep.capture_stream() if use_graph else None   # warm-up on the stream the capture will use
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+    # Graph mode: the eager warm-up, the capture, every replay and the optimizer run on ONE stream (GraphedStep.stream).
+    run_stream = GraphedStep.capture_stream() if use_graph else None
+    if run_stream is not None:
+        run_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(run_stream) if run_stream is not None else contextlib.nullcontext():
         for it in range(n_eager):
             probe = None
             if not args.no_kernel_timing and it == n_eager - 1:
@@ -307,29 +310,29 @@ def main():
                 dominant = probe.dominant()
                 all_kernels = probe.summary()
                 roof_probe = probe
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-    sync()
-    graphed = None
-    if use_graph:
-        graphed = GraphedStep(model, opt, imgs, gts, world, opt_inside=args.graph == 2)
-        for it in range(2):                                            # untimed replays
-            set_lr(opt, pol, n_eager + it)
-            loss = graphed()
         sync()
-    elif dominant is not None:
-        timer = K.KernelTimer(K.provider(), names=[dominant])
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        if graphed is not None:
-            set_lr(opt, pol, args.warmup + it)
-            loss = graphed()
-        else:
-            loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
-        if args.trace_loss and rank == 0:
-            print("step", it, "loss", float(loss.item()), "lr", opt.param_groups[0]["lr"], file=sys.stderr, flush=True)
-    sync()
-    dt = time.perf_counter() - t0
+        graphed = None
+        if use_graph:
+            graphed = GraphedStep(model, opt, imgs, gts, world, opt_inside=args.graph == 2)
+            for it in range(2):                                            # untimed replays
+                set_lr(opt, pol, n_eager + it)
+                loss = graphed()
+            sync()
+        elif dominant is not None:
+            timer = K.KernelTimer(K.provider(), names=[dominant])
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            if graphed is not None:
+                set_lr(opt, pol, args.warmup + it)
+                loss = graphed()
+            else:
+                loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
+            if args.trace_loss and rank == 0:
+                print("step", it, "loss", float(loss.item()), "lr", opt.param_groups[0]["lr"], file=sys.stderr, flush=True)
+        sync()
+        dt = time.perf_counter() - t0
+    if run_stream is not None:
+        torch.cuda.current_stream().wait_stream(run_stream)
     if timer is not None:
         timer.stop()
     elif dominant is not None:

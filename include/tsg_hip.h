@@ -435,6 +435,23 @@ int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* 
                        const int* blockmap_dev, int64_t nblocks, float scale, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Training pre-processing on the GPU — replaces TrainPre.__call__ of the reference's dataloaders
+ * (model/bisenet/cityscapes.bisenet.R18/dataloader.py:16-35) = furnace/utils/img_utils.py random_mirror (:138-143),
+ * random_scale (:110-117: cv2 INTER_LINEAR image / INTER_NEAREST label), normalize (:174-180),
+ * random_crop_pad_to_shape (:24-40, :60-75) and the transpose / float / long of datasets/BaseDataset.py:47-48,
+ * as one kernel: each output pixel of the padded crop is sampled straight from the uint8 source image.
+ *   imgs[i] uint8 [H][W][3], gts[i] uint8 [H][W] (device pointers, host array of n <= tsg_augment_max_samples());
+ *   geom[7*i..] = {H, W, SH, SW, flip, crop_y, crop_x}: SH = int(H*scale), SW = int(W*scale), crop position in the
+ *   scaled image (host-drawn with the reference's `random` call sequence);
+ *   out_img float [n][3][CH][CW] = (v/255 - mean[c]) / std[c], 0 in the padding; out_gt [n][CH][CW] int64 (TSG_I64) or
+ *   uint8 (TSG_U8), pad_label in the padding.
+ * ---------------------------------------------------------------------- */
+int tsg_augment_max_samples(void);
+int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, int n, int CH, int CW,
+                     const float* mean, const float* std, int pad_label, float* out_img, void* out_gt, int gt_type,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
  * Collectives of the hot path — replace the exchange steps of the reference's SyncBN / DDP:
  * furnace/legacy/sync_bn/syncbn.py:75-78 (ReduceAddCoalesced / Broadcast of [sum x, sum x^2]),
  * furnace/legacy/sync_bn/comm.py:57-132 (the master/slave pipes carrying them), and the

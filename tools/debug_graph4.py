@@ -52,18 +52,26 @@ del model, opt
 torch.cuda.empty_cache()
 
 model, opt, pol = make()
-side = {0: torch.cuda.current_stream(), 1: torch.cuda.Stream(), 2: bench.GraphedStep.capture_stream()}[a.side]
-if a.side == 1:
-    bench.GraphedStep.stream = torch.cuda.Stream()       # capture on a stream other than the warm-up's (the old behaviour)
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for it in range(a.warm):
-        bench.train_step(model, opt, imgs, gts, pol, it, 1)
-torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+Y = bench.GraphedStep.capture_stream()
+D = torch.cuda.current_stream()
+def warm(stream, its):
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        for it in its:
+            bench.train_step(model, opt, imgs, gts, pol, it, 1)
+    torch.cuda.current_stream().wait_stream(stream); torch.cuda.synchronize()
+if a.side == 0:   warm(D, range(a.warm))                                  # everything eager on the default stream
+elif a.side == 1: warm(torch.cuda.Stream(), range(a.warm))               # warm-up on X, capture on Y
+elif a.side == 2: warm(Y, range(a.warm))                                 # warm-up on Y, capture on Y
+elif a.side == 3: warm(D, range(1)); warm(Y, range(1, a.warm))           # first step (lazy state) on D, rest on Y
+elif a.side == 4: warm(Y, range(a.warm))                                 # as 2, and the replays + optimizer run on Y too
+elif a.side == 5: warm(Y, range(a.warm - 1)); warm(D, range(a.warm - 1, a.warm))   # last eager step on D
 gr = bench.GraphedStep(model, opt, imgs, gts, 1)
+run_stream = Y if a.side == 4 else D
 for it in range(a.steps):
-    bench.set_lr(opt, pol, a.warm + it)
-    gr.graph.replay(); torch.cuda.synchronize()
-    line = stats(model, gr.loss)
-    opt.step(); torch.cuda.synchronize()
+    with torch.cuda.stream(run_stream):
+        bench.set_lr(opt, pol, a.warm + it)
+        gr.graph.replay(); torch.cuda.synchronize()
+        line = stats(model, gr.loss)
+        opt.step(); torch.cuda.synchronize()
     print(f"[{a.tag}] step {it}: GRAPH {line}\n[{a.tag}]          EAGER {ref[it]}", flush=True)

@@ -1,0 +1,131 @@
+// The training pre-processing of the reference's dataloaders as ONE pass on the GPU.
+//
+// Restates TrainPre.__call__ (model/bisenet/cityscapes.bisenet.R18/dataloader.py:16-35; same in pspnet / psanet / dfn)
+// built from furnace/utils/img_utils.py:
+//   random_mirror (:138-143)              horizontal flip of image and label
+//   random_scale (:110-117)               sh = int(H * s), sw = int(W * s); image cv2.INTER_LINEAR, label cv2.INTER_NEAREST
+//   normalize (:174-180)                  (img / 255 - mean) / std
+//   random_crop_pad_to_shape (:24-40)     crop at crop_pos (clipped by the array), centred padding (pad_image_to_shape
+//                                         :60-75: margin = pad // 2 before, pad // 2 + pad % 2 after), 0 for the
+//                                         normalised image, 255 for the label
+//   .transpose(2, 0, 1) and BaseDataset.py:47-48 (.float() / .long())
+// The random draws (flip, scale, crop position) are made on the HOST with the reference's own call sequence on Python's
+// `random`, so a seeded run selects the same crops; they arrive here as per-sample parameters.
+//
+// cv2 semantics restated (cv2 itself is not in this image: parity with cv2's 11-bit fixed-point rounding of the uint8
+// resize is unpinned; the numpy oracle oracle/augment_ref.py follows the same formulas in float64):
+//   INTER_LINEAR: src = (dst + 0.5) * (in / out) - 0.5; i0 = floor(src); w = src - i0; i0 < 0 -> (0, w = 0);
+//                 i0 >= in - 1 -> (in - 1, w = 0); the uint8 result is the interpolated value rounded to nearest.
+//   INTER_NEAREST: src = min(floor(dst * (in / out)), in - 1).
+// One thread per output pixel: 4 taps x 3 bytes in, 3 floats + 1 label out; no intermediate image ever exists.
+#include "tsg_common.h"
+
+namespace tsg {
+
+constexpr int kAugMax = 16;          // samples per launch (parameters travel by value in the kernel arguments)
+
+struct AugSample {
+  const uint8_t* img;                // [H][W][3], channel order as the network expects it (BaseDataset.py:45 flips BGR)
+  const uint8_t* gt;                 // [H][W]
+  int H, W, SH, SW;                  // source size, scaled size
+  int flip;
+  int crop_y, crop_x;                // crop position in the scaled image
+  int top, left;                     // padding margins of the crop inside the output
+  int ch, cw;                        // rows / columns of the scaled image that the crop actually covers
+};
+
+struct AugBatch {
+  AugSample s[kAugMax];
+  int n;
+  int CH, CW;                        // output crop size
+  float mean[3], inv_std[3];
+  int pad_label;
+};
+
+__device__ __forceinline__ void lin_index(int dst, double scale, int in, int& i0, int& i1, float& w) {
+  const double src = ((double)dst + 0.5) * scale - 0.5;        // cv2 computes this in double, then narrows the weight
+  int s = (int)floor(src);
+  float f = (float)(src - (double)s);
+  if (s < 0) { s = 0; f = 0.f; }
+  if (s >= in - 1) { s = in - 1; f = 0.f; }
+  i0 = s; i1 = s + 1 < in ? s + 1 : in - 1; w = f;
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void augment_crop_k(AugBatch b, float* __restrict__ out_img, LT* __restrict__ out_gt) {
+  const int sidx = blockIdx.z;
+  const AugSample& p = b.s[sidx];
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  const int oy = blockIdx.y;
+  if (ox >= b.CW) return;
+  const int64_t plane = (int64_t)b.CH * b.CW;
+  float* oi = out_img + (int64_t)sidx * 3 * plane + (int64_t)oy * b.CW + ox;
+  LT* og = out_gt + (int64_t)sidx * plane + (int64_t)oy * b.CW + ox;
+  const int iy = oy - p.top, ix = ox - p.left;
+  if (iy < 0 || iy >= p.ch || ix < 0 || ix >= p.cw) {          // padding: 0 after normalisation, pad_label
+    oi[0] = 0.f; oi[plane] = 0.f; oi[2 * plane] = 0.f;
+    *og = (LT)b.pad_label;
+    return;
+  }
+  const int sy = p.crop_y + iy, sx = p.crop_x + ix;              // pixel of the (mirrored, scaled) image
+  const double fy = (double)p.H / (double)p.SH, fx = (double)p.W / (double)p.SW;
+  int y0, y1, x0, x1; float wy, wx;
+  lin_index(sy, fy, p.H, y0, y1, wy);
+  lin_index(sx, fx, p.W, x0, x1, wx);
+  int ny = (int)floor((double)sy * fy); if (ny > p.H - 1) ny = p.H - 1;
+  int nx = (int)floor((double)sx * fx); if (nx > p.W - 1) nx = p.W - 1;
+  if (p.flip) { x0 = p.W - 1 - x0; x1 = p.W - 1 - x1; nx = p.W - 1 - nx; }   // resize(flip(img)) == flip-indexed taps
+  const uint8_t* r0 = p.img + ((int64_t)y0 * p.W) * 3;
+  const uint8_t* r1 = p.img + ((int64_t)y1 * p.W) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = (float)r0[x0 * 3 + c], bb = (float)r0[x1 * 3 + c];
+    const float cc = (float)r1[x0 * 3 + c], d = (float)r1[x1 * 3 + c];
+    float v = (1.f - wy) * ((1.f - wx) * a + wx * bb) + wy * ((1.f - wx) * cc + wx * d);
+    v = floorf(v + 0.5f);                                        // the resized image is uint8 again
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    oi[c * plane] = (v / 255.0f - b.mean[c]) * b.inv_std[c];
+  }
+  *og = (LT)p.gt[(int64_t)ny * p.W + nx];
+}
+
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" {
+
+int tsg_augment_max_samples(void) { return kAugMax; }
+
+int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, int n, int CH, int CW,
+                     const float* mean, const float* std, int pad_label, float* out_img, void* out_gt, int gt_type,
+                     void* stream) {
+  if (!imgs || !gts || !geom || !mean || !std || !out_img || !out_gt) return TSG_E_NULL;
+  if (n < 1 || n > kAugMax || CH < 1 || CW < 1) return TSG_E_SHAPE;
+  if (gt_type != TSG_I64 && gt_type != TSG_U8) return TSG_E_DTYPE;
+  AugBatch b;
+  b.n = n; b.CH = CH; b.CW = CW; b.pad_label = pad_label;
+  for (int c = 0; c < 3; ++c) { b.mean[c] = mean[c]; b.inv_std[c] = 1.0f / std[c]; }
+  for (int i = 0; i < n; ++i) {
+    const int32_t* g = geom + 7 * i;                             // H, W, SH, SW, flip, crop_y, crop_x
+    AugSample& s = b.s[i];
+    s.img = (const uint8_t*)imgs[i]; s.gt = (const uint8_t*)gts[i];
+    if (!s.img || !s.gt) return TSG_E_NULL;
+    s.H = g[0]; s.W = g[1]; s.SH = g[2]; s.SW = g[3]; s.flip = g[4] != 0; s.crop_y = g[5]; s.crop_x = g[6];
+    if (s.H < 1 || s.W < 1 || s.SH < 1 || s.SW < 1 || s.crop_y < 0 || s.crop_x < 0 || s.crop_y >= s.SH || s.crop_x >= s.SW)
+      return TSG_E_SHAPE;                                        // img_utils.py:27-28 asserts the same
+    s.ch = s.SH - s.crop_y < CH ? s.SH - s.crop_y : CH;          // numpy slicing clips the crop at the array border
+    s.cw = s.SW - s.crop_x < CW ? s.SW - s.crop_x : CW;
+    s.top = (CH - s.ch) / 2;                                     // pad_image_to_shape: margin[0] = pad // 2
+    s.left = (CW - s.cw) / 2;
+  }
+  dim3 grid((unsigned)((CW + 255) / 256), (unsigned)CH, (unsigned)n);
+  if (gt_type == TSG_I64)
+    hipLaunchKernelGGL((augment_crop_k<int64_t>), grid, dim3(256), 0, (hipStream_t)stream, b, out_img, (int64_t*)out_gt);
+  else
+    hipLaunchKernelGGL((augment_crop_k<uint8_t>), grid, dim3(256), 0, (hipStream_t)stream, b, out_img, (uint8_t*)out_gt);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

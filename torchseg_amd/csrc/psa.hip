@@ -466,38 +466,75 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   // ---- staging maps: 16-byte chunks.  A tile = BM * 8 chunks (ACH per thread), B tile = 512 chunks (2 per thread)
   //   NT image [rows][8 chunks]: chunk id c -> row c >> 3, k-chunk c & 7
   //   TR image [64 k][cols / 8 chunks]: chunk id c -> k row c / (cols / 8), column chunk c % (cols / 8)
+  // Everything that does not depend on the K tile is computed once per thread here (the K loop is issue-bound:
+  // 64-bit index arithmetic and software bf16 rounding in it cost more cycles than its MFMAs).
+  // Loads are UNCONDITIONAL (per-lane predicates compile to divergent branches, ~40 of them per K tile): rows / columns /
+  // k positions outside the problem are clamped to the last valid chunk, i.e. they read real tensor data; the K tail is
+  // made exact by zeroing the B chunk (finite x 0), rows / columns beyond M / N are never stored.
   uint4 ra[PF][G::ACH], rb[PF][2];
+  const bf16_t* pa[G::ACH]; int ka[G::ACH], oa[G::ACH];                  // base pointer (k = 0), k inside the tile, LDS offset
+  const bf16_t* pb[2];      int kb[2],      ob[2];      bool vb[2];      // vb: column / row of B inside the problem
+  const int64_t sa_k = A_TR ? g.M : 1, sb_k = B_TR ? g.N : 1;            // elements per unit of k
+  const int Kd = (int)g.K;
+  const int ka_max = A_TR ? Kd - 1 : Kd - 8, kb_max = B_TR ? Kd - 1 : Kd - 8;
+#pragma unroll
+  for (int q = 0; q < G::ACH; ++q) {
+    const int c = tid + MM_T * q;
+    if (A_TR) {
+      const int kr = c / (BM / 8), mc = (c % (BM / 8)) * 8;
+      const int64_t m = (m0 + mc < g.M) ? m0 + mc : g.M - 8;
+      ka[q] = kr; pa[q] = Ag + m; oa[q] = kr * G::A_TR_ROW + mc;
+    } else {
+      const int mr = c >> 3, kc = (c & 7) * 8;
+      const int64_t m = (m0 + mr < g.M) ? m0 + mr : g.M - 1;
+      ka[q] = kc; pa[q] = Ag + m * g.K; oa[q] = mr * MM_NT_ROW + kc;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = tid + MM_T * q;
+    if (B_TR) {
+      const int kr = c >> 3, nc = (c & 7) * 8;
+      vb[q] = n0 + nc < g.N;
+      kb[q] = kr; pb[q] = Bg + (vb[q] ? n0 + nc : g.N - 8); ob[q] = kr * MM_B_TR_ROW + nc;
+    } else {
+      const int nr = c >> 3, kc = (c & 7) * 8;
+      vb[q] = n0 + nr < g.N;
+      kb[q] = kc; pb[q] = Bg + (vb[q] ? n0 + nr : g.N - 1) * g.K; ob[q] = nr * MM_NT_ROW + kc;
+    }
+  }
   float bl[2][8];                                       // EXPB 1: lse * log2e of the thread's B columns (fixed per block)
   if (EXPB == 1) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int c = tid + MM_T * q;
-      const int64_t n = n0 + (c & 7) * 8;
+      const int64_t n = n0 + ((tid + MM_T * q) & 7) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) bl[q][e] = (n + e < g.N) ? lse[n + e] * kLog2e : 0.f;
     }
   }
-  auto fetch = [&](uint4* qa, uint4* qb, int64_t k0) {
+  // Tiles are fetched in increasing order, so every chunk's pointer just advances by one tile (a 64-bit add); only the
+  // last, partial K tile takes the clamped path (K % 64 != 0: 3600 = 56 * 64 + 16).
+  const int64_t step_a = (int64_t)MM_BK * sa_k, step_b = (int64_t)MM_BK * sb_k;
 #pragma unroll
-    for (int q = 0; q < G::ACH; ++q) {
-      const int c = tid + MM_T * q;
-      if (A_TR) {
-        const int64_t k = k0 + c / (BM / 8), m = m0 + (c % (BM / 8)) * 8;
-        qa[q] = (k < g.K && m < g.M) ? ld16(Ag + k * g.M + m) : make_uint4(0, 0, 0, 0);
-      } else {
-        const int64_t m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
-        qa[q] = (k < g.K && m < g.M) ? ld16(Ag + m * g.K + k) : make_uint4(0, 0, 0, 0);
+  for (int q = 0; q < G::ACH; ++q) pa[q] += (int64_t)ka[q] * sa_k;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) pb[q] += (int64_t)kb[q] * sb_k;
+  auto fetch = [&](uint4* qa, uint4* qb, int k0) {
+    if (k0 + MM_BK <= Kd) {
+#pragma unroll
+      for (int q = 0; q < G::ACH; ++q) { qa[q] = ld16(pa[q]); pa[q] += step_a; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { qb[q] = ld16(pb[q]); pb[q] += step_b; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < G::ACH; ++q) {
+        const int over = k0 + ka[q] - ka_max;                  // > 0: this chunk lies beyond K, read the last valid one
+        qa[q] = ld16(pa[q] - (over > 0 ? (int64_t)over * sa_k : 0));
       }
-    }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = tid + MM_T * q;
-      if (B_TR) {
-        const int64_t k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
-        qb[q] = (k < g.K && n < g.N) ? ld16(Bg + k * g.N + n) : make_uint4(0, 0, 0, 0);
-      } else {
-        const int64_t n = n0 + (c >> 3), k = k0 + (c & 7) * 8;
-        qb[q] = (k < g.K && n < g.N) ? ld16(Bg + n * g.K + k) : make_uint4(0, 0, 0, 0);
+      for (int q = 0; q < 2; ++q) {
+        const int over = k0 + kb[q] - kb_max;
+        qb[q] = ld16(pb[q] - (over > 0 ? (int64_t)over * sb_k : 0));
       }
     }
   };
@@ -508,40 +545,30 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
     for (int i = 0; i < 4; ++i) {
       const float lo = exp2_fast(fmaf(__uint_as_float(w[i] << 16), kLog2e, -l2[2 * i]));
       const float hi = exp2_fast(fmaf(__uint_as_float(w[i] & 0xffff0000u), kLog2e, -l2[2 * i + 1]));
-      w[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+      w[i] = pack2_bf16(lo, hi);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   };
-  auto stash = [&](const uint4* qa, const uint4* qb, int stage, int64_t k0) {
+  auto stash = [&](const uint4* qa, const uint4* qb, int stage, int k0) {
     bf16_t* sa = lds + (size_t)stage * G::STAGE;
     bf16_t* sb = sa + G::A_ELEMS;
 #pragma unroll
-    for (int q = 0; q < G::ACH; ++q) {
-      const int c = tid + MM_T * q;
-      const int off = A_TR ? (c / (BM / 8)) * G::A_TR_ROW + (c % (BM / 8)) * 8 : (c >> 3) * MM_NT_ROW + (c & 7) * 8;
-      *reinterpret_cast<uint4*>(sa + off) = qa[q];
-    }
+    for (int q = 0; q < G::ACH; ++q) *reinterpret_cast<uint4*>(sa + oa[q]) = qa[q];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int c = tid + MM_T * q;
       uint4 v = qb[q];
+      const bool in = vb[q] && k0 + kb[q] < Kd;            // the K tail (and the padding) must be exact zeros, not exp(-lse)
       if (EXPB == 1) {
-        const int64_t k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
-        v = (k < g.K && n < g.N) ? expchunk(v, bl[q]) : make_uint4(0, 0, 0, 0);     // padding must stay 0, not exp(-lse)
+        v = expchunk(v, bl[q]);
       } else if (EXPB == 2) {
-        const int64_t n = n0 + (c >> 3), k = k0 + (c & 7) * 8;
-        if (k < g.K && n < g.N) {
-          float l2[8];
-          const float4 l0 = *reinterpret_cast<const float4*>(lse + k), l1 = *reinterpret_cast<const float4*>(lse + k + 4);
-          l2[0] = l0.x * kLog2e; l2[1] = l0.y * kLog2e; l2[2] = l0.z * kLog2e; l2[3] = l0.w * kLog2e;
-          l2[4] = l1.x * kLog2e; l2[5] = l1.y * kLog2e; l2[6] = l1.z * kLog2e; l2[7] = l1.w * kLog2e;
-          v = expchunk(v, l2);
-        } else {
-          v = make_uint4(0, 0, 0, 0);
-        }
+        const int k = k0 + kb[q] < kb_max ? k0 + kb[q] : kb_max;
+        const float4 l0 = *reinterpret_cast<const float4*>(lse + k), l1 = *reinterpret_cast<const float4*>(lse + k + 4);
+        const float l2[8] = {l0.x * kLog2e, l0.y * kLog2e, l0.z * kLog2e, l0.w * kLog2e,
+                             l1.x * kLog2e, l1.y * kLog2e, l1.z * kLog2e, l1.w * kLog2e};
+        v = expchunk(v, l2);
       }
-      const int off = B_TR ? (c >> 3) * MM_B_TR_ROW + (c & 7) * 8 : (c >> 3) * MM_NT_ROW + (c & 7) * 8;
-      *reinterpret_cast<uint4*>(sb + off) = v;
+      v.x = in ? v.x : 0u; v.y = in ? v.y : 0u; v.z = in ? v.z : 0u; v.w = in ? v.w : 0u;
+      *reinterpret_cast<uint4*>(sb + ob[q]) = v;
     }
   };
 
@@ -566,17 +593,16 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   stash(ra[0], rb[0], 0, 0);
 #pragma unroll
   for (int u = 1; u <= PF; ++u)
-    if (u < nk) fetch(ra[u % PF], rb[u % PF], (int64_t)u * MM_BK);
+    if (u < nk) fetch(ra[u % PF], rb[u % PF], u * MM_BK);
   for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int kt = kt0 + u;
       if (kt >= nk) break;
-      constexpr int dummy = 0; (void)dummy;
       const int s = (u + 1) % PF;                        // == (kt + 1) % PF: kt0 is a multiple of PF
       __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
-      if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (int64_t)(kt + 1) * MM_BK);
-      if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (int64_t)(kt + 1 + PF) * MM_BK);
+      if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (kt + 1) * MM_BK);
+      if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (kt + 1 + PF) * MM_BK);
       const bf16_t* sa = lds + (size_t)(kt & 1) * G::STAGE;
       const bf16_t* sb = sa + G::A_ELEMS;
 #pragma unroll
@@ -655,7 +681,7 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
     }
     uint32_t o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+    for (int e = 0; e < 4; ++e) o[e] = pack2_bf16(v[2 * e], v[2 * e + 1]);
     *reinterpret_cast<uint4*>(Cg + m * g.N + n) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }

@@ -34,6 +34,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> two bf16 in one word (low half = a), round to nearest even: v_cvt_pk_bf16_f32 on gfx950
+typedef __attribute__((ext_vector_type(2))) float tsg_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 tsg_bf16x2;
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+  const tsg_f32x2 f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, tsg_bf16x2));
+}
+
 // Vec<T>: one 16-byte global access worth of elements, unpacked to floats.
 template <typename T> struct Vec;
 

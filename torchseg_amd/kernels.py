@@ -506,6 +506,32 @@ class HipKernels:
                 "tsg_conv3x3_wrw")
         return dw
 
+    # ---- training pre-processing ---------------------------------------------------
+    def augment_crop(self, imgs, gts, geom, crop_hw, mean, std, pad_label=255, label_dtype=torch.int64):
+        """imgs[i] uint8 [H,W,3], gts[i] uint8 [H,W] on the GPU; geom int32 numpy [n,7] = H, W, SH, SW, flip, crop_y,
+        crop_x -> (float32 [n,3,CH,CW], labels [n,CH,CW])"""
+        import numpy as np
+        n = len(imgs)
+        CH, CW = int(crop_hw[0]), int(crop_hw[1])
+        dev = imgs[0].device
+        for t in list(imgs) + list(gts):
+            if t.dtype != torch.uint8 or not t.is_contiguous() or not t.is_cuda:
+                raise L.TsgError("augment_crop takes contiguous uint8 tensors on the GPU")
+        out = torch.empty((n, 3, CH, CW), dtype=torch.float32, device=dev)
+        lab = torch.empty((n, CH, CW), dtype=label_dtype, device=dev)
+        cap = self.lib.tsg_augment_max_samples()
+        geom = np.ascontiguousarray(geom, dtype=np.int32).reshape(n, 7)
+        m = np.ascontiguousarray(mean, dtype=np.float32)
+        s = np.ascontiguousarray(std, dtype=np.float32)
+        for i0 in range(0, n, cap):
+            k = min(cap, n - i0)
+            pi = (C.c_void_p * k)(*[imgs[i0 + j].data_ptr() for j in range(k)])
+            pg = (C.c_void_p * k)(*[gts[i0 + j].data_ptr() for j in range(k)])
+            L.check(self.lib.tsg_augment_crop(pi, pg, geom[i0:i0 + k].ctypes.data, k, CH, CW, m.ctypes.data, s.ctypes.data,
+                                              int(pad_label), out[i0:].data_ptr(), lab[i0:].data_ptr(), _label_code(lab),
+                                              L.stream_ptr(out)), "tsg_augment_crop")
+        return out, lab
+
     # ---- evaluation metric ----------------------------------------------------
     def confusion_map(self, pred, gt, n_cl, out=None):
         """pred, gt: class-index maps (int64 or uint8, same numel) -> int64 [n_cl*n_cl + 3], accumulated into `out`"""
