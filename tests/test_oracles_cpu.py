@@ -121,3 +121,28 @@ def test_metric_host_mirror_scores_and_cpu_refusal():
     if not torch.cuda.is_available():
         with pytest.raises(Exception):
             metric.hist_info(19, np.zeros((4, 4), np.int64), np.zeros((4, 4), np.int64))
+
+
+def test_augment_oracle_geometry_matches_torch_resampling():
+    """oracle/augment_ref.py restates cv2.resize from OpenCV's documented geometry (cv2 is not installed).  The same
+    geometry is what torch implements: INTER_LINEAR == F.interpolate(bilinear, align_corners=False, no antialias) on
+    float data, INTER_NEAREST == torch 'nearest' (floor(dst * in / out)).  Pin the oracle's float taps to torch."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import augment_ref as R
+    rng = np.random.RandomState(3)
+    for (h, w, sh, sw) in [(20, 30, 35, 52), (20, 30, 10, 15), (17, 23, 17, 40), (8, 8, 3, 5)]:
+        img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].double()
+        want = F.interpolate(t, size=(sh, sw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        got = R.resize_linear_u8(img, sh, sw).astype(np.float64)
+        assert np.abs(got - np.clip(np.floor(want + 0.5), 0, 255)).max() <= 1.0        # equal up to .5 ties
+        assert (got != np.clip(np.floor(want + 0.5), 0, 255)).mean() < 1e-2      # float32 weight vs float64: .5 ties only
+        gt = rng.randint(0, 19, size=(h, w)).astype(np.uint8)
+        wantn = F.interpolate(torch.from_numpy(gt)[None, None].float(), size=(sh, sw), mode="nearest")[0, 0].numpy()
+        assert np.array_equal(R.resize_nearest(gt, sh, sw), wantn.astype(np.uint8))
+    # crop + pad bookkeeping of random_crop_pad_to_shape / pad_image_to_shape (img_utils.py:24-75)
+    a = np.arange(5 * 7).reshape(5, 7)
+    p = R.pad_to_shape(a, (8, 10), 255)
+    assert p.shape == (8, 10) and p[1, 1] == a[0, 0] and p[0, 0] == 255 and p[-2, -2] == 255 and p[5, 7] == a[4, 6]

@@ -38,8 +38,9 @@ struct AugBatch {
   AugSample s[kAugMax];
   int n;
   int CH, CW;                        // output crop size
-  float mean[3], inv_std[3];
+  float mean[3], inv_std[3], pad_img[3];
   int pad_label;
+  int with_gt;
 };
 
 __device__ __forceinline__ void lin_index(int dst, double scale, int in, int& i0, int& i1, float& w) {
@@ -60,11 +61,11 @@ __global__ __launch_bounds__(256) void augment_crop_k(AugBatch b, float* __restr
   if (ox >= b.CW) return;
   const int64_t plane = (int64_t)b.CH * b.CW;
   float* oi = out_img + (int64_t)sidx * 3 * plane + (int64_t)oy * b.CW + ox;
-  LT* og = out_gt + (int64_t)sidx * plane + (int64_t)oy * b.CW + ox;
+  LT* og = b.with_gt ? out_gt + (int64_t)sidx * plane + (int64_t)oy * b.CW + ox : nullptr;
   const int iy = oy - p.top, ix = ox - p.left;
   if (iy < 0 || iy >= p.ch || ix < 0 || ix >= p.cw) {          // padding: 0 after normalisation, pad_label
-    oi[0] = 0.f; oi[plane] = 0.f; oi[2 * plane] = 0.f;
-    *og = (LT)b.pad_label;
+    oi[0] = b.pad_img[0]; oi[plane] = b.pad_img[1]; oi[2 * plane] = b.pad_img[2];
+    if (og) *og = (LT)b.pad_label;
     return;
   }
   const int sy = p.crop_y + iy, sx = p.crop_x + ix;              // pixel of the (mirrored, scaled) image
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void augment_crop_k(AugBatch b, float* __restr
     v = fminf(fmaxf(v, 0.f), 255.f);
     oi[c * plane] = (v / 255.0f - b.mean[c]) * b.inv_std[c];
   }
-  *og = (LT)p.gt[(int64_t)ny * p.W + nx];
+  if (og) *og = (LT)p.gt[(int64_t)ny * p.W + nx];
 }
 
 }  // namespace tsg
@@ -98,19 +99,24 @@ extern "C" {
 int tsg_augment_max_samples(void) { return kAugMax; }
 
 int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, int n, int CH, int CW,
-                     const float* mean, const float* std, int pad_label, float* out_img, void* out_gt, int gt_type,
-                     void* stream) {
-  if (!imgs || !gts || !geom || !mean || !std || !out_img || !out_gt) return TSG_E_NULL;
+                     const float* mean, const float* std, float pad_pixel, int pad_label, float* out_img, void* out_gt,
+                     int gt_type, void* stream) {
+  if (!imgs || !geom || !mean || !std || !out_img) return TSG_E_NULL;
+  if ((gts == nullptr) != (out_gt == nullptr)) return TSG_E_NULL;
   if (n < 1 || n > kAugMax || CH < 1 || CW < 1) return TSG_E_SHAPE;
-  if (gt_type != TSG_I64 && gt_type != TSG_U8) return TSG_E_DTYPE;
+  if (gts && gt_type != TSG_I64 && gt_type != TSG_U8) return TSG_E_DTYPE;
   AugBatch b;
   b.n = n; b.CH = CH; b.CW = CW; b.pad_label = pad_label;
-  for (int c = 0; c < 3; ++c) { b.mean[c] = mean[c]; b.inv_std[c] = 1.0f / std[c]; }
+  b.with_gt = gts != nullptr;
+  for (int c = 0; c < 3; ++c) {
+    b.mean[c] = mean[c]; b.inv_std[c] = 1.0f / std[c];
+    b.pad_img[c] = pad_pixel < 0.f ? 0.f : (pad_pixel / 255.0f - mean[c]) * b.inv_std[c];
+  }
   for (int i = 0; i < n; ++i) {
     const int32_t* g = geom + 7 * i;                             // H, W, SH, SW, flip, crop_y, crop_x
     AugSample& s = b.s[i];
-    s.img = (const uint8_t*)imgs[i]; s.gt = (const uint8_t*)gts[i];
-    if (!s.img || !s.gt) return TSG_E_NULL;
+    s.img = (const uint8_t*)imgs[i]; s.gt = gts ? (const uint8_t*)gts[i] : nullptr;
+    if (!s.img || (gts && !s.gt)) return TSG_E_NULL;
     s.H = g[0]; s.W = g[1]; s.SH = g[2]; s.SW = g[3]; s.flip = g[4] != 0; s.crop_y = g[5]; s.crop_x = g[6];
     if (s.H < 1 || s.W < 1 || s.SH < 1 || s.SW < 1 || s.crop_y < 0 || s.crop_x < 0 || s.crop_y >= s.SH || s.crop_x >= s.SW)
       return TSG_E_SHAPE;                                        // img_utils.py:27-28 asserts the same
@@ -120,7 +126,7 @@ int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int3
     s.left = (CW - s.cw) / 2;
   }
   dim3 grid((unsigned)((CW + 255) / 256), (unsigned)CH, (unsigned)n);
-  if (gt_type == TSG_I64)
+  if (gt_type == TSG_I64 || !gts)
     hipLaunchKernelGGL((augment_crop_k<int64_t>), grid, dim3(256), 0, (hipStream_t)stream, b, out_img, (int64_t*)out_gt);
   else
     hipLaunchKernelGGL((augment_crop_k<uint8_t>), grid, dim3(256), 0, (hipStream_t)stream, b, out_img, (uint8_t*)out_gt);

@@ -379,6 +379,41 @@ static int grid_for(int64_t work) {
 
 using namespace tsg;
 
+// Half-pixel-centre bilinear resize (cv2.resize INTER_LINEAR on float data == F.interpolate(align_corners=False), no
+// antialiasing): what the evaluator applies to the class scores of every scale (furnace/engine/evaluator.py:250-252:
+// cv2.resize(score, (ori_cols, ori_rows), interpolation=cv2.INTER_LINEAR)).  src = (dst + 0.5) * in / out - 0.5,
+// i0 = floor(src), border taps clamped with weight 0 (OpenCV resize.cpp).  Planar [NC, IH, IW] -> [NC, OH, OW]; up- or
+// down-sampling.  `accumulate` adds into y (the sum over scales of sliding_eval, evaluator.py:196-199).
+__device__ __forceinline__ void hp_index(int dst, double scale, int in, int& i0, int& i1, float& w) {
+  const double src = ((double)dst + 0.5) * scale - 0.5;
+  int s = (int)floor(src);
+  float f = (float)(src - (double)s);
+  if (s < 0) { s = 0; f = 0.f; }
+  if (s >= in - 1) { s = in - 1; f = 0.f; }
+  i0 = s; i1 = s + 1 < in ? s + 1 : in - 1; w = f;
+}
+
+template <typename T, bool ACC>
+__global__ __launch_bounds__(kT) void resize_hp_k(const T* __restrict__ x, float* __restrict__ y, int64_t NC, int IH,
+                                                  int IW, int OH, int OW) {
+  const double sy = (double)IH / (double)OH, sx = (double)IW / (double)OW;
+  const int64_t total = NC * OH * (int64_t)OW;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t nc = t / OH;
+    int y0, y1, x0, x1; float wy, wx;
+    hp_index(oy, sy, IH, y0, y1, wy);
+    hp_index(ox, sx, IW, x0, x1, wx);
+    const T* p = x + nc * IH * (int64_t)IW;
+    const float a = ld1<T>(p + (int64_t)y0 * IW + x0), b = ld1<T>(p + (int64_t)y0 * IW + x1);
+    const float c = ld1<T>(p + (int64_t)y1 * IW + x0), d = ld1<T>(p + (int64_t)y1 * IW + x1);
+    const float v = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
+    y[i] = ACC ? y[i] + v : v;
+  }
+}
+
 extern "C" {
 
 static int up_fwd_launch(const void* x, const void* add, int add_mode, void* y, int dtype, int64_t NC,
@@ -528,6 +563,21 @@ int tsg_upsample_nearest_fwd(const void* x, void* y, int elem_bytes, int64_t NC,
     case 8: GO(8); break;
     default: return TSG_E_DTYPE;
   }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_resize_bilinear_hp(const void* x, float* y, int dtype, int64_t NC, int IH, int IW, int OH, int OW,
+                           int accumulate, void* stream) {
+  if (!x || !y) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (NC <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return TSG_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(NC * OH * (int64_t)OW);
+#define GO(T, A) hipLaunchKernelGGL((resize_hp_k<T, A>), dim3(grid), dim3(kT), 0, st, (const T*)x, y, NC, IH, IW, OH, OW)
+  if (dtype == TSG_F32) { if (accumulate) GO(float, true); else GO(float, false); }
+  else { if (accumulate) GO(bf16_t, true); else GO(bf16_t, false); }
 #undef GO
   TSG_CHECK_LAUNCH();
   return 0;

@@ -507,18 +507,19 @@ class HipKernels:
         return dw
 
     # ---- training pre-processing ---------------------------------------------------
-    def augment_crop(self, imgs, gts, geom, crop_hw, mean, std, pad_label=255, label_dtype=torch.int64):
-        """imgs[i] uint8 [H,W,3], gts[i] uint8 [H,W] on the GPU; geom int32 numpy [n,7] = H, W, SH, SW, flip, crop_y,
-        crop_x -> (float32 [n,3,CH,CW], labels [n,CH,CW])"""
+    def augment_crop(self, imgs, gts, geom, crop_hw, mean, std, pad_label=255, label_dtype=torch.int64, pad_pixel=-1.0):
+        """imgs[i] uint8 [H,W,3], gts[i] uint8 [H,W] (or gts=None) on the GPU; geom int32 numpy [n,7] = H, W, SH, SW, flip,
+        crop_y, crop_x -> (float32 [n,3,CH,CW], labels [n,CH,CW] or None).  pad_pixel < 0: the normalised image is padded
+        with 0 (TrainPre); >= 0: the raw image is padded with that value (evaluator)."""
         import numpy as np
         n = len(imgs)
         CH, CW = int(crop_hw[0]), int(crop_hw[1])
         dev = imgs[0].device
-        for t in list(imgs) + list(gts):
+        for t in list(imgs) + list(gts or []):
             if t.dtype != torch.uint8 or not t.is_contiguous() or not t.is_cuda:
                 raise L.TsgError("augment_crop takes contiguous uint8 tensors on the GPU")
         out = torch.empty((n, 3, CH, CW), dtype=torch.float32, device=dev)
-        lab = torch.empty((n, CH, CW), dtype=label_dtype, device=dev)
+        lab = torch.empty((n, CH, CW), dtype=label_dtype, device=dev) if gts is not None else None
         cap = self.lib.tsg_augment_max_samples()
         geom = np.ascontiguousarray(geom, dtype=np.int32).reshape(n, 7)
         m = np.ascontiguousarray(mean, dtype=np.float32)
@@ -526,11 +527,25 @@ class HipKernels:
         for i0 in range(0, n, cap):
             k = min(cap, n - i0)
             pi = (C.c_void_p * k)(*[imgs[i0 + j].data_ptr() for j in range(k)])
-            pg = (C.c_void_p * k)(*[gts[i0 + j].data_ptr() for j in range(k)])
+            pg = (C.c_void_p * k)(*[gts[i0 + j].data_ptr() for j in range(k)]) if gts is not None else None
             L.check(self.lib.tsg_augment_crop(pi, pg, geom[i0:i0 + k].ctypes.data, k, CH, CW, m.ctypes.data, s.ctypes.data,
-                                              int(pad_label), out[i0:].data_ptr(), lab[i0:].data_ptr(), _label_code(lab),
+                                              float(pad_pixel), int(pad_label), out[i0:].data_ptr(),
+                                              lab[i0:].data_ptr() if lab is not None else None,
+                                              _label_code(lab) if lab is not None else L.I64,
                                               L.stream_ptr(out)), "tsg_augment_crop")
         return out, lab
+
+    def resize_bilinear_hp(self, x, OH, OW, out=None, accumulate=False):
+        """x [..., IH, IW] f32 / bf16 contiguous -> fp32 [..., OH, OW], half-pixel centres (cv2 INTER_LINEAR on float data)"""
+        _require_contiguous(x)
+        IH, IW = x.shape[-2], x.shape[-1]
+        NC = x.numel() // (IH * IW)
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-2]) + (OH, OW), dtype=torch.float32, device=x.device)
+            accumulate = False
+        L.check(self.lib.tsg_resize_bilinear_hp(x.data_ptr(), out.data_ptr(), L.dtype_code(x), NC, IH, IW, int(OH), int(OW),
+                                                int(accumulate), L.stream_ptr(x)), "tsg_resize_bilinear_hp")
+        return out
 
     # ---- evaluation metric ----------------------------------------------------
     def confusion_map(self, pred, gt, n_cl, out=None):
