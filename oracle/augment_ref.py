@@ -16,8 +16,14 @@ import random
 import numpy as np
 
 
+def _cv_scale(n_in, n_out):
+    """OpenCV derives the source step as 1 / inv_scale with inv_scale = dsize / ssize (resize.cpp), both in double; the
+    double rounding matters exactly where dst * in / out is an integer (e.g. 7 * 20 / 35: 3.9999999999999996 -> 3)."""
+    return 1.0 / (float(n_out) / float(n_in))
+
+
 def _lin_taps(n_in, n_out):
-    scale = float(n_in) / float(n_out)
+    scale = _cv_scale(n_in, n_out)
     src = (np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5
     i0 = np.floor(src).astype(np.int64)
     w = (src - i0).astype(np.float32).astype(np.float64)      # cv2 keeps the weight in float
@@ -29,8 +35,9 @@ def _lin_taps(n_in, n_out):
     return i0, i1, w
 
 
-def resize_linear_u8(img, sh, sw):
-    """cv2.resize(img, (sw, sh), interpolation=cv2.INTER_LINEAR) for an HWC uint8 image (float geometry, see header)."""
+def resize_linear_u8(img, sh, sw, rounded=True):
+    """cv2.resize(img, (sw, sh), interpolation=cv2.INTER_LINEAR) for an HWC uint8 image (float geometry, see header);
+    rounded=False returns the interpolated values before the uint8 rounding."""
     y0, y1, wy = _lin_taps(img.shape[0], sh)
     x0, x1, wx = _lin_taps(img.shape[1], sw)
     f = img.astype(np.float64)
@@ -38,13 +45,15 @@ def resize_linear_u8(img, sh, sw):
     top = (1 - wx) * f[y0][:, x0] + wx * f[y0][:, x1]
     bot = (1 - wx) * f[y1][:, x0] + wx * f[y1][:, x1]
     v = (1 - wy) * top + wy * bot
+    if not rounded:
+        return v
     return np.clip(np.floor(v + 0.5), 0, 255).astype(np.uint8)
 
 
 def resize_nearest(gt, sh, sw):
     """cv2.resize(gt, (sw, sh), interpolation=cv2.INTER_NEAREST)."""
-    iy = np.minimum(np.floor(np.arange(sh) * (float(gt.shape[0]) / sh)).astype(np.int64), gt.shape[0] - 1)
-    ix = np.minimum(np.floor(np.arange(sw) * (float(gt.shape[1]) / sw)).astype(np.int64), gt.shape[1] - 1)
+    iy = np.minimum(np.floor(np.arange(sh) * _cv_scale(gt.shape[0], sh)).astype(np.int64), gt.shape[0] - 1)
+    ix = np.minimum(np.floor(np.arange(sw) * _cv_scale(gt.shape[1], sw)).astype(np.int64), gt.shape[1] - 1)
     return gt[iy][:, ix]
 
 

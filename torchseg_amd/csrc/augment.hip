@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void augment_crop_k(AugBatch b, float* __restr
     return;
   }
   const int sy = p.crop_y + iy, sx = p.crop_x + ix;              // pixel of the (mirrored, scaled) image
-  const double fy = (double)p.H / (double)p.SH, fx = (double)p.W / (double)p.SW;
+  // OpenCV's source step: 1 / inv_scale with inv_scale = dsize / ssize, both double (resize.cpp)
+  const double fy = 1.0 / ((double)p.SH / (double)p.H), fx = 1.0 / ((double)p.SW / (double)p.W);
   int y0, y1, x0, x1; float wy, wx;
   lin_index(sy, fy, p.H, y0, y1, wy);
   lin_index(sx, fx, p.W, x0, x1, wx);

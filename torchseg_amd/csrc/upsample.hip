@@ -396,7 +396,7 @@ __device__ __forceinline__ void hp_index(int dst, double scale, int in, int& i0,
 template <typename T, bool ACC>
 __global__ __launch_bounds__(kT) void resize_hp_k(const T* __restrict__ x, float* __restrict__ y, int64_t NC, int IH,
                                                   int IW, int OH, int OW) {
-  const double sy = (double)IH / (double)OH, sx = (double)IW / (double)OW;
+  const double sy = 1.0 / ((double)OH / (double)IH), sx = 1.0 / ((double)OW / (double)IW);   // as OpenCV forms it
   const int64_t total = NC * OH * (int64_t)OW;
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
     const int ox = (int)(i % OW);
