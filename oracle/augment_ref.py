@@ -17,8 +17,7 @@ import numpy as np
 
 
 def _cv_scale(n_in, n_out):
-    """OpenCV derives the source step as 1 / inv_scale with inv_scale = dsize / ssize (resize.cpp), both in double; the
-    double rounding matters exactly where dst * in / out is an integer (e.g. 7 * 20 / 35: 3.9999999999999996 -> 3)."""
+    """OpenCV derives the source step as 1 / inv_scale with inv_scale = dsize / ssize (resize.cpp), both in double."""
     return 1.0 / (float(n_out) / float(n_in))
 
 
