@@ -454,9 +454,9 @@ int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* 
  *   may be NULL (evaluation: image only).
  * ---------------------------------------------------------------------- */
 int tsg_augment_max_samples(void);
-int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, int n, int CH, int CW,
-                     const float* mean, const float* std, float pad_pixel, int pad_label, float* out_img, void* out_gt,
-                     int gt_type, void* stream);
+int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, const double* inv_scale, int n,
+                     int CH, int CW, const float* mean, const float* std, float pad_pixel, int pad_label, float* out_img,
+                     void* out_gt, int gt_type, void* stream);
 
 /* ------------------------------------------------------------------------
  * Collectives of the hot path — replace the exchange steps of the reference's SyncBN / DDP:

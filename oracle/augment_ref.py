@@ -21,8 +21,8 @@ def _cv_scale(n_in, n_out):
     return 1.0 / (float(n_out) / float(n_in))
 
 
-def _lin_taps(n_in, n_out):
-    scale = _cv_scale(n_in, n_out)
+def _lin_taps(n_in, n_out, inv_scale=None):
+    scale = _cv_scale(n_in, n_out) if inv_scale is None else 1.0 / float(inv_scale)
     src = (np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5
     i0 = np.floor(src).astype(np.int64)
     w = (src - i0).astype(np.float32).astype(np.float64)      # cv2 keeps the weight in float
@@ -34,11 +34,11 @@ def _lin_taps(n_in, n_out):
     return i0, i1, w
 
 
-def resize_linear_u8(img, sh, sw, rounded=True):
+def resize_linear_u8(img, sh, sw, rounded=True, inv_scale=None):
     """cv2.resize(img, (sw, sh), interpolation=cv2.INTER_LINEAR) for an HWC uint8 image (float geometry, see header);
     rounded=False returns the interpolated values before the uint8 rounding."""
-    y0, y1, wy = _lin_taps(img.shape[0], sh)
-    x0, x1, wx = _lin_taps(img.shape[1], sw)
+    y0, y1, wy = _lin_taps(img.shape[0], sh, None if inv_scale is None else inv_scale[0])
+    x0, x1, wx = _lin_taps(img.shape[1], sw, None if inv_scale is None else inv_scale[1])
     f = img.astype(np.float64)
     wy = wy[:, None, None]; wx = wx[None, :, None]
     top = (1 - wx) * f[y0][:, x0] + wx * f[y0][:, x1]

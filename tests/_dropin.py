@@ -15,11 +15,11 @@ def have_reference():
     return os.path.isdir(os.path.join(REF, "model"))
 
 
-def stage(tmp_path, family, exp):
+def stage(tmp_path, family, exp, files=("config.py", "network.py")):
     base = os.path.join(str(tmp_path), "TorchSeg")
     exp_dir = os.path.join(base, "model", family, exp)
     os.makedirs(exp_dir, exist_ok=True)
-    for f in ("config.py", "network.py"):
+    for f in files:
         shutil.copy(os.path.join(REF, "model", family, exp, f), exp_dir)   # test-time copy only, never committed
     link = os.path.join(base, "furnace")
     if not os.path.exists(link):
@@ -29,7 +29,11 @@ def stage(tmp_path, family, exp):
 
 def run_in(exp_dir, script, timeout=600):
     env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "torchseg_amd", "shims")])
+    paths = [ROOT, os.path.join(ROOT, "torchseg_amd", "shims")]
+    import importlib.util
+    if importlib.util.find_spec("cv2") is None:                 # the stand-in must never shadow a real OpenCV
+        paths.append(os.path.join(ROOT, "torchseg_amd", "shims_optional"))
+    env["PYTHONPATH"] = os.pathsep.join(paths)
     r = subprocess.run([sys.executable, "-c", script], cwd=exp_dir, env=env, capture_output=True,
                        text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]

@@ -225,3 +225,100 @@ def test_checkpoints_interchange_with_reference_engine(tmp_path):
         assert a[k] == b[k], (k, a[k], b[k])
     c = run(_CKPT_REF_READ, our_ckpt, ours=False)
     assert c["mom_shapes"] == a["mom_shapes"] and c["lrs"] == a["lrs"]
+
+
+_IMPORTS = r'''
+import ast, importlib, json, sys
+from config import config                         # puts <TorchSeg>/furnace on sys.path, as the scripts do first
+missing = []
+for script in ("train.py", "eval.py", "dataloader.py"):
+    tree = ast.parse(open(script).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ImportFrom) and node.level == 0:
+            if node.module.split(".")[0] in ("tools",):      # tools/benchmark of the .speed variants: out of scope
+                continue
+            try:
+                mod = importlib.import_module(node.module)
+            except ImportError as e:
+                if node.module.startswith("apex"):
+                    raise
+                missing.append("%s: import %s (%s)" % (script, node.module, e)); continue
+            for a in node.names:
+                if a.name != "*" and not hasattr(mod, a.name):
+                    try:
+                        importlib.import_module(node.module + "." + a.name)
+                    except ImportError:
+                        missing.append("%s: from %s import %s" % (script, node.module, a.name))
+        elif isinstance(node, ast.Import):
+            for a in node.names:
+                try:
+                    importlib.import_module(a.name)
+                except ImportError as e:
+                    missing.append("%s: import %s (%s)" % (script, a.name, e))
+print(json.dumps(missing))
+'''
+
+
+@pytest.mark.parametrize("family,exp", [("bisenet", "cityscapes.bisenet.R18"), ("dfn", "cityscapes.dfn.R101_v1c"),
+                                        ("pspnet", "ade.pspnet.R50_v1c"), ("psanet", "ade.psanet.R50_v1c")])
+def test_every_import_of_the_unchanged_scripts_resolves(tmp_path, family, exp):
+    """INTEGRATION.md's drop-in step must not end in an ImportError: every `import` / `from ... import name` of the
+    UNCHANGED train.py, eval.py and dataloader.py of each family resolves against our furnace/ (+ the apex / easydict
+    shims, + the cv2 stand-in only because this image has no OpenCV)."""
+    files = [f for f in ("config.py", "network.py", "train.py", "eval.py", "dataloader.py")
+             if os.path.exists(os.path.join("/root/reference/model", family, exp, f))]
+    d = stage(tmp_path, family, exp, files=files)
+    missing = json.loads(run_in(d, _IMPORTS).strip().splitlines()[-1])
+    assert not missing, missing
+
+
+_TRAINPRE = r'''
+import json, random, numpy as np
+from config import config
+from dataloader import TrainPre                   # the UNCHANGED reference class, running on OUR utils.img_utils
+sys_path_ok = True
+rng = np.random.RandomState(0)
+img = rng.randint(0, 256, size=(96, 160, 3)).astype(np.uint8)
+gt = rng.randint(0, 19, size=(96, 160)).astype(np.uint8)
+config.image_height, config.image_width = 64, 80
+config.train_scale_array = [0.75, 1.0, 1.5]
+pre = TrainPre(config.image_mean, config.image_std)
+random.seed(3)
+p_img, p_gt, extra = pre(img, gt)
+from oracle import augment_ref as R
+random.seed(3)
+par = R.draw_params(img.shape[:2], config.train_scale_array, (64, 80))
+w_img, w_gt = R.train_pre(img, gt, par, config.image_mean, config.image_std, (64, 80))
+print(json.dumps(dict(shape=list(p_img.shape), gt_equal=bool(np.array_equal(p_gt, w_gt)),
+                      frac_off=float((np.abs(p_img - w_img) > 1e-5).mean()), max_off=float(np.abs(p_img - w_img).max()))))
+'''
+
+
+def test_unchanged_trainpre_runs_on_our_img_utils_and_equals_the_oracle(tmp_path):
+    """The reference's own TrainPre (bisenet dataloader.py:11-35), unchanged, on our utils.img_utils: same sample as the
+    step-by-step oracle the GPU pipeline is tested against (labels equal; image equal up to uint8 .5 ties)."""
+    d = stage(tmp_path, "bisenet", "cityscapes.bisenet.R18", files=("config.py", "network.py", "dataloader.py"))
+    out = json.loads(run_in(d, _TRAINPRE).strip().splitlines()[-1])
+    assert out["shape"] == [3, 64, 80] and out["gt_equal"]
+    assert out["frac_off"] <= 1e-3 and out["max_off"] <= (1 / 255) / 0.224 + 1e-5
+
+
+def test_dataset_tables_match_the_reference(tmp_path):
+    d = stage(tmp_path, "bisenet", "cityscapes.bisenet.R18")
+    script = r"""
+import importlib.util, json, sys
+from config import config
+from datasets import Cityscapes, VOC
+def ref(path, name):
+    src = open(path).read().replace("from datasets.BaseDataset import BaseDataset", "BaseDataset = object")
+    ns = {}
+    exec(compile(src.split("if __name__")[0], path, "exec"), ns)
+    return ns[name]
+RC = ref("/root/reference/furnace/datasets/cityscapes/cityscapes.py", "Cityscapes")
+RV = ref("/root/reference/furnace/datasets/voc/voc.py", "VOC")
+print(json.dumps(dict(city=Cityscapes.get_class_colors() == RC.get_class_colors() and Cityscapes.get_class_names() == RC.get_class_names()
+                           and Cityscapes.trans_labels == RC.trans_labels,
+                      voc=VOC.get_class_colors() == RV.get_class_colors() and VOC.get_class_names() == RV.get_class_names())))
+"""
+    out = json.loads(run_in(d, script).strip().splitlines()[-1])
+    assert out == {"city": True, "voc": True}

@@ -1,0 +1,84 @@
+"""GPU parity of the evaluator: sliding windows, multi-scale, flip TTA, score resize and the fused
+arg-max confusion matrix, against oracle/evaluator_ref.py (furnace/engine/evaluator.py:186-298 restated in numpy)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import evaluator_ref as R
+
+pytestmark = pytest.mark.gpu
+MEAN, STD = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+C = 7
+
+
+class TinySeg(nn.Module):
+    """A network with the reference's eval contract: [n,3,h,w] -> log-probabilities [n,C,h,w] (network.py:111)."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 12, 3, padding=1)
+        self.c2 = nn.Conv2d(12, C, 3, padding=2, dilation=2)
+
+    def forward(self, x):
+        return F.log_softmax(self.c2(torch.tanh(self.c1(x))), dim=1)
+
+
+def _setup(cuda, scales, flip):
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    from engine.evaluator import Evaluator
+    torch.manual_seed(5)
+    net = TinySeg()
+    ev = Evaluator(None, C, MEAN, STD, None, scales, flip, [0])
+    ev.val_func = TinySeg().to(cuda)
+    ev.val_func.load_state_dict(net.state_dict())
+    return net, ev
+
+
+@pytest.mark.parametrize("hw,crop,scales,flip", [
+    ((70, 90), 48, [0.75, 1.0, 1.5], True),          # windows + padding in one dimension at 0.75 (53 x 68 -> rows < crop? no: 53 >= 48)
+    ((40, 100), 64, [0.5, 1.0], True),               # 0.5: 20 x 50 <= crop (single padded window); 1.0: rows padded, cols slide
+    ((64, 64), 64, [1.0], False),                    # exactly one window, no padding
+    ((33, 47), 32, [1.0, 1.25, 1.75], False),        # odd sizes, non-integer scaled sizes (cvRound)
+])
+def test_sliding_eval_matches_oracle(cuda, hw, crop, scales, flip):
+    net, ev = _setup(cuda, scales, flip)
+    rng = np.random.RandomState(hw[0])
+    img = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
+    want_pred, want_scores = R.sliding_eval(net, img, C, scales, crop, 2 / 3, MEAN, STD, flip, return_scores=True)
+    scores = ev.sliding_scores(img, crop, 2 / 3, 0)
+    got = scores.permute(1, 2, 0).cpu().numpy()
+    assert got.shape == want_scores.shape
+    # the network input differs from the oracle's only at uint8 rounding ties of the resize (float32 vs float64): a
+    # handful of pixels move by one grey level, i.e. ~1e-2 in normalised units, and the scores follow
+    err = np.abs(got - want_scores)
+    assert np.median(err) <= 1e-5 and (err > 2e-3 * len(scales)).mean() <= 5e-3, (np.median(err), err.max())
+    pred = ev.sliding_eval(img, crop, 2 / 3, 0)
+    top2 = np.sort(want_scores, axis=2)
+    clear = (top2[:, :, -1] - top2[:, :, -2]) > 1e-2
+    assert np.array_equal(pred[clear], want_pred[clear]) and clear.mean() > 0.9
+    # fused arg-max confusion matrix == hist_info on the class map (metric.py:9-20)
+    label = rng.randint(0, C, size=hw).astype(np.int64)
+    label[:3] = 255
+    hist = ev.hist_from_scores(scores, label).cpu().numpy()
+    p = scores.argmax(0).cpu().numpy()
+    k = (label >= 0) & (label < C)
+    ref = np.bincount(C * label[k].astype(int) + p[k], minlength=C * C)
+    assert np.array_equal(hist[:C * C], ref) and hist[C * C] == k.sum() and hist[C * C + 1] == (p[k] == label[k]).sum()
+
+
+def test_whole_eval_and_scale_process_signatures(cuda):
+    net, ev = _setup(cuda, [1.0], False)
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, size=(30, 44, 3)).astype(np.uint8)
+    sp = ev.scale_process(img, (30, 44), 32, 2 / 3, 0)
+    want = R.scale_process(net, img, (30, 44), 32, 2 / 3, MEAN, STD, False)
+    assert sp.shape == want.shape == (30, 44, C)
+    assert np.abs(sp - want).max() <= 1e-4
+    pred = ev.whole_eval(img, (60, 88), input_size=48, device=0)
+    inp, margin = R.process_image(img, MEAN, STD, 48)
+    sc = R.val_func_process(net, inp, False)[:, margin[0]:48 - margin[1], margin[2]:48 - margin[3]]
+    ref = R.resize_scores(np.ascontiguousarray(sc.transpose(1, 2, 0)), 60, 88).argmax(2)
+    assert (pred != ref).mean() <= 0.01

@@ -96,7 +96,7 @@ _PROTOS = {
     "tsg_psa_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_psa_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_augment_max_samples": (_i, []),
-    "tsg_augment_crop": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _i, _p, _p, _i, _p]),
+    "tsg_augment_crop": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _f, _i, _p, _p, _i, _p]),
     "tsg_resize_bilinear_hp": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
     "tsg_comm_init_library": (_i, [C.c_char_p]),
     "tsg_comm_unique_id_bytes": (_i, []),

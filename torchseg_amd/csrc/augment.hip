@@ -32,6 +32,7 @@ struct AugSample {
   int crop_y, crop_x;                // crop position in the scaled image
   int top, left;                     // padding margins of the crop inside the output
   int ch, cw;                        // rows / columns of the scaled image that the crop actually covers
+  double fy, fx;                     // source step per scaled pixel (OpenCV: 1 / inv_scale)
 };
 
 struct AugBatch {
@@ -69,8 +70,7 @@ __global__ __launch_bounds__(256) void augment_crop_k(AugBatch b, float* __restr
     return;
   }
   const int sy = p.crop_y + iy, sx = p.crop_x + ix;              // pixel of the (mirrored, scaled) image
-  // OpenCV's source step: 1 / inv_scale with inv_scale = dsize / ssize, both double (resize.cpp)
-  const double fy = 1.0 / ((double)p.SH / (double)p.H), fx = 1.0 / ((double)p.SW / (double)p.W);
+  const double fy = p.fy, fx = p.fx;
   int y0, y1, x0, x1; float wy, wx;
   lin_index(sy, fy, p.H, y0, y1, wy);
   lin_index(sx, fx, p.W, x0, x1, wx);
@@ -99,9 +99,9 @@ extern "C" {
 
 int tsg_augment_max_samples(void) { return kAugMax; }
 
-int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, int n, int CH, int CW,
-                     const float* mean, const float* std, float pad_pixel, int pad_label, float* out_img, void* out_gt,
-                     int gt_type, void* stream) {
+int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int32_t* geom, const double* inv_scale, int n,
+                     int CH, int CW, const float* mean, const float* std, float pad_pixel, int pad_label, float* out_img,
+                     void* out_gt, int gt_type, void* stream) {
   if (!imgs || !geom || !mean || !std || !out_img) return TSG_E_NULL;
   if ((gts == nullptr) != (out_gt == nullptr)) return TSG_E_NULL;
   if (n < 1 || n > kAugMax || CH < 1 || CW < 1) return TSG_E_SHAPE;
@@ -125,6 +125,12 @@ int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int3
     s.cw = s.SW - s.crop_x < CW ? s.SW - s.crop_x : CW;
     s.top = (CH - s.ch) / 2;                                     // pad_image_to_shape: margin[0] = pad // 2
     s.left = (CW - s.cw) / 2;
+    // OpenCV's source step is 1 / inv_scale: inv_scale = dsize / ssize when resize() is given a size (random_scale,
+    // img_utils.py:114), the fx / fy argument itself when it is given factors (evaluator.py:192-193)
+    const double isy = inv_scale ? inv_scale[2 * i] : (double)s.SH / (double)s.H;
+    const double isx = inv_scale ? inv_scale[2 * i + 1] : (double)s.SW / (double)s.W;
+    if (!(isy > 0.0) || !(isx > 0.0)) return TSG_E_SHAPE;
+    s.fy = 1.0 / isy; s.fx = 1.0 / isx;
   }
   dim3 grid((unsigned)((CW + 255) / 256), (unsigned)CH, (unsigned)n);
   if (gt_type == TSG_I64 || !gts)

@@ -87,3 +87,39 @@ def compute_score(hist, correct, labeled):
     mean_IU_no_back = np.nanmean(iu[1:])
     mean_pixel_acc = correct / labeled
     return iu, mean_IU, mean_IU_no_back, mean_pixel_acc
+
+
+# ---- ADE-style per-image metrics (reference metric.py:33-91), small host-side numpy like the reference ----------------
+def meanIoU(area_intersection, area_union):
+    """Per-class IoU over a set of images ([n_images, n_classes] areas), its mean, and the mean without class 0."""
+    iou = 1.0 * np.sum(area_intersection, axis=1) / np.sum(area_union, axis=1)
+    return iou, np.nanmean(iou), np.nanmean(iou[1:])
+
+
+def intersectionAndUnion(imPred, imLab, numClass):
+    """Per-class intersection / union areas of one image; label -1 (after the +1 shift: 0) is unlabeled and removes the
+    pixel from prediction and ground truth alike."""
+    pred = np.asarray(imPred).copy() + 1
+    lab = np.asarray(imLab).copy() + 1
+    pred = pred * (lab > 0)
+    hist = lambda a: np.histogram(a, bins=numClass, range=(1, numClass))[0]       # noqa: E731
+    inter = hist(pred * (pred == lab))
+    return inter, hist(pred) + hist(lab) - inter
+
+
+def mean_pixel_accuracy(pixel_correct, pixel_labeled):
+    return 1.0 * np.sum(pixel_correct) / (np.spacing(1) + np.sum(pixel_labeled))
+
+
+def pixelAccuracy(imPred, imLab):
+    """(accuracy, correct, labeled) over the labeled (>= 0) pixels of one image."""
+    labeled = np.sum(imLab >= 0)
+    correct = np.sum((imPred == imLab) * (imLab >= 0))
+    return 1.0 * correct / labeled, correct, labeled
+
+
+def accuracy(preds, label):
+    valid = (label >= 0)
+    hits = (valid * (preds == label)).sum()
+    total = valid.sum()
+    return float(hits) / (total + 1e-10), total

@@ -507,10 +507,12 @@ class HipKernels:
         return dw
 
     # ---- training pre-processing ---------------------------------------------------
-    def augment_crop(self, imgs, gts, geom, crop_hw, mean, std, pad_label=255, label_dtype=torch.int64, pad_pixel=-1.0):
+    def augment_crop(self, imgs, gts, geom, crop_hw, mean, std, pad_label=255, label_dtype=torch.int64, pad_pixel=-1.0,
+                     inv_scale=None):
         """imgs[i] uint8 [H,W,3], gts[i] uint8 [H,W] (or gts=None) on the GPU; geom int32 numpy [n,7] = H, W, SH, SW, flip,
         crop_y, crop_x -> (float32 [n,3,CH,CW], labels [n,CH,CW] or None).  pad_pixel < 0: the normalised image is padded
-        with 0 (TrainPre); >= 0: the raw image is padded with that value (evaluator)."""
+        with 0 (TrainPre); >= 0: the raw image is padded with that value (evaluator).  inv_scale float64 [n,2] = the
+        (fy, fx) factors cv2.resize was called with, None = derived from the sizes."""
         import numpy as np
         n = len(imgs)
         CH, CW = int(crop_hw[0]), int(crop_hw[1])
@@ -524,11 +526,15 @@ class HipKernels:
         geom = np.ascontiguousarray(geom, dtype=np.int32).reshape(n, 7)
         m = np.ascontiguousarray(mean, dtype=np.float32)
         s = np.ascontiguousarray(std, dtype=np.float32)
+        if inv_scale is not None:
+            inv_scale = np.ascontiguousarray(inv_scale, dtype=np.float64).reshape(n, 2)
         for i0 in range(0, n, cap):
             k = min(cap, n - i0)
             pi = (C.c_void_p * k)(*[imgs[i0 + j].data_ptr() for j in range(k)])
             pg = (C.c_void_p * k)(*[gts[i0 + j].data_ptr() for j in range(k)]) if gts is not None else None
-            L.check(self.lib.tsg_augment_crop(pi, pg, geom[i0:i0 + k].ctypes.data, k, CH, CW, m.ctypes.data, s.ctypes.data,
+            L.check(self.lib.tsg_augment_crop(pi, pg, geom[i0:i0 + k].ctypes.data,
+                                              inv_scale[i0:i0 + k].ctypes.data if inv_scale is not None else None,
+                                              k, CH, CW, m.ctypes.data, s.ctypes.data,
                                               float(pad_pixel), int(pad_label), out[i0:].data_ptr(),
                                               lab[i0:].data_ptr() if lab is not None else None,
                                               _label_code(lab) if lab is not None else L.I64,
