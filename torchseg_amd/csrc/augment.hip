@@ -79,14 +79,18 @@ __global__ __launch_bounds__(256) void augment_crop_k(AugBatch b, float* __restr
   if (p.flip) { x0 = p.W - 1 - x0; x1 = p.W - 1 - x1; nx = p.W - 1 - nx; }   // resize(flip(img)) == flip-indexed taps
   const uint8_t* r0 = p.img + ((int64_t)y0 * p.W) * 3;
   const uint8_t* r1 = p.img + ((int64_t)y1 * p.W) * 3;
+  // interpolate in double with the float-rounded weights, operation for operation as the numpy oracle does: the uint8
+  // rounding below is a step function, and with factors like 1.5 a sizeable share of the values sit exactly on x.5
+  const double dwx = (double)wx, dwy = (double)wy;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float a = (float)r0[x0 * 3 + c], bb = (float)r0[x1 * 3 + c];
-    const float cc = (float)r1[x0 * 3 + c], d = (float)r1[x1 * 3 + c];
-    float v = (1.f - wy) * ((1.f - wx) * a + wx * bb) + wy * ((1.f - wx) * cc + wx * d);
-    v = floorf(v + 0.5f);                                        // the resized image is uint8 again
-    v = fminf(fmaxf(v, 0.f), 255.f);
-    oi[c * plane] = (v / 255.0f - b.mean[c]) * b.inv_std[c];
+    const double a = (double)r0[x0 * 3 + c], bb = (double)r0[x1 * 3 + c];
+    const double cc = (double)r1[x0 * 3 + c], d = (double)r1[x1 * 3 + c];
+    const double top = (1.0 - dwx) * a + dwx * bb, bot = (1.0 - dwx) * cc + dwx * d;
+    double v = (1.0 - dwy) * top + dwy * bot;
+    v = floor(v + 0.5);                                          // the resized image is uint8 again
+    v = fmin(fmax(v, 0.0), 255.0);
+    oi[c * plane] = ((float)v / 255.0f - b.mean[c]) * b.inv_std[c];
   }
   if (og) *og = (LT)p.gt[(int64_t)ny * p.W + nx];
 }

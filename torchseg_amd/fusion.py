@@ -110,7 +110,7 @@ class _PresumUpFn(torch.autograd.Function):
     def backward(ctx, dy):
         from .upsample import _backward_any_layout
         d = _backward_any_layout(dy, *ctx.in_hw)
-        return d, d, None, None
+        return (d if ctx.needs_input_grad[0] else None), (d if ctx.needs_input_grad[1] else None), None, None
 
 
 def upsample_presum(a, b, size=None, scale_factor=None):
