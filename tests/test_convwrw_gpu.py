@@ -62,3 +62,63 @@ def test_wrw_conv_module_matches_stock_autocast(cuda):
     assert g1.dtype == torch.float32 and g1.shape == g0.shape
     assert ((g1 - g0).norm() / g0.norm()).item() <= 1e-2          # MIOpen rounds its result to bf16, ours stays fp32
     assert ((x1.grad - x0.grad).norm() / x0.grad.norm()).item() <= 1e-2
+
+
+# ---- pair-tiled kernel: any C_in, C_out multiple of 64 -----------------------------------------------------------------
+def _check_gen(cuda, B, H, W, Cin, Cout, seed=0):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    g = torch.Generator().manual_seed(seed + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    # channel- and position-dependent scaling: a swapped (oc tile, ci tile) pair or tap cannot pass
+    x = x * (1.0 + 0.01 * torch.arange(Cin).view(1, Cin, 1, 1)) + 0.1 * torch.arange(W).view(1, 1, 1, W) / W
+    dy = dy * (1.0 + 0.02 * torch.arange(Cout).view(1, Cout, 1, 1))
+    xb = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dw = kp.conv3x3_wrw(xb, dyb, variant="gen")
+    assert dw.shape == (Cout, Cin, 3, 3) and dw.dtype == torch.float32
+    assert dw.is_contiguous(memory_format=torch.channels_last)
+    want = conv_ref.conv2d_wgrad_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(dy), ksize=3, stride=1, pad=1)
+    rel = ((dw.double().cpu() - want).norm() / want.norm()).item()
+    assert rel <= 1e-4, rel
+    worst = ((dw.double().cpu() - want).abs().amax(dim=(2, 3)) / want.abs().amax()).max().item()
+    assert worst <= 1e-4, worst                       # every (oc, ci) pair individually
+    return dw
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 32, 128, 64), (2, 6, 40, 64, 128), (1, 5, 7, 128, 192), (2, 12, 36, 256, 128),
+                                   (3, 9, 33, 64, 64), (1, 4, 32, 512, 512)])
+def test_conv3x3_wrw_gen_vs_oracle(cuda, shape):
+    _check_gen(cuda, *shape)
+
+
+@pytest.mark.parametrize("B,C,S", [(16, 128, 128), (16, 256, 64), (16, 512, 32)])
+def test_conv3x3_wrw_gen_resnet18_sizes_vs_miopen_and_deterministic(cuda, B, C, S):
+    """layer2 / layer3 / layer4 geometry at BASELINE config 2, whole batch: against MIOpen's own weight gradient on the same
+    operands (its result is rounded to bf16: 1e-2), run-to-run bit-identical, plus the oracle on a 2-image slice."""
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    g = torch.Generator(device=cuda).manual_seed(C)
+    x = torch.randn(B, C, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, C, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(C, C, 3, 3, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    a = kp.conv3x3_wrw(x, dy)
+    b = kp.conv3x3_wrw(x, dy)
+    assert torch.equal(a, b)
+    ref = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert ((a - ref.float()).norm() / ref.float().norm()).item() <= 1e-2
+    sl = kp.conv3x3_wrw(x[:2].contiguous(memory_format=torch.channels_last), dy[:2].contiguous(memory_format=torch.channels_last))
+    want = conv_ref.conv2d_wgrad_ref(x[:2].double().cpu(), dy[:2].double().cpu(), ksize=3, stride=1, pad=1)
+    assert ((sl.double().cpu() - want).norm() / want.norm()).item() <= 1e-4
+
+
+def test_install_conv_wrw_covers_every_stride1_3x3_of_bisenet(cuda):
+    import torch.nn as nn
+    from torchseg_amd.convwrw import WrwConv2d, install_conv_wrw
+    from torchseg_amd.workloads.bisenet import BiSeNet
+    net = BiSeNet(19, True, None, None, nn.BatchNorm2d)
+    n = install_conv_wrw(net)
+    want = sum(1 for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
+               and m.in_channels % 64 == 0 and m.out_channels % 64 == 0)
+    assert n == want == sum(isinstance(m, WrwConv2d) for m in net.modules()) and n >= 20

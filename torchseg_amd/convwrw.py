@@ -1,4 +1,11 @@
-"""Weight gradient of ResNet-18 layer1's 3x3 convolutions on our MFMA kernel.
+"""Weight gradient of the stride-1 3x3 convolutions (C_in, C_out multiples of 64) on our MFMA kernels.
+
+Round 2: the layer1 kernel below runs over (oc tile, ci tile) pairs of 64 x 64 channels (`tsg_conv3x3_wrw_gen`), which
+covers every stride-1 3x3 convolution of BiSeNet-R18 (layer2-4, refines, attention-refinement modules, heads): MIOpen's
+split-K kernels for them take 94-288 us each plus a zero fill and a cast (tools/probe_conv2.py), 4.2 ms per step in
+total for the weight gradients.  TSG_CONV_WRW_MAXC (default 512) caps the channel count that is re-classed.
+
+Round 1 text: weight gradient of ResNet-18 layer1's 3x3 convolutions on our MFMA kernel.
 
 The four `conv3x3(64, 64)` of layer1 (furnace/base_model/resnet.py:24-29,36-53) see the largest
 activations of the context path ([16, 64, 256, 256] at BASELINE config 2).  MIOpen computes their
@@ -57,15 +64,17 @@ class WrwConv2d(nn.Conv2d):
 
 
 def _eligible(m):
-    return (type(m) is nn.Conv2d and m.in_channels == 64 and m.out_channels == 64 and m.kernel_size == (3, 3)
+    return (type(m) is nn.Conv2d and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.kernel_size == (3, 3)
             and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None)
 
 
 def install_conv_wrw(module):
     """Re-class the eligible convolutions in place; returns how many were found."""
+    import os
+    maxc = int(os.environ.get("TSG_CONV_WRW_MAXC", "512"))
     n = 0
     for m in module.modules():
-        if _eligible(m):
+        if _eligible(m) and max(m.in_channels, m.out_channels) <= maxc:
             m.__class__ = WrwConv2d
             n += 1
     return n

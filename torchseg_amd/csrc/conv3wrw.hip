@@ -264,6 +264,135 @@ __global__ __launch_bounds__(256) void conv3_wrw_tr_k(const bf16_t* __restrict__
     }
 }
 
+// ---------------------------------------------------------------- variant 3: any C_in, C_out that are multiples of 64
+// The same kernel body over (oc tile, ci tile) PAIRS of 64 x 64 channels: a block owns one pair and every bpp-th pixel
+// tile, reads the 64-channel slices of dy and x it needs (pixel strides C_out / C_in instead of 64) and writes one
+// [64 x 576] partial.  128 -> 128 at 128^2 is 4 pairs, 512 -> 512 at 32^2 is 64 pairs: every operand slice is read by
+// C_out / 64 (x) or C_in / 64 (dy) blocks -- 268 MB of (Infinity-Cache resident) traffic for each of the 77-GFLOP layers
+// of ResNet-18, against ~85 us of MFMA time, so the kernel stays on the MFMA side of its roofline exactly like the
+// 64 -> 64 case it was built for.  (furnace/base_model/resnet.py:24-29 every BasicBlock conv3x3 with stride 1; bisenet
+// network.py:43-52 refines / arms, :140-156 head conv_3x3.)
+struct W3GenGeom {
+  int B, H, W, tiles_h, tiles_w, ntiles;
+  int Cin, Cout, nci, npairs, bpp;      // channel counts, ci tiles, (oc tile, ci tile) pairs, blocks per pair
+};
+
+__global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                       float* __restrict__ part, W3GenGeom g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  bf16_t* dyL = reinterpret_cast<bf16_t*>(lds);       // [128 pixels][T3_RBE]
+  bf16_t* xL = dyL + T3_DY;                           // [204 pixels][T3_RBE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wh = wave & 1;            // oc half, ci half of the 64 x 64 pair
+  const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
+  const int pair = blockIdx.x % g.npairs, slot = blockIdx.x / g.npairs;
+  const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
+
+  const int spart = tid & 7, spix = tid >> 3;
+  int xr[T3_XU], xc[T3_XU];
+#pragma unroll
+  for (int u = 0; u < T3_XU; ++u) {
+    const int pp = spix + 32 * u;
+    xr[u] = pp < T3_NPX ? pp / T3_PC : -1;
+    xc[u] = pp % T3_PC;
+  }
+  const int fbase = (8 * half + (i16 >> 2)) * T3_RBE + 16 * sub + 4 * (i16 & 3);
+  const lds_v4i16* afr = (const lds_v4i16*)(dyL + fbase + 32 * wm);
+  const lds_v4i16* bfr = (const lds_v4i16*)(xL + fbase + 32 * wh);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  uint4 rd[W3_TH];
+  uint4 rx[T3_XU];
+  auto fetch = [&](int tile) {
+    const int ow0 = (tile % g.tiles_w) * W3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
+    const int b = tile / (g.tiles_w * g.tiles_h);
+    const int64_t pix = ((int64_t)b * g.H + oh0) * g.W + ow0;
+    const bf16_t* dt = dy + (pix + spix) * g.Cout + oc0 + spart * 8;
+#pragma unroll
+    for (int u = 0; u < W3_TH; ++u)
+      rd[u] = (oh0 + u < g.H && ow0 + spix < g.W) ? *reinterpret_cast<const uint4*>(dt + (int64_t)u * g.W * g.Cout)
+                                                  : make_uint4(0, 0, 0, 0);
+    const bf16_t* xo = x + pix * g.Cin + ci0 + spart * 8;
+#pragma unroll
+    for (int u = 0; u < T3_XU; ++u) {
+      const int ih = oh0 - 1 + xr[u], iw = ow0 - 1 + xc[u];
+      rx[u] = (xr[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                  ? *reinterpret_cast<const uint4*>(xo + ((int64_t)(xr[u] - 1) * g.W + xc[u] - 1) * g.Cin)
+                  : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  int tile = slot;
+  if (tile < g.ntiles) fetch(tile);
+  for (; tile < g.ntiles; tile += g.bpp) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < W3_TH; ++u)
+      *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = rd[u];
+#pragma unroll
+    for (int u = 0; u < T3_XU; ++u)
+      if (u < T3_XU - 1 || xr[u] >= 0)
+        *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = rx[u];
+    __syncthreads();
+    if (tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      union { v4i16 q[2]; bf16x8 v; } fa;
+      fa.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
+      fa.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int px = ((ks >> 1) + kh) * T3_PC + (ks & 1) * 16 + kw;
+          union { v4i16 q[2]; bf16x8 v; } fb;
+          fb.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 0) * (T3_RBE / 4)));
+          fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4) * (T3_RBE / 4)));
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
+        }
+    }
+  }
+  // partial of this (pair, slot): [pair][slot][64 oc][9 taps][64 ci]
+  float* out = part + ((int64_t)pair * g.bpp + slot) * W3_C * W3_N;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[oc * W3_N + t * W3_C + 32 * wh + (lane & 31)] = acc[t][r];
+    }
+}
+
+// dw[oc0 + oc][tap][ci0 + 0..63] = sum over the pair's bpp partials (fixed order, fp64).  Block = one run of 64 ci.
+__global__ __launch_bounds__(256) void conv3_wrw_gen_fold(const float* __restrict__ part, W3GenGeom g,
+                                                          float* __restrict__ dw) {
+  __shared__ double sm[16][64];
+  const int run = blockIdx.x % (W3_C * 9), pair = blockIdx.x / (W3_C * 9);       // run = oc * 9 + tap inside the pair
+  const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
+  const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
+  const float* src = part + (int64_t)pair * g.bpp * W3_C * W3_N + run * 64 + c4 * 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+  for (int s = gs; s < g.bpp; s += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * W3_C * W3_N);
+    a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  }
+  sm[gs][c4 * 4 + 0] = a0; sm[gs][c4 * 4 + 1] = a1; sm[gs][c4 * 4 + 2] = a2; sm[gs][c4 * 4 + 3] = a3;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x];
+    const int oc = run / 9, tap = run % 9;
+    dw[((int64_t)(oc0 + oc) * 9 + tap) * g.Cin + ci0 + threadIdx.x] = (float)t;
+  }
+}
+
 // dw[flat] = sum over the per-block partials (fixed order, fp64); 64 consecutive entries per block
 __global__ __launch_bounds__(256) void conv3_wrw_fold(const float* __restrict__ part, int nparts, int64_t stride,
                                                       float* __restrict__ dw) {
@@ -340,6 +469,50 @@ int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t
 int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
                        size_t ws_bytes, void* stream) {
   return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream);
+}
+
+static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % W3_C || Cout % W3_C) return TSG_E_SHAPE;
+  const int64_t th = (H + W3_TH - 1) / W3_TH, tw = (W + W3_TW - 1) / W3_TW;
+  if (B * th * tw > 0x7fffffffLL || B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) > 0x7fffffff00LL) return TSG_E_SHAPE;
+  g->B = (int)B; g->H = (int)H; g->W = (int)W; g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
+  g->Cin = Cin; g->Cout = Cout; g->nci = Cin / W3_C; g->npairs = (Cout / W3_C) * g->nci;
+  int bpp = (512 + g->npairs - 1) / g->npairs;               // ~2 blocks per CU over all pairs
+  if (bpp > g->ntiles) bpp = g->ntiles;
+  if (bpp < 1) bpp = 1;
+  g->bpp = bpp;
+  return 0;
+}
+
+int tsg_conv3x3_wrw_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
+                                  int groups) {
+  return dtype == TSG_BF16 && Cin > 0 && Cout > 0 && Cin % W3_C == 0 && Cout % W3_C == 0 && kh == 3 && kw == 3 &&
+         stride == 1 && pad == 1 && dilation == 1 && groups == 1;
+}
+
+size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t H, int64_t W, int Cin, int Cout) {
+  W3GenGeom g;
+  if (w3gen_geom(&g, B, H, W, Cin, Cout)) return 0;
+  return (size_t)g.npairs * g.bpp * W3_C * W3_N * sizeof(float);
+}
+
+int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, int Cin, int Cout,
+                        void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !ws) return TSG_E_NULL;
+  W3GenGeom g;
+  int e = w3gen_geom(&g, B, H, W, Cin, Cout);
+  if (e) return e;
+  if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout)) return TSG_E_WS;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
+  hipLaunchKernelGGL(conv3_wrw_gen_k, dim3(g.npairs * g.bpp), dim3(256), T3_LDS, st, (const bf16_t*)x,
+                     (const bf16_t*)dy, (float*)ws, g);
+  TSG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
+  TSG_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // extern "C"

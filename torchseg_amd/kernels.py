@@ -483,27 +483,40 @@ class HipKernels:
     def conv3x3_wrw_supported(self, x, weight, stride, padding, dilation, groups):
         if x.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
             return False
-        return bool(self.lib.tsg_conv3x3_wrw_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
-                                                       weight.shape[3], stride, padding, dilation, groups))
+        return bool(self.lib.tsg_conv3x3_wrw_gen_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
+                                                           weight.shape[3], stride, padding, dilation, groups))
 
     def conv3x3_wrw(self, x, dy, variant=None):
-        """x, dy [B,64,H,W] bf16 channels_last -> dw fp32 [64,64,3,3] channels_last.
-        variant "tr" (default, TSG_CONV_WRW_IMPL) = transposing-LDS-read kernel, "v1" = transposed-staging kernel."""
+        """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 channels_last (Cin, Cout multiples of 64; 3x3, stride 1, padding 1) ->
+        dw fp32 [Cout,Cin,3,3] channels_last.  64 -> 64 takes the single-pair kernel (variant "tr", or "v1" = the
+        transposed-staging kernel, TSG_CONV_WRW_IMPL); everything else the pair-tiled kernel ("gen"; also selectable for
+        64 -> 64 with variant="gen")."""
         if variant is None:
             variant = os.environ.get("TSG_CONV_WRW_IMPL", "tr")
-        fn = self.lib.tsg_conv3x3_wrw_tr if variant == "tr" else self.lib.tsg_conv3x3_wrw
         for t in (x, dy):
             if not t.is_contiguous(memory_format=torch.channels_last) or t.dtype != torch.bfloat16:
                 raise ValueError("conv3x3_wrw expects bf16 channels_last tensors")
-        B, _, H, W = x.shape
-        if tuple(dy.shape) != (B, 64, H, W):
-            raise ValueError("conv3x3_wrw: dy must have the shape of x (stride 1, padding 1)")
-        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        ws = getattr(self, "_c3_ws", None)
-        if ws is None or ws.device != x.device:
-            ws = self._c3_ws = torch.empty(self.lib.tsg_conv3x3_wrw_ws_bytes(), dtype=torch.uint8, device=x.device)
-        L.check(fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
-                "tsg_conv3x3_wrw")
+        B, Cin, H, W = x.shape
+        Cout = dy.shape[1]
+        if tuple(dy.shape) != (B, Cout, H, W):
+            raise ValueError("conv3x3_wrw: dy must have the spatial shape of x (stride 1, padding 1)")
+        dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if Cin == 64 and Cout == 64 and variant != "gen":
+            fn = self.lib.tsg_conv3x3_wrw_tr if variant == "tr" else self.lib.tsg_conv3x3_wrw
+            ws = getattr(self, "_c3_ws", None)
+            if ws is None or ws.device != x.device:
+                ws = self._c3_ws = torch.empty(self.lib.tsg_conv3x3_wrw_ws_bytes(), dtype=torch.uint8, device=x.device)
+            L.check(fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
+                    "tsg_conv3x3_wrw")
+            return dw
+        wsb = self.lib.tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout)
+        if wsb == 0:
+            raise L.TsgError("conv3x3_wrw: unsupported shape %s -> %d channels" % (tuple(x.shape), Cout))
+        ws = getattr(self, "_c3g_ws", None)                       # one buffer, grown to the largest layer (<= 76 MB)
+        if ws is None or ws.device != x.device or ws.numel() < wsb:
+            ws = self._c3g_ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_conv3x3_wrw_gen(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(),
+                                             ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_gen")
         return dw
 
     # ---- training pre-processing ---------------------------------------------------
