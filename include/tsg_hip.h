@@ -235,6 +235,10 @@ int tsg_conv3x3_wrw_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, 
 size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t H, int64_t W, int Cin, int Cout);
 int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, int Cin, int Cout,
                         void* ws, size_t ws_bytes, void* stream);
+/* out[ci][kh][kw][oc] (bf16) = w[oc][2-kh][2-kw][ci] (fp32 or bf16, the channels_last filter layout): the filter with
+ * which the DATA gradient of a stride-1 / padding-1 3x3 convolution is itself a forward convolution of dy — what
+ * autograd's cuDNN backward-data call computes for resnet.py:24-29 — so that it can run on the (faster) forward kernels. */
+int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int I, void* stream);
 
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward

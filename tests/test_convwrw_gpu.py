@@ -122,3 +122,34 @@ def test_install_conv_wrw_covers_every_stride1_3x3_of_bisenet(cuda):
     want = sum(1 for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
                and m.in_channels % 64 == 0 and m.out_channels % 64 == 0)
     assert n == want == sum(isinstance(m, WrwConv2d) for m in net.modules()) and n >= 20
+
+
+@pytest.mark.parametrize("O,I", [(64, 64), (128, 64), (96, 160), (512, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_rot180_transpose_is_exact(cuda, O, I, dtype):
+    from torchseg_amd import kernels as K
+    w = torch.randn(O, I, 3, 3, device=cuda).to(dtype).contiguous(memory_format=torch.channels_last)
+    got = K.provider().conv3x3_weight_rot180_t(w)
+    want = w.flip(2, 3).transpose(0, 1).to(torch.bfloat16)
+    assert got.shape == (I, O, 3, 3) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
+def test_dgrad_through_forward_convolution_matches_oracle(cuda):
+    """dx of a stride-1 / padding-1 3x3 convolution == conv(dy, rot180(w)^T) (resnet.py:24-29 backward): against the
+    fp64 data gradient of the conv oracle on the same bf16-rounded operands, and against autograd through the module."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torchseg_amd import convwrw, kernels as K
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.1
+    dy = torch.randn(2, 64, 20, 36, generator=g)
+    wr, dyr = conv_ref.bf16_round(w), conv_ref.bf16_round(dy)
+    xz = torch.zeros(2, 64, 20, 36, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xz, wr, None, 1, 1).backward(dyr)                         # torch CPU fp64 autograd of the oracle's definition
+    wb = w.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dx = F.conv2d(dyb, K.provider().conv3x3_weight_rot180_t(wb), None, 1, 1)
+    rel = ((dx.double().cpu() - xz.grad).norm() / xz.grad.norm()).item()
+    assert rel <= 5e-3, rel                                            # bf16 output rounding
+    assert convwrw._DGRAD_FWD

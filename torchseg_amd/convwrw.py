@@ -23,6 +23,11 @@ import torch.nn.functional as F
 from . import kernels as K
 
 
+import os as _os
+# TSG_CONV_DGRAD_FWD=1|0 (default 1): data gradient of the C_in == C_out layers through a forward convolution
+_DGRAD_FWD = _os.environ.get("TSG_CONV_DGRAD_FWD", "1").strip().lower() not in ("0", "false", "no", "off", "")
+
+
 class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, wb):
@@ -31,6 +36,7 @@ class _ConvWrwFn(torch.autograd.Function):
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
+        ctx.dgrad_fwd = _DGRAD_FWD and weight.shape[0] == weight.shape[1]
         return y
 
     @staticmethod
@@ -41,8 +47,13 @@ class _ConvWrwFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
         if ctx.need_dx:
-            dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            if ctx.dgrad_fwd:
+                # dx = conv(dy, rot180(w)^T): the library's forward kernels beat its backward-data kernels on the
+                # symmetric layers (tools/probe_conv2.py); same bf16 operands, fp32 accumulation
+                dx = F.conv2d(dy, K.provider().conv3x3_weight_rot180_t(wb), None, 1, 1)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         dw = K.provider().conv3x3_wrw(x, dy)
         return dx, dw.to(ctx.wdtype), None
 

@@ -519,6 +519,16 @@ class HipKernels:
                                              ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_gen")
         return dw
 
+    def conv3x3_weight_rot180_t(self, w):
+        """w [O,I,3,3] fp32 / bf16 channels_last -> bf16 [I,O,3,3] channels_last with the taps rotated by 180 degrees"""
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or not w.is_contiguous(memory_format=torch.channels_last):
+            raise L.TsgError("conv3x3_weight_rot180_t takes a channels_last [O, I, 3, 3] filter")
+        O, I = w.shape[0], w.shape[1]
+        out = torch.empty((I, O, 3, 3), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_conv3x3_weight_rot180_t(w.data_ptr(), L.dtype_code(w), out.data_ptr(), O, I, L.stream_ptr(w)),
+                "tsg_conv3x3_weight_rot180_t")
+        return out
+
     # ---- training pre-processing ---------------------------------------------------
     def augment_crop(self, imgs, gts, geom, crop_hw, mean, std, pad_label=255, label_dtype=torch.int64, pad_pixel=-1.0,
                      inv_scale=None):
