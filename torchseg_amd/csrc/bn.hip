@@ -19,6 +19,7 @@
 //   bwd_reduce   2 reads           = 2s   (+s when the ReLU mask comes from y)
 //   bwd_apply    2 reads + 1 write = 3s   (+s mask-from-y, +s dres)
 #include "tsg_common.h"
+#include <stdlib.h>
 
 namespace tsg {
 
@@ -259,6 +260,13 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
 // =========================================================================
 // element-wise passes
 // =========================================================================
+// TSG_BN_REVERSE=1|0 (default set by measurement): the apply kernels traverse the tensor end-first
+static int bn_reverse() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TSG_BN_REVERSE"); v = e ? (e[0] != '0') : 0; }
+  return v;
+}
+
 template <typename T, int V, bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void bn_fwd_nchw(
     const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw(
 template <typename T, int V, bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
     const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ fp) {
+    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ fp, int rev) {
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
   const int64_t g = (int64_t)blockIdx.y * GT + gl;
@@ -302,7 +310,9 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
   float a[V], b[V];
   ldc<V>(fp, c0, a);
   ldc<V>(fp + C, c0, b);
-  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  // rev: walk the tensor END first.  The statistics pass that ran just before read x front to back, so the tail of x is
+  // what the 256 MB Infinity Cache still holds; blocks are dispatched in index order, so the first ones take the tail.
+  const int64_t row0 = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
   for (int64_t row = row0 + r; row < row1; row += (int64_t)kUnroll * R) {
@@ -369,7 +379,7 @@ template <typename T, int V, int MASK, bool DRES>
 __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
     T* __restrict__ dx, T* __restrict__ dres,
-    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ bp) {
+    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ bp, int rev) {
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
   const int64_t g = (int64_t)blockIdx.y * GT + gl;
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
   ldc<V>(bp + 2 * C, c0, mu);
   ldc<V>(bp + 3 * C, c0, bc);
   ldc<V>(bp + 4 * C, c0, c2);
-  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row0 = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
   for (int64_t row = row0 + r; row < row1; row += (int64_t)kUnroll * R) {
@@ -729,7 +739,7 @@ static int launch_fwd(const T* x, const T* res, T* y, int layout, int64_t N, int
     NhwcGeom g = nhwc_geom(M, C, V);
     dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
 #define L_(A, B) hipLaunchKernelGGL((bn_fwd_nhwc<T, V, A, B>), grid, dim3(kThreads), 0, st, \
-      x, res, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, fp)
+      x, res, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, fp, bn_reverse())
     if (R_ && S_) L_(true, true); else if (R_) L_(true, false); else if (S_) L_(false, true); else L_(false, false);
 #undef L_
   }
@@ -756,7 +766,7 @@ static int launch_bwd(const T* dy, const T* x, const T* y, T* dx, T* dres, int l
     NhwcGeom g = nhwc_geom(M, C, V);
     dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
 #define L_(MK, D) hipLaunchKernelGGL((bn_bwd_nhwc<T, V, MK, D>), grid, dim3(kThreads), 0, st, \
-      dy, x, y, dx, dres, M, C, g.gt, g.rows_per_iter, g.rows_per_block, bp)
+      dy, x, y, dx, dres, M, C, g.gt, g.rows_per_iter, g.rows_per_block, bp, bn_reverse())
     if (mask == 0) { if (D_) L_(0, true); else L_(0, false); }
     else if (mask == 1) { if (D_) L_(1, true); else L_(1, false); }
     else { if (D_) L_(2, true); else L_(2, false); }

@@ -14,6 +14,7 @@
 // A block's 4 waves own the whole [64 x 576] accumulator (9 tiles of 32x32 each: oc half x ci half x 9 taps)
 // in MFMA registers across all its tiles; per-block partials are summed in fp64 in a fixed order.
 #include "tsg_common.h"
+#include <stdlib.h>
 
 namespace tsg {
 
@@ -477,7 +478,10 @@ static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t H, int64_t W, int Cin, in
   if (B * th * tw > 0x7fffffffLL || B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) > 0x7fffffff00LL) return TSG_E_SHAPE;
   g->B = (int)B; g->H = (int)H; g->W = (int)W; g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
   g->Cin = Cin; g->Cout = Cout; g->nci = Cin / W3_C; g->npairs = (Cout / W3_C) * g->nci;
-  int bpp = (512 + g->npairs - 1) / g->npairs;               // ~2 blocks per CU over all pairs
+  // one block per CU at a time (300 registers per lane): a second round of blocks would only add partials to fold
+  static int target = 0;
+  if (!target) { const char* e = getenv("TSG_CONV_WRW_BLOCKS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+  int bpp = (target + g->npairs - 1) / g->npairs;
   if (bpp > g->ntiles) bpp = g->ntiles;
   if (bpp < 1) bpp = 1;
   g->bpp = bpp;
