@@ -226,15 +226,17 @@ int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t
  * between the variants (different summation order), each is deterministic run to run. */
 int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
                        void* ws, size_t ws_bytes, void* stream);
-/* Any C_in, C_out that are multiples of 64 (every stride-1 3x3 convolution of the ResNet-18 context path, the refines,
- * the attention-refinement modules and the heads: resnet.py:24-29, bisenet network.py:43-52,140-156): the kernel above
- * over (oc tile, ci tile) pairs of 64 x 64 channels.  x [B,H,W,Cin], dy [B,H,W,Cout] bf16 channels_last; dw fp32
- * [Cout][3][3][Cin]; ws: tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout) bytes.  Deterministic. */
+/* Any C_in, C_out that are multiples of 64, stride 1 or 2 (every 3x3 convolution of the ResNet-18 context path, the
+ * spatial path, the refines, the attention-refinement modules and the heads: resnet.py:24-29,36-53, bisenet
+ * network.py:43-52,114-137,140-156): the kernel above over (oc tile, ci tile) pairs of 64 x 64 channels; for stride 2 the
+ * x patch of a tile is 9 x 65 input pixels and the K fragments step two pixels.  x [B,Hin,Win,Cin], dy
+ * [B,OH,OW,Cout] (OH = (Hin - 1) / stride + 1) bf16 channels_last; dw fp32 [Cout][3][3][Cin];
+ * ws: tsg_conv3x3_wrw_gen_ws_bytes(...) bytes.  Deterministic. */
 int tsg_conv3x3_wrw_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                   int dilation, int groups);
-size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t H, int64_t W, int Cin, int Cout);
-int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, int Cin, int Cout,
-                        void* ws, size_t ws_bytes, void* stream);
+size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout, int stride);
+int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout,
+                        int stride, void* ws, size_t ws_bytes, void* stream);
 /* out[ci][kh][kw][oc] (bf16) = w[oc][2-kh][2-kw][ci] (fp32 or bf16, the channels_last filter layout): the filter with
  * which the DATA gradient of a stride-1 / padding-1 3x3 convolution is itself a forward convolution of dy — what
  * autograd's cuDNN backward-data call computes for resnet.py:24-29 — so that it can run on the (faster) forward kernels. */

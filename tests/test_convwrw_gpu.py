@@ -65,21 +65,21 @@ def test_wrw_conv_module_matches_stock_autocast(cuda):
 
 
 # ---- pair-tiled kernel: any C_in, C_out multiple of 64 -----------------------------------------------------------------
-def _check_gen(cuda, B, H, W, Cin, Cout, seed=0):
+def _check_gen(cuda, B, H, W, Cin, Cout, seed=0, stride=1):
     from torchseg_amd import kernels as K
     kp = K.provider()
     g = torch.Generator().manual_seed(seed + Cin + Cout)
     x = torch.randn(B, Cin, H, W, generator=g)
-    dy = torch.randn(B, Cout, H, W, generator=g)
+    dy = torch.randn(B, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=g)
     # channel- and position-dependent scaling: a swapped (oc tile, ci tile) pair or tap cannot pass
     x = x * (1.0 + 0.01 * torch.arange(Cin).view(1, Cin, 1, 1)) + 0.1 * torch.arange(W).view(1, 1, 1, W) / W
     dy = dy * (1.0 + 0.02 * torch.arange(Cout).view(1, Cout, 1, 1))
     xb = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
     dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
-    dw = kp.conv3x3_wrw(xb, dyb, variant="gen")
+    dw = kp.conv3x3_wrw(xb, dyb, variant="gen", stride=stride)
     assert dw.shape == (Cout, Cin, 3, 3) and dw.dtype == torch.float32
     assert dw.is_contiguous(memory_format=torch.channels_last)
-    want = conv_ref.conv2d_wgrad_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(dy), ksize=3, stride=1, pad=1)
+    want = conv_ref.conv2d_wgrad_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(dy), ksize=3, stride=stride, pad=1)
     rel = ((dw.double().cpu() - want).norm() / want.norm()).item()
     assert rel <= 1e-4, rel
     worst = ((dw.double().cpu() - want).abs().amax(dim=(2, 3)) / want.abs().amax()).max().item()
@@ -91,6 +91,28 @@ def _check_gen(cuda, B, H, W, Cin, Cout, seed=0):
                                    (3, 9, 33, 64, 64), (1, 4, 32, 512, 512)])
 def test_conv3x3_wrw_gen_vs_oracle(cuda, shape):
     _check_gen(cuda, *shape)
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 64, 64, 64), (2, 13, 70, 64, 128), (1, 9, 33, 128, 64), (2, 8, 64, 256, 128),
+                                   (1, 2, 2, 64, 64), (1, 31, 129, 64, 64)])
+def test_conv3x3_wrw_gen_stride2_vs_oracle(cuda, shape):
+    """bisenet network.py:114-137 (spatial path) and resnet.py layer2-4 first blocks: 3x3 / stride 2 / padding 1, even and
+    odd input sizes (OH = (Hin - 1) // 2 + 1)."""
+    _check_gen(cuda, *shape, stride=2)
+
+
+def test_conv3x3_wrw_gen_stride2_spatial_path_size_vs_miopen(cuda):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    for (B, Cin, Cout, Hin) in [(16, 64, 64, 512), (16, 128, 256, 128)]:
+        g = torch.Generator(device=cuda).manual_seed(Cin)
+        x = torch.randn(B, Cin, Hin, Hin, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, Cout, Hin // 2, Hin // 2, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+        w = torch.zeros(Cout, Cin, 3, 3, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+        a = kp.conv3x3_wrw(x, dy, stride=2)
+        assert torch.equal(a, kp.conv3x3_wrw(x, dy, stride=2))
+        ref = torch.ops.aten.convolution_backward(dy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        assert ((a - ref.float()).norm() / ref.float().norm()).item() <= 1e-2
 
 
 @pytest.mark.parametrize("B,C,S", [(16, 128, 128), (16, 256, 64), (16, 512, 32)])
@@ -113,15 +135,15 @@ def test_conv3x3_wrw_gen_resnet18_sizes_vs_miopen_and_deterministic(cuda, B, C, 
     assert ((sl.double().cpu() - want).norm() / want.norm()).item() <= 1e-4
 
 
-def test_install_conv_wrw_covers_every_stride1_3x3_of_bisenet(cuda):
+def test_install_conv_wrw_covers_every_3x3_of_bisenet_but_the_stems(cuda):
     import torch.nn as nn
     from torchseg_amd.convwrw import WrwConv2d, install_conv_wrw
     from torchseg_amd.workloads.bisenet import BiSeNet
     net = BiSeNet(19, True, None, None, nn.BatchNorm2d)
     n = install_conv_wrw(net)
-    want = sum(1 for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
+    want = sum(1 for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)
                and m.in_channels % 64 == 0 and m.out_channels % 64 == 0)
-    assert n == want == sum(isinstance(m, WrwConv2d) for m in net.modules()) and n >= 20
+    assert n == want == sum(isinstance(m, WrwConv2d) for m in net.modules()) and n == 25
 
 
 @pytest.mark.parametrize("O,I", [(64, 64), (128, 64), (96, 160), (512, 512)])

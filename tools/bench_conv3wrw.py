@@ -22,25 +22,28 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
-# (name, count per step, Cin, Cout, H)
-LAYERS = [("layer1", 4, 64, 64, 256), ("layer2", 3, 128, 128, 128), ("refine @128", 1, 128, 128, 128),
+# (name, count per step, Cin, Cout, Hin[, stride])
+LAYERS = [("sp.conv_3x3_1 s2", 1, 64, 64, 512, 2), ("sp.conv_3x3_2 s2", 1, 64, 64, 256, 2), ("layer2.0 s2", 1, 64, 128, 256, 2),
+          ("layer3.0 s2", 1, 128, 256, 128, 2), ("layer4.0 s2", 1, 256, 512, 64, 2), ("layer1", 4, 64, 64, 256), ("layer2", 3, 128, 128, 128), ("refine @128", 1, 128, 128, 128),
           ("layer3", 3, 256, 256, 64), ("layer4", 3, 512, 512, 32), ("head1 128->256 @128", 1, 128, 256, 128),
           ("head2 256->64 @128", 1, 256, 64, 128), ("head0 128->256 @64", 1, 128, 256, 64), ("arm16 256->128 @64", 1, 256, 128, 64),
           ("arm32 512->128 @32", 1, 512, 128, 32), ("refine @64", 1, 128, 128, 64)]
 only = os.environ.get("ONLY")
 tot_o = tot_m = 0.0
-for name, cnt, cin, cout, H in LAYERS:
+for row in LAYERS:
+    name, cnt, cin, cout, H = row[:5]
+    st = row[5] if len(row) > 5 else 1
     if only and only not in name:
         continue
     x = torch.randn(16, cin, H, H, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
-    dy = torch.randn(16, cout, H, H, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(16, cout, H // st, H // st, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
     w = torch.randn(cout, cin, 3, 3, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
-    t = timeit(lambda: kp.conv3x3_wrw(x, dy))
-    t2 = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+    t = timeit(lambda: kp.conv3x3_wrw(x, dy, stride=st))
+    t2 = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [1, 1], [1, 1], False, [0, 0], 1,
                                                             [False, True, False]), 10)
-    a = kp.conv3x3_wrw(x, dy)
-    b = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-    fl = 2.0 * 16 * cin * cout * 9 * H * H
+    a = kp.conv3x3_wrw(x, dy, stride=st)
+    b = torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    fl = 2.0 * 16 * cin * cout * 9 * (H // st) ** 2
     print("%-22s x%d  ours %7.1f us (%.2f PF)   MIOpen %7.1f us   rel diff %.1e" %
           (name, cnt, t, fl / t / 1e9, t2, ((a - b.float()).norm() / b.float().norm()).item()), flush=True)
     tot_o += cnt * t; tot_m += cnt * t2

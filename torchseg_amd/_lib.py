@@ -72,8 +72,8 @@ _PROTOS = {
     "tsg_conv3x3_wrw": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_conv3x3_wrw_tr": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_conv3x3_wrw_gen_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "tsg_conv3x3_wrw_gen_ws_bytes": (_sz, [_i64, _i64, _i64, _i, _i]),
-    "tsg_conv3x3_wrw_gen": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _p, _sz, _p]),
+    "tsg_conv3x3_wrw_gen_ws_bytes": (_sz, [_i64, _i64, _i64, _i, _i, _i]),
+    "tsg_conv3x3_wrw_gen": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _sz, _p]),
     "tsg_conv3x3_weight_rot180_t": (_i, [_p, _i, _p, _i, _i, _p]),
     "tsg_multi_copy_f32": (_i, [_p, _p, _p, _i, _p, _i64, _f, _p]),
     "tsg_ohem_make_plan": (_i, [_i64, _i, _i64, _f, C.POINTER(OhemPlan)]),

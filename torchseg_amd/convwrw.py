@@ -30,13 +30,14 @@ _DGRAD_FWD = _os.environ.get("TSG_CONV_DGRAD_FWD", "1").strip().lower() not in (
 
 class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, wb):
+    def forward(ctx, x, weight, wb, stride):
         # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
-        y = F.conv2d(x, wb, None, 1, 1)
+        y = F.conv2d(x, wb, None, stride, 1)
+        ctx.stride = stride
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
-        ctx.dgrad_fwd = _DGRAD_FWD and weight.shape[0] == weight.shape[1]
+        ctx.dgrad_fwd = _DGRAD_FWD and stride == 1 and weight.shape[0] == weight.shape[1]
         return y
 
     @staticmethod
@@ -52,10 +53,11 @@ class _ConvWrwFn(torch.autograd.Function):
                 # symmetric layers (tools/probe_conv2.py); same bf16 operands, fp32 accumulation
                 dx = F.conv2d(dy, K.provider().conv3x3_weight_rot180_t(wb), None, 1, 1)
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                st = ctx.stride
+                dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [st, st], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        dw = K.provider().conv3x3_wrw(x, dy)
-        return dx, dw.to(ctx.wdtype), None
+        dw = K.provider().conv3x3_wrw(x, dy, stride=ctx.stride)
+        return dx, dw.to(ctx.wdtype), None, None
 
 
 class WrwConv2d(nn.Conv2d):
@@ -70,13 +72,13 @@ class WrwConv2d(nn.Conv2d):
                                                   self.groups):
                 with torch.autocast("cuda", enabled=False):
                     wb = self.weight.detach().to(torch.bfloat16)
-                    return _ConvWrwFn.apply(xb, self.weight, wb)
+                    return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0])
         return super().forward(x)
 
 
 def _eligible(m):
     return (type(m) is nn.Conv2d and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.kernel_size == (3, 3)
-            and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None)
+            and m.stride in ((1, 1), (2, 2)) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None)
 
 
 def install_conv_wrw(module):

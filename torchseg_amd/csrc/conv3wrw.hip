@@ -274,15 +274,27 @@ __global__ __launch_bounds__(256) void conv3_wrw_tr_k(const bf16_t* __restrict__
 // 64 -> 64 case it was built for.  (furnace/base_model/resnet.py:24-29 every BasicBlock conv3x3 with stride 1; bisenet
 // network.py:43-52 refines / arms, :140-156 head conv_3x3.)
 struct W3GenGeom {
-  int B, H, W, tiles_h, tiles_w, ntiles;
-  int Cin, Cout, nci, npairs, bpp;      // channel counts, ci tiles, (oc tile, ci tile) pairs, blocks per pair
+  int B, H, W, tiles_h, tiles_w, ntiles;   // H, W: OUTPUT size (= size of dy)
+  int Hin, Win;                            // input size (= H, W for stride 1)
+  int Cin, Cout, nci, npairs, bpp;         // channel counts, ci tiles, (oc tile, ci tile) pairs, blocks per pair
 };
 
+// stride S in {1, 2}: the x patch of a 4 x 32 output tile is (4 S + 3 - S) x (32 S + 3 - S) input pixels (6 x 34 / 9 x 65),
+// still pixel-major in LDS; the K = output-pixel fragments of tap (kh, kw) start at patch pixel (S row + kh, S col + kw)
+// and step S pixels per K index -- every lane of a transposing read supplies its own address, so a stride is free.
+template <int S> struct W3S {
+  static constexpr int PR = S * W3_TH + 3 - S, PC = S * W3_TW + 3 - S, NPX = PR * PC;
+  static constexpr int XU = (NPX * 8 + 255) / 256;                                  // 16-byte x chunks per thread: 7 / 19
+  static constexpr size_t LDS = (size_t)(T3_DY + NPX * T3_RBE) * sizeof(bf16_t);    // 63,744 B / 136,896 B
+};
+
+template <int S>
 __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ part, W3GenGeom g) {
+  typedef W3S<S> P;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   bf16_t* dyL = reinterpret_cast<bf16_t*>(lds);       // [128 pixels][T3_RBE]
-  bf16_t* xL = dyL + T3_DY;                           // [204 pixels][T3_RBE]
+  bf16_t* xL = dyL + T3_DY;                           // [P::NPX pixels][T3_RBE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wh = wave & 1;            // oc half, ci half of the 64 x 64 pair
   const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
@@ -290,16 +302,16 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
   const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
 
   const int spart = tid & 7, spix = tid >> 3;
-  int xr[T3_XU], xc[T3_XU];
+  int xr[P::XU], xc[P::XU];
 #pragma unroll
-  for (int u = 0; u < T3_XU; ++u) {
+  for (int u = 0; u < P::XU; ++u) {
     const int pp = spix + 32 * u;
-    xr[u] = pp < T3_NPX ? pp / T3_PC : -1;
-    xc[u] = pp % T3_PC;
+    xr[u] = pp < P::NPX ? pp / P::PC : -1;
+    xc[u] = pp % P::PC;
   }
-  const int fbase = (8 * half + (i16 >> 2)) * T3_RBE + 16 * sub + 4 * (i16 & 3);
-  const lds_v4i16* afr = (const lds_v4i16*)(dyL + fbase + 32 * wm);
-  const lds_v4i16* bfr = (const lds_v4i16*)(xL + fbase + 32 * wh);
+  const int chan = 16 * sub + 4 * (i16 & 3);
+  const lds_v4i16* afr = (const lds_v4i16*)(dyL + (8 * half + (i16 >> 2)) * T3_RBE + chan + 32 * wm);
+  const lds_v4i16* bfr = (const lds_v4i16*)(xL + S * (8 * half + (i16 >> 2)) * T3_RBE + chan + 32 * wh);
 
   f32x16 acc[9];
 #pragma unroll
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   uint4 rd[W3_TH];
-  uint4 rx[T3_XU];
+  uint4 rx[P::XU];
   auto fetch = [&](int tile) {
     const int ow0 = (tile % g.tiles_w) * W3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
     const int b = tile / (g.tiles_w * g.tiles_h);
@@ -318,12 +330,13 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
     for (int u = 0; u < W3_TH; ++u)
       rd[u] = (oh0 + u < g.H && ow0 + spix < g.W) ? *reinterpret_cast<const uint4*>(dt + (int64_t)u * g.W * g.Cout)
                                                   : make_uint4(0, 0, 0, 0);
-    const bf16_t* xo = x + pix * g.Cin + ci0 + spart * 8;
+    const int ih0 = S * oh0 - 1, iw0 = S * ow0 - 1;                       // input pixel of patch (0, 0)
+    const bf16_t* xo = x + (((int64_t)b * g.Hin + ih0) * g.Win + iw0) * g.Cin + ci0 + spart * 8;
 #pragma unroll
-    for (int u = 0; u < T3_XU; ++u) {
-      const int ih = oh0 - 1 + xr[u], iw = ow0 - 1 + xc[u];
-      rx[u] = (xr[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-                  ? *reinterpret_cast<const uint4*>(xo + ((int64_t)(xr[u] - 1) * g.W + xc[u] - 1) * g.Cin)
+    for (int u = 0; u < P::XU; ++u) {
+      const int ih = ih0 + xr[u], iw = iw0 + xc[u];
+      rx[u] = (xr[u] >= 0 && ih >= 0 && ih < g.Hin && iw >= 0 && iw < g.Win)
+                  ? *reinterpret_cast<const uint4*>(xo + ((int64_t)xr[u] * g.Win + xc[u]) * g.Cin)
                   : make_uint4(0, 0, 0, 0);
     }
   };
@@ -336,13 +349,13 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
     for (int u = 0; u < W3_TH; ++u)
       *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = rd[u];
 #pragma unroll
-    for (int u = 0; u < T3_XU; ++u)
-      if (u < T3_XU - 1 || xr[u] >= 0)
+    for (int u = 0; u < P::XU; ++u)
+      if (u < P::XU - 1 || xr[u] >= 0)
         *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = rx[u];
     __syncthreads();
     if (tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < 8; ++ks) {                  // 16 output pixels: tile row ks >> 1, columns 16 (ks & 1) + 8 half ..
       union { v4i16 q[2]; bf16x8 v; } fa;
       fa.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
       fa.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
@@ -350,10 +363,10 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int px = ((ks >> 1) + kh) * T3_PC + (ks & 1) * 16 + kw;
+          const int px = (S * (ks >> 1) + kh) * P::PC + S * (ks & 1) * 16 + kw;   // patch pixel of the fragment's first K
           union { v4i16 q[2]; bf16x8 v; } fb;
           fb.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 0) * (T3_RBE / 4)));
-          fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4) * (T3_RBE / 4)));
+          fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4 * S) * (T3_RBE / 4)));
           acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
         }
     }
@@ -472,13 +485,17 @@ int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int6
   return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream);
 }
 
-static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % W3_C || Cout % W3_C) return TSG_E_SHAPE;
+static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout, int stride) {
+  if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || Cin % W3_C || Cout % W3_C) return TSG_E_SHAPE;
+  if (stride != 1 && stride != 2) return TSG_E_SHAPE;
+  const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;       // 3x3, padding 1
   const int64_t th = (H + W3_TH - 1) / W3_TH, tw = (W + W3_TW - 1) / W3_TW;
-  if (B * th * tw > 0x7fffffffLL || B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) > 0x7fffffff00LL) return TSG_E_SHAPE;
-  g->B = (int)B; g->H = (int)H; g->W = (int)W; g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
+  if (B * th * tw > 0x7fffffffLL || B * Hin * Win * (int64_t)(Cin > Cout ? Cin : Cout) > 0x7fffffff00LL) return TSG_E_SHAPE;
+  g->B = (int)B; g->H = (int)H; g->W = (int)W; g->Hin = (int)Hin; g->Win = (int)Win;
+  g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
   g->Cin = Cin; g->Cout = Cout; g->nci = Cin / W3_C; g->npairs = (Cout / W3_C) * g->nci;
   // one block per CU at a time (300 registers per lane): a second round of blocks would only add partials to fold
+  // (measured: 256 blocks 826 img/s, 512 blocks 815, 128 blocks 789)
   static int target = 0;
   if (!target) { const char* e = getenv("TSG_CONV_WRW_BLOCKS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
   int bpp = (target + g->npairs - 1) / g->npairs;
@@ -491,28 +508,35 @@ static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t H, int64_t W, int Cin, in
 int tsg_conv3x3_wrw_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
                                   int groups) {
   return dtype == TSG_BF16 && Cin > 0 && Cout > 0 && Cin % W3_C == 0 && Cout % W3_C == 0 && kh == 3 && kw == 3 &&
-         stride == 1 && pad == 1 && dilation == 1 && groups == 1;
+         (stride == 1 || stride == 2) && pad == 1 && dilation == 1 && groups == 1;
 }
 
-size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t H, int64_t W, int Cin, int Cout) {
+size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout, int stride) {
   W3GenGeom g;
-  if (w3gen_geom(&g, B, H, W, Cin, Cout)) return 0;
+  if (w3gen_geom(&g, B, Hin, Win, Cin, Cout, stride)) return 0;
   return (size_t)g.npairs * g.bpp * W3_C * W3_N * sizeof(float);
 }
 
-int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, int Cin, int Cout,
-                        void* ws, size_t ws_bytes, void* stream) {
+int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout,
+                        int stride, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !ws) return TSG_E_NULL;
   W3GenGeom g;
-  int e = w3gen_geom(&g, B, H, W, Cin, Cout);
+  int e = w3gen_geom(&g, B, Hin, Win, Cin, Cout, stride);
   if (e) return e;
-  if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout)) return TSG_E_WS;
+  if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, Hin, Win, Cin, Cout, stride)) return TSG_E_WS;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
-  hipLaunchKernelGGL(conv3_wrw_gen_k, dim3(g.npairs * g.bpp), dim3(256), T3_LDS, st, (const bf16_t*)x,
-                     (const bf16_t*)dy, (float*)ws, g);
+  if (stride == 1) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<1>::LDS));
+    hipLaunchKernelGGL(conv3_wrw_gen_k<1>, dim3(g.npairs * g.bpp), dim3(256), W3S<1>::LDS, st, (const bf16_t*)x,
+                       (const bf16_t*)dy, (float*)ws, g);
+  } else {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<2>::LDS));
+    hipLaunchKernelGGL(conv3_wrw_gen_k<2>, dim3(g.npairs * g.bpp), dim3(256), W3S<2>::LDS, st, (const bf16_t*)x,
+                       (const bf16_t*)dy, (float*)ws, g);
+  }
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
   TSG_CHECK_LAUNCH();

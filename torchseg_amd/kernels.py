@@ -486,11 +486,11 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_wrw_gen_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                            weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_wrw(self, x, dy, variant=None):
-        """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 channels_last (Cin, Cout multiples of 64; 3x3, stride 1, padding 1) ->
-        dw fp32 [Cout,Cin,3,3] channels_last.  64 -> 64 takes the single-pair kernel (variant "tr", or "v1" = the
-        transposed-staging kernel, TSG_CONV_WRW_IMPL); everything else the pair-tiled kernel ("gen"; also selectable for
-        64 -> 64 with variant="gen")."""
+    def conv3x3_wrw(self, x, dy, variant=None, stride=1):
+        """x [B,Cin,Hin,Win], dy [B,Cout,OH,OW] bf16 channels_last (Cin, Cout multiples of 64; 3x3, padding 1, stride 1 or
+        2) -> dw fp32 [Cout,Cin,3,3] channels_last.  64 -> 64 / stride 1 takes the single-pair kernel (variant "tr", or
+        "v1" = the transposed-staging kernel, TSG_CONV_WRW_IMPL); everything else the pair-tiled kernel ("gen"; also
+        selectable for 64 -> 64 with variant="gen")."""
         if variant is None:
             variant = os.environ.get("TSG_CONV_WRW_IMPL", "tr")
         for t in (x, dy):
@@ -498,10 +498,10 @@ class HipKernels:
                 raise ValueError("conv3x3_wrw expects bf16 channels_last tensors")
         B, Cin, H, W = x.shape
         Cout = dy.shape[1]
-        if tuple(dy.shape) != (B, Cout, H, W):
-            raise ValueError("conv3x3_wrw: dy must have the spatial shape of x (stride 1, padding 1)")
+        if tuple(dy.shape) != (B, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1):
+            raise ValueError("conv3x3_wrw: dy does not have the output shape of a 3x3 / padding 1 / stride %d convolution of x" % stride)
         dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        if Cin == 64 and Cout == 64 and variant != "gen":
+        if Cin == 64 and Cout == 64 and stride == 1 and variant != "gen":
             fn = self.lib.tsg_conv3x3_wrw_tr if variant == "tr" else self.lib.tsg_conv3x3_wrw
             ws = getattr(self, "_c3_ws", None)
             if ws is None or ws.device != x.device:
@@ -509,14 +509,14 @@ class HipKernels:
             L.check(fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
                     "tsg_conv3x3_wrw")
             return dw
-        wsb = self.lib.tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout)
+        wsb = self.lib.tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout, stride)
         if wsb == 0:
-            raise L.TsgError("conv3x3_wrw: unsupported shape %s -> %d channels" % (tuple(x.shape), Cout))
-        ws = getattr(self, "_c3g_ws", None)                       # one buffer, grown to the largest layer (<= 76 MB)
+            raise L.TsgError("conv3x3_wrw: unsupported shape %s -> %d channels, stride %d" % (tuple(x.shape), Cout, stride))
+        ws = getattr(self, "_c3g_ws", None)                       # one buffer, grown to the largest layer (<= 38 MB)
         if ws is None or ws.device != x.device or ws.numel() < wsb:
             ws = self._c3g_ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-        L.check(self.lib.tsg_conv3x3_wrw_gen(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(),
-                                             ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_gen")
+        L.check(self.lib.tsg_conv3x3_wrw_gen(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, int(stride),
+                                             ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_gen")
         return dw
 
     def conv3x3_weight_rot180_t(self, w):
