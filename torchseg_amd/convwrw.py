@@ -24,8 +24,11 @@ from . import kernels as K
 
 
 import os as _os
-# TSG_CONV_DGRAD_FWD=1|0 (default 1): data gradient of the C_in == C_out layers through a forward convolution
-_DGRAD_FWD = _os.environ.get("TSG_CONV_DGRAD_FWD", "1").strip().lower() not in ("0", "false", "no", "off", "")
+# TSG_CONV_DGRAD_FWD=0|1|2 (default 1): data gradient through a forward convolution for the C_in == C_out stride-1 layers
+# (1; their forward shapes are in the shipped MIOpen find-db) or for every stride-1 layer (2)
+_DGRAD_MODE = _os.environ.get("TSG_CONV_DGRAD_FWD", "1").strip().lower()
+_DGRAD_FWD = _DGRAD_MODE not in ("0", "false", "no", "off", "")
+_DGRAD_ANY = _DGRAD_MODE == "2"
 
 
 class _ConvWrwFn(torch.autograd.Function):
@@ -37,7 +40,7 @@ class _ConvWrwFn(torch.autograd.Function):
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
-        ctx.dgrad_fwd = _DGRAD_FWD and stride == 1 and weight.shape[0] == weight.shape[1]
+        ctx.dgrad_fwd = _DGRAD_FWD and stride == 1 and (_DGRAD_ANY or weight.shape[0] == weight.shape[1])
         return y
 
     @staticmethod
