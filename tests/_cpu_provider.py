@@ -147,6 +147,35 @@ class OracleProvider:
         denom = float(sel[4:5].view(torch.float32)[0])
         return (p * (w * float(gscale[0]) / denom).unsqueeze(1)).reshape(logits.shape).to(logits.dtype)
 
+    def upsample_fwd(self, x, add, OH, OW):
+        self._note("upsample_fwd")
+        y = torch.nn.functional.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=True)
+        return y if add is None else y + add
+
+    # fused upsample + criterion (tsg_ohem_up_*): the interpolation followed by the plain-CE stand-ins above
+    def ohem_up_supported(self, z, OH, OW, thresh):
+        return z.shape[1] <= 32 and OH >= 2 * z.shape[2] and OW >= 2 * z.shape[3]
+
+    def ohem_up_fwd(self, z, labels, OH, OW, ignore_label, thresh, min_kept, weight):
+        calls, self.calls = self.calls, None
+        try:
+            out = self.ohem_fwd(torch.nn.functional.interpolate(z.float(), size=(OH, OW), mode="bilinear", align_corners=True),
+                                labels, ignore_label, thresh, min_kept, weight)
+        finally:
+            self.calls = calls
+        self._note("ohem_up_fwd")
+        return out
+
+    def ohem_up_bwd(self, z, labels, OH, OW, ignore_label, weight, nll, lse, sel, gscale):
+        self._note("ohem_up_bwd")
+        calls, self.calls = self.calls, None
+        try:
+            full = torch.nn.functional.interpolate(z.float(), size=(OH, OW), mode="bilinear", align_corners=True)
+            d = self.ohem_bwd(full, labels, ignore_label, weight, nll, lse, sel, gscale)
+            return self._up_bwd(d, z.shape[2], z.shape[3]).to(z.dtype)
+        finally:
+            self.calls = calls
+
     def upsample_presum_fwd(self, x, x2, OH, OW):
         self._note("upsample_presum_fwd")
         return torch.nn.functional.interpolate(x + x2, size=(OH, OW), mode="bilinear", align_corners=True)

@@ -106,7 +106,8 @@ class _RefStyleHead(nn.Module):
 @pytest.mark.parametrize("log_softmax,ignore,C", [(True, -1, 150), (False, 255, 19)])
 def test_unchanged_call_pattern_runs_on_the_hip_kernels(cuda, log_softmax, ignore, C):
     """nn.CrossEntropyLoss built by an unchanged train.py, called by an unchanged network.py, under our DDP wrapper:
-    tsg_ohem_fwd/bwd must run (no aten log_softmax / nll_loss), and the numbers must equal the CPU's."""
+    tsg_ohem_fwd/bwd must run (no aten log_softmax / nll_loss) — for <= 32 classes their fused-upsample forms, so
+    that not even the full-resolution logits exist — and the numbers must equal the CPU's."""
     from torchseg_amd import kernels as K
     from torchseg_amd.ddp import DistributedDataParallel
     torch.manual_seed(4)
@@ -123,17 +124,21 @@ def test_unchanged_call_pattern_runs_on_the_hip_kernels(cuda, log_softmax, ignor
     ref_loss.backward()
     kp = K.provider()
     calls = []
-    orig_f, orig_b = kp.ohem_fwd, kp.ohem_bwd
+    orig_f, orig_b, orig_uf, orig_ub = kp.ohem_fwd, kp.ohem_bwd, kp.ohem_up_fwd, kp.ohem_up_bwd
     kp.ohem_fwd = lambda *a, **k: (calls.append("fwd"), orig_f(*a, **k))[1]
     kp.ohem_bwd = lambda *a, **k: (calls.append("bwd"), orig_b(*a, **k))[1]
+    kp.ohem_up_fwd = lambda *a, **k: (calls.append("up_fwd"), orig_uf(*a, **k))[1]
+    kp.ohem_up_bwd = lambda *a, **k: (calls.append("up_bwd"), orig_ub(*a, **k))[1]
     try:
         with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
             loss = net(x.to(cuda), y.to(cuda))
             loss.backward()
     finally:
-        del kp.ohem_fwd, kp.ohem_bwd
-    assert calls == ["fwd", "bwd"]
+        del kp.ohem_fwd, kp.ohem_bwd, kp.ohem_up_fwd, kp.ohem_up_bwd
+    assert calls == (["up_fwd", "up_bwd"] if C <= 32 else ["fwd", "bwd"])
     ops = {e.key for e in prof.key_averages()}
+    if C <= 32:
+        assert not any("upsample_bilinear2d" in o for o in ops), ops
     assert not ({"aten::_log_softmax", "aten::nll_loss2d_forward", "aten::nll_loss_nd"} & ops), ops
     assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
     for (n, p), (_, q) in zip(net.module.named_parameters(), ref.named_parameters()):

@@ -86,9 +86,19 @@ def test_deferred_interpolate_is_transparent(cuda):
     (log_softmax, arithmetic, indexing) sees exactly the materialised tensor, with autograd."""
     from torchseg_amd import kernels as K
     from torchseg_amd.losses import ProbOhemCrossEntropy2d
-    from torchseg_amd.upsample import DeferredUpsample, install_aten_overrides, install_deferred_interpolate
+    from torchseg_amd.upsample import (DeferredUpsample, install_aten_overrides, install_deferred_interpolate,
+                                       uninstall_deferred_interpolate)
     install_aten_overrides()
     install_deferred_interpolate()
+    try:
+        _transparent_body(cuda, DeferredUpsample, K, ProbOhemCrossEntropy2d)
+    finally:
+        uninstall_deferred_interpolate()
+    assert not isinstance(F.interpolate(torch.randn(1, 3, 4, 4, device=cuda), scale_factor=8, mode="bilinear",
+                                        align_corners=True), DeferredUpsample)
+
+
+def _transparent_body(cuda, DeferredUpsample, K, ProbOhemCrossEntropy2d):
     x = torch.randn(2, 19, 8, 8, device=cuda, requires_grad=True)
     y = F.interpolate(x, scale_factor=8, mode="bilinear", align_corners=True)
     assert isinstance(y, DeferredUpsample) and tuple(y.shape) == (2, 19, 64, 64)

@@ -129,3 +129,59 @@ def test_bad_labels_are_reported_not_indexed(standin, monkeypatch):
     assert int(sel[5]) == 1 and torch.isfinite(loss)
     with pytest.raises(Exception, match="neither ignore_label nor a class"):
         losses.check_labels(sel)
+
+
+@pytest.mark.parametrize("via_log_softmax", [False, True])
+def test_head_upsampling_stays_pending_for_the_criterion(standin, via_log_softmax):
+    """pspnet network.py:46-56 / bisenet network.py:164-166 + train.py's criterion: F.interpolate(logits, x8) ->
+    [F.log_softmax ->] CrossEntropyLoss runs as ONE fused call (tsg_ohem_up_*), the full-resolution logits are never
+    produced; gradients equal eager's."""
+    from torchseg_amd.fusion import DeferredLogSoftmax, FuseMode
+    from torchseg_amd.upsample import DeferredUpsample
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 7, 4, 5, generator=g)
+    y = torch.randint(0, 7, (2, 32, 40), generator=g)
+    y[:, :3] = 255
+    crit = nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+
+    def head(t):
+        fm = F.interpolate(t * 1.5, scale_factor=8, mode='bilinear', align_corners=True)
+        return F.log_softmax(fm, dim=1) if via_log_softmax else fm
+
+    xr = x.clone().requires_grad_(True)
+    ref = crit(head(xr), y)
+    ref.backward()
+    xf = x.clone().requires_grad_(True)
+    with FuseMode(head=True):
+        fm = head(xf)
+        assert isinstance(fm, DeferredLogSoftmax if via_log_softmax else DeferredUpsample)
+        out = crit(fm, y)
+    out.backward()
+    assert standin.calls == ["ohem_up_fwd", "ohem_up_bwd"]
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(xf.grad, xr.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_pending_upsampling_is_a_real_tensor_for_everything_else(standin):
+    from torchseg_amd.fusion import FuseMode, materialize
+    from torchseg_amd.upsample import DeferredUpsample
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 5, 3, 3, generator=g)
+    ref = F.interpolate(x, scale_factor=4, mode='bilinear', align_corners=True)
+    xf = x.clone().requires_grad_(True)
+    with FuseMode(head=True):
+        up = F.interpolate(xf, scale_factor=4, mode='bilinear', align_corners=True)
+        assert isinstance(up, DeferredUpsample)
+        assert isinstance(F.interpolate(xf, scale_factor=2, mode='bilinear', align_corners=True), torch.Tensor)   # < 4
+        assert isinstance(F.interpolate(xf, scale_factor=4, mode='nearest'), torch.Tensor)
+        wide = torch.randn(1, 64, 3, 3, requires_grad=True)
+        assert isinstance(F.interpolate(wide, scale_factor=4, mode='bilinear', align_corners=True), torch.Tensor)  # features
+        s = torch.sigmoid(up)                          # e.g. a focal-loss head or an evaluator
+        m = up.argmax(1)
+    assert isinstance(s, torch.Tensor) and isinstance(m, torch.Tensor)
+    torch.testing.assert_close(s, torch.sigmoid(ref))
+    out = materialize(up)
+    assert isinstance(out, torch.Tensor)
+    torch.testing.assert_close(out, ref)
+    with FuseMode(head=True), torch.no_grad():         # eval path: nothing is deferred
+        assert isinstance(F.interpolate(x, scale_factor=4, mode='bilinear', align_corners=True), torch.Tensor)

@@ -11,15 +11,15 @@ def test_conv_module_swaps_select_only_the_intended_layers_and_pass_through_on_c
     net = nn.Sequential(
         nn.Conv2d(3, 64, 7, 2, 3, bias=False),          # image stem            -> StemConv2d
         nn.Conv2d(64, 64, 3, 1, 1, bias=False),         # layer1-style 3x3      -> WrwConv2d
-        nn.Conv2d(64, 64, 3, 2, 1, bias=False),         # stride 2              -> untouched
+        nn.Conv2d(64, 64, 3, 2, 1, bias=False),         # stride 2 (down-sampling block) -> WrwConv2d
         nn.Conv2d(64, 64, 3, 1, 2, dilation=2, bias=False),   # dilated          -> untouched
         nn.Conv2d(64, 64, 3, 1, 1, bias=True),          # biased                -> untouched
         nn.Conv2d(3, 64, 7, 2, 3, bias=True),           # biased stem           -> untouched
     )
     ref = [m.weight.detach().clone() for m in net]
     keys = list(net.state_dict().keys())
-    assert install_stem_conv(net) == 1 and install_conv_wrw(net) == 1
-    assert [type(m) for m in net] == [StemConv2d, WrwConv2d, nn.Conv2d, nn.Conv2d, nn.Conv2d, nn.Conv2d]
+    assert install_stem_conv(net) == 1 and install_conv_wrw(net) == 2
+    assert [type(m) for m in net] == [StemConv2d, WrwConv2d, WrwConv2d, nn.Conv2d, nn.Conv2d, nn.Conv2d]
     assert list(net.state_dict().keys()) == keys                       # same parameters, same names
     assert all(torch.equal(m.weight, w) for m, w in zip(net, ref))
     x = torch.randn(1, 3, 32, 32)

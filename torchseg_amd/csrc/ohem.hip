@@ -500,116 +500,140 @@ __global__ __launch_bounds__(kT) void ohem_bwd_k(
 // (SURVEY.md §8f-1).  z is [B, C, IH, IW]; the virtual logits are [B, C, OH, OW].
 //
 // Both directions are "column walkers": a thread owns ONE output column ox and
-// walks down a band of output rows.  For its column it keeps, per class, the two
-// horizontally interpolated source rows H0[c] / H1[c] (rows y0 / y1) in registers;
-// they change only when y0 advances (every ~scale output rows), so per pixel and
-// class the logit costs 2 FMAs:  v_c = (1-ly)*H0[c] + ly*H1[c]   — the same
-// operations, in the same order, as the 4-tap formula of aten::upsample_bilinear2d.
-// z itself is tiny (L2-resident) and read with wave-broadcast loads.
-//   forward : per pixel max / sum-exp over the C register values (1 exp per class),
-//             then the shared pass-A accounting.  HBM: label read + nll/lse write.
-//   backward: g_c = coef*(softmax_c - [c==t]) is folded straight into the vertical
-//             transposed taps (accA/accB per class, flushed when a source row is
-//             complete) -> V[B,C,IH,OW] fp32; a small second kernel applies the
-//             horizontal transposed taps.  No atomics, fixed order => deterministic.
+// walks down output rows.  Per class it keeps the horizontally interpolated source
+// row H0[c] (row y0) and the row difference D[c] = H1[c] - H0[c] in registers (in
+// log2 units: z is multiplied by log2(e) when it is staged in LDS), so a logit
+// costs one FMA, v_c = fma(ly, D[c], H0[c]), and the softmax one v_exp_f32 per
+// class.  H0 / D change only when y0 advances (every ~scale rows) and are then
+// rebuilt from the LDS copy of the two source rows — never from their old values,
+// so a pixel's logits do not depend on how the rows were banded.  The class count
+// is a compile-time pad CP (classes >= C hold -1e30: exp2 gives 0), the loops have
+// no per-class branches.
+//   forward : tile = 256 columns x 32 rows; the z window of the tile (<= 6 x 34
+//             source pixels x CP) sits in LDS; max / sum-exp2 / log2 in registers;
+//             the target logit is re-evaluated from the window with the same
+//             expressions (4 LDS reads) instead of a CP-long select chain.
+//             HBM: label read + nll / lse write.
+//   backward: block = RB source rows x SB source columns of dz, threads = every
+//             output column whose taps touch them (neighbouring blocks overlap by
+//             one source column / row: each dz element has exactly one owner, no
+//             atomics, fixed summation order).  g_c = coef*(softmax_c - [c==t]) is
+//             folded into the vertical transposed taps in registers (accA / accB);
+//             when a source row is complete the block applies the horizontal
+//             transposed taps through LDS and stores the dz row.  The one-hot is
+//             a row of an LDS table (ds_read_b128), not a compare chain.
 // =============================================================================
-constexpr int kFwdBand = 32;                 // output rows per forward band
-constexpr int kBwdCH = 8;                    // source rows owned by a backward block
+constexpr int kFwdBand = 32;                 // output rows per forward tile
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+constexpr float kNegBig = -1.0e30f;
 
-template <typename T, int CMAX>
-__device__ __forceinline__ void load_hrow(const T* __restrict__ zb, int C, int64_t plane, int IW, int y,
-                                          int x0, int x1, float lx, float (&H)[CMAX]) {
-  const float hx = 1.f - lx;
-  const T* r = zb + (int64_t)y * IW;
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c)
-    if (c < C) H[c] = hx * ld1<T>(r + c * plane + x0) + lx * ld1<T>(r + c * plane + x1);
+struct UpFwdGeom { int C, IH, IW, OH, OW; float sy, sx; int WR, WC, xblocks, bands, hist_words; };
+
+__device__ __forceinline__ void src_index0(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+  src_index(scale, dst, in_size, i0, i1, l1);
+  if (i1 == i0) l1 = 0.f;                    // last source row / column: both taps coincide, weight 1
 }
 
-template <typename T, int LT, int CMAX>
-__global__ __launch_bounds__(kT) void ohem_up_pass_a(
-    const T* __restrict__ z, const void* __restrict__ labels, int64_t B, int C, int IH, int IW,
-    int OH, int OW, float sy, float sx, int64_t ignore_label, float thresh, int64_t tb, int shift0,
-    int bins0, const float* __restrict__ weight, float* __restrict__ nll_out,
-    float* __restrict__ lse_out, uint32_t* __restrict__ hist0, BlkPart* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
-  __shared__ uint8_t lab_s[kFwdBand * kT];          // labels of the current band (255 = ignored), C <= 32
+template <typename T, int LT, int CP>
+__global__ __launch_bounds__(kT) void ohem_up_fwd_k(
+    const T* __restrict__ z, const void* __restrict__ labels, int64_t B, UpFwdGeom g,
+    int64_t ignore_label, float thresh, int64_t tb, int shift0, int bins0,
+    const float* __restrict__ weight, float* __restrict__ nll_out, float* __restrict__ lse_out,
+    uint32_t* __restrict__ hist0, BlkPart* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lh[];       // [hist_words] histogram
+  float* Zw = reinterpret_cast<float*>(lh + g.hist_words);            // [CP][WR][WC] window of z * log2(e)
+  uint8_t* lab_s = reinterpret_cast<uint8_t*>(Zw + CP * g.WR * g.WC); // [kFwdBand][kT] labels (255 = ignored)
   const int tid = threadIdx.x;
   for (int i = tid; i < bins0; i += kT) lh[i] = 0;
-  __syncthreads();
   PassAcc acc;
-  const int xblocks = (OW + kT - 1) / kT, bands = (OH + kFwdBand - 1) / kFwdBand;
-  const int64_t total = B * bands * (int64_t)xblocks;
+  const int C = g.C, IH = g.IH, IW = g.IW, OH = g.OH, OW = g.OW, WR = g.WR, WC = g.WC;
+  const int64_t total = B * g.bands * (int64_t)g.xblocks;
   const int64_t plane = (int64_t)IH * IW;
   for (int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
-    const int xb = (int)(tile % xblocks);
-    const int band = (int)((tile / xblocks) % bands);
-    const int64_t b = tile / ((int64_t)xblocks * bands);
+    const int xb = (int)(tile % g.xblocks);
+    const int band = (int)((tile / g.xblocks) % g.bands);
+    const int64_t b = tile / ((int64_t)g.xblocks * g.bands);
+    const int oy_beg = band * kFwdBand;
+    const int oy_end = oy_beg + kFwdBand < OH ? oy_beg + kFwdBand : OH;
     const int ox = xb * kT + tid;
-    if (ox >= OW) continue;
-    int x0, x1; float lx;
-    src_index(sx, ox, IW, x0, x1, lx);
+    const bool live = ox < OW;
+    int ys_lo, xs_lo, t1; float tf;
+    src_index0(g.sy, oy_beg, IH, ys_lo, t1, tf);
+    src_index0(g.sx, xb * kT, IW, xs_lo, t1, tf);
     const T* zb = z + b * C * plane;
-    float H0[CMAX], H1[CMAX];
-    int cy0 = -1, cy1 = -1;
-    const int oy_end = (band + 1) * kFwdBand < OH ? (band + 1) * kFwdBand : OH;
-    // side data of the whole band first (kFwdBand independent loads in flight per thread);
-    // each thread only ever reads back its own column, so no barrier is needed.
-#pragma unroll
-    for (int u = 0; u < kFwdBand; ++u) {
-      const int oy = band * kFwdBand + u;
-      int64_t lab = ignore_label;
-      if (oy < oy_end) lab = Lab<LT>::get(labels, (b * OH + oy) * (int64_t)OW + ox);
-      const bool is_cls = label_is_class(lab, ignore_label, C);
-      if (!is_cls && lab != ignore_label) acc.cnt_bad++;
-      lab_s[u * kT + tid] = is_cls ? (uint8_t)lab : (uint8_t)255;
+    __syncthreads();                                   // the previous tile's readers are done (also orders lh init)
+    for (int i = tid; i < CP * WR * WC; i += kT) {
+      const int c = i / (WR * WC);
+      const int rr = (i / WC) % WR, xx = i % WC;
+      const int yy = ys_lo + rr < IH ? ys_lo + rr : IH - 1;
+      const int xg = xs_lo + xx < IW ? xs_lo + xx : IW - 1;
+      Zw[i] = c < C ? ld1<T>(zb + c * plane + (int64_t)yy * IW + xg) * kLog2e : kNegBig;
     }
-    for (int oy = band * kFwdBand; oy < oy_end; ++oy) {
+    // labels of the whole tile: kFwdBand independent loads in flight per thread; each thread only ever reads
+    // back its own column
+#pragma unroll 1
+    for (int u0 = 0; u0 < kFwdBand; u0 += 8) {
+      int64_t lab[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int oy = oy_beg + u0 + u;
+        lab[u] = (live && oy < oy_end) ? Lab<LT>::get(labels, (b * OH + oy) * (int64_t)OW + ox) : ignore_label;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool is_cls = label_is_class(lab[u], ignore_label, C);
+        if (!is_cls && lab[u] != ignore_label) acc.cnt_bad++;
+        lab_s[(u0 + u) * kT + tid] = is_cls ? (uint8_t)lab[u] : (uint8_t)255;
+      }
+    }
+    __syncthreads();
+    if (!live) continue;
+    int x0, x1; float lx;
+    src_index0(g.sx, ox, IW, x0, x1, lx);
+    const int xl0 = x0 - xs_lo, xl1 = x1 - xs_lo;
+    float H0[CP], D[CP];
+    int cy0 = -1, ro0 = 0, ro1 = 0;
+    for (int oy = oy_beg; oy < oy_end; ++oy) {
       int y0, y1; float ly;
-      src_index(sy, oy, IH, y0, y1, ly);
+      src_index0(g.sy, oy, IH, y0, y1, ly);
+      y0 = __builtin_amdgcn_readfirstlane(y0);
+      y1 = __builtin_amdgcn_readfirstlane(y1);
       if (y0 != cy0) {
-        if (y0 == cy1) {
+        ro0 = (y0 - ys_lo) * WC; ro1 = (y1 - ys_lo) * WC;
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c) H0[c] = H1[c];
-        } else {
-          load_hrow<T, CMAX>(zb, C, plane, IW, y0, x0, x1, lx, H0);
+        for (int c = 0; c < CP; ++c) {
+          const float* zr = Zw + c * WR * WC;
+          const float a0 = zr[ro0 + xl0], a1 = zr[ro0 + xl1], b0 = zr[ro1 + xl0], b1 = zr[ro1 + xl1];
+          const float h0 = __builtin_fmaf(lx, a1 - a0, a0), h1 = __builtin_fmaf(lx, b1 - b0, b0);
+          H0[c] = h0; D[c] = h1 - h0;
         }
-        cy0 = y0; cy1 = -1;
+        cy0 = y0;
       }
-      if (y1 != cy1) {
-        if (y1 == cy0) {
+      float v[CP];
+      float m = kNegBig;
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c) H1[c] = H0[c];
-        } else {
-          load_hrow<T, CMAX>(zb, C, plane, IW, y1, x0, x1, lx, H1);
-        }
-        cy1 = y1;
-      }
-      const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
-      const int lab = lab_s[(oy - band * kFwdBand) * kT + tid];
-      const bool valid = lab != 255;
-      const int t = valid ? lab : 0;
-      const float hy = 1.f - ly;
-      float v[CMAX];
-      float m = -INFINITY, xt = 0.f;
-#pragma unroll
-      for (int c = 0; c < CMAX; ++c) {
-        if (c < C) {
-          v[c] = hy * H0[c] + ly * H1[c];
-          m = fmaxf(m, v[c]);
-          if (c == t) xt = v[c];
-        }
-      }
+      for (int c = 0; c < CP; ++c) { v[c] = __builtin_fmaf(ly, D[c], H0[c]); m = fmaxf(m, v[c]); }
       float ssum = 0.f;
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c)
-        if (c < C) ssum += __expf(v[c] - m);
-      const float ls = m + logf(ssum);
-      float nl = ls - xt;
+      for (int c = 0; c < CP; ++c) ssum += __builtin_amdgcn_exp2f(v[c] - m);
+      const float l2 = m + __builtin_amdgcn_logf(ssum);
+      const int lab = lab_s[(oy - oy_beg) * kT + tid];
+      const bool valid = lab != 255;
+      const int t = valid ? lab : 0;
+      float xt;
+      {  // the target logit, by the expressions that produced v[t]
+        const float* zr = Zw + t * WR * WC;
+        const float a0 = zr[ro0 + xl0], a1 = zr[ro0 + xl1], b0 = zr[ro1 + xl0], b1 = zr[ro1 + xl1];
+        const float h0 = __builtin_fmaf(lx, a1 - a0, a0), h1 = __builtin_fmaf(lx, b1 - b0, b0);
+        xt = __builtin_fmaf(ly, h1 - h0, h0);
+      }
+      float nl = (l2 - xt) * kLn2;
       nl = nl < 0.f ? 0.f : nl;
       nl = valid ? nl : 0.f;
+      const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
       nll_out[gp] = nl;
-      lse_out[gp] = ls;
+      lse_out[gp] = l2 * kLn2;
       const float w = (weight && valid) ? weight[t] : 1.f;
       account(acc, valid, nl, w, thresh, tb, shift0, bins0, lh);
     }
@@ -617,152 +641,219 @@ __global__ __launch_bounds__(kT) void ohem_up_pass_a(
   fold_block(acc, lh, bins0, hist0, part);
 }
 
-// backward, vertical part.  grid = (x-blocks, source-row bands, B); V[b][c][iy][ox] fp32.
-template <typename T, int LT, int CMAX>
-__global__ __launch_bounds__(kT) void ohem_up_bwd_v(
-    const T* __restrict__ z, const void* __restrict__ labels, int C, int IH, int IW, int OH, int OW,
-    float sy, float sx, int64_t ignore_label, const float* __restrict__ weight,
-    const float* __restrict__ nll, const float* __restrict__ lse, const int32_t* __restrict__ sel,
-    const float* __restrict__ gscale, float* __restrict__ V) {
-  int ox = blockIdx.x * kT + threadIdx.x;
-  const bool live = ox < OW;
-  if (!live) return;
-  const int r0 = blockIdx.y * kBwdCH;
-  const int r1 = (r0 + kBwdCH < IH) ? r0 + kBwdCH : IH;
+struct UpBwdGeom { int C, IH, IW, OH, OW; float sy, sx; int RB, SB, XS; };
+
+template <typename T, int LT, int CP, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
+    const T* __restrict__ z, const void* __restrict__ labels, UpBwdGeom g, int64_t ignore_label,
+    const float* __restrict__ weight, const float* __restrict__ nll, const float* __restrict__ lse,
+    const int32_t* __restrict__ sel, const float* __restrict__ gscale, T* __restrict__ dz) {
+  constexpr int VP = CP + 1;                          // odd row stride: column-major writes and class-major reads both spread over the banks
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NT = blockDim.x, tid = threadIdx.x;
+  const int C = g.C, IH = g.IH, IW = g.IW, OH = g.OH, OW = g.OW, XS = g.XS;
+  float* oh = smem;                                   // [CP][CP] one-hot rows (16-byte aligned rows: CP % 4 == 0)
+  float* Zr = oh + CP * CP;                           // [2][CP][XS] the two live source rows * log2(e)
+  float* lxs = Zr + 2 * CP * XS;                      // [NT] lambda_x of every column of the block
+  float* Vs = lxs + NT;                               // [NT][VP] a completed source row, before the horizontal taps
+  int* xst = reinterpret_cast<int*>(Vs + NT * VP);    // [XS + 2] first column whose x0 is xs_lo + j
+  const int s0 = blockIdx.x * g.SB, s1 = s0 + g.SB < IW ? s0 + g.SB : IW;
+  const int r0 = blockIdx.y * g.RB, r1 = r0 + g.RB < IH ? r0 + g.RB : IH;
   const int64_t b = blockIdx.z;
+  int xlo, xhi, tmp;
+  footprint(g.sx, s0, OW, xlo, tmp);
+  footprint(g.sx, s1 - 1, OW, tmp, xhi);
+  const int nact = xhi - xlo + 1;                     // <= NT (host)
+  const bool live = tid < nact;
+  const int ox = live ? xlo + tid : xhi;
+  int x0, x1, xs_lo; float lx, tf;
+  src_index0(g.sx, ox, IW, x0, x1, lx);
+  src_index0(g.sx, xlo, IW, xs_lo, tmp, tf);
+  const int xl0 = x0 - xs_lo, xl1 = x1 - xs_lo;
+  lxs[tid] = live ? lx : 0.f;
+  for (int i = tid; i < CP * CP; i += NT) oh[i] = (i / CP == i % CP) ? 1.f : 0.f;
+  for (int j = tid; j < XS + 2; j += NT) xst[j] = nact;
+  __syncthreads();
+  if (live) {
+    int p0 = -1, p1; float pf;
+    if (tid > 0) src_index0(g.sx, ox - 1, IW, p0, p1, pf);
+    if (p0 != x0) xst[xl0] = tid;                     // OW >= 2 IW: x0 advances by at most 1 per column
+  }
   const float thr = __uint_as_float((uint32_t)sel[0]);
   const int branch = sel[3];
-  const float g = gscale[0] / reinterpret_cast<const float*>(sel)[4];
+  const float gs = gscale[0] / reinterpret_cast<const float*>(sel)[4];
   const int64_t plane = (int64_t)IH * IW;
   const T* zb = z + b * C * plane;
-  float* Vb = V + b * C * (int64_t)IH * OW;
-  int x0, x1; float lx;
-  src_index(sx, ox, IW, x0, x1, lx);
   // output rows whose y0 lies in [r0-1, r1-1]
   int oy_lo = 0, oy_hi = OH - 1;
-  if (sy > 0.f) {
-    const float inv = 1.f / sy;
-    int l = (int)ceilf((float)(r0 - 1) * inv) - 1;
-    int h = (int)floorf((float)r1 * inv) + 1;
+  if (g.sy > 0.f) {
+    const float inv = 1.f / g.sy;
+    const int l = (int)ceilf((float)(r0 - 1) * inv) - 1;
+    const int h = (int)floorf((float)r1 * inv) + 1;
     oy_lo = l < 0 ? 0 : l;
     oy_hi = h > OH - 1 ? OH - 1 : h;
   }
-  float H0[CMAX], H1[CMAX], accA[CMAX], accB[CMAX];
+  float H0[CP], D[CP], accA[CP], accB[CP];
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) { accA[c] = 0.f; accB[c] = 0.f; H0[c] = 0.f; H1[c] = 0.f; }
-  int cy0 = -1, cy1 = -1;
-  int cur = -2;                                      // source row accA belongs to
-  auto flush = [&](int row, const float (&a)[CMAX]) {
-    if (row >= r0 && row < r1) {
+  for (int c = 0; c < CP; ++c) { accA[c] = 0.f; accB[c] = 0.f; H0[c] = 0.f; D[c] = 0.f; }
+  int cur = -2;                                       // source row accA belongs to (accB: cur + 1)
+  int staged0 = -1, staged1 = -1;                     // source rows held by the two ring slots
+
+  auto flush = [&](int row, const float (&a)[CP]) {   // block-uniform
+    if (row < r0 || row >= r1) return;
+    __syncthreads();                                  // the previous horizontal pass has read Vs
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c)
-        if (c < C) Vb[((int64_t)c * IH + row) * OW + ox] = a[c];
+    for (int c = 0; c < CP; ++c) Vs[tid * VP + c] = live ? a[c] : 0.f;
+    __syncthreads();
+    const int nS = s1 - s0;
+    for (int idx = tid; idx < C * nS; idx += NT) {
+      const int c = idx % C, s = s0 + idx / C, j = s - xs_lo;
+      float sum = 0.f;
+      const int xa = xst[j], xb = xst[j + 1];
+      for (int x = xa; x < xb; ++x) sum = __builtin_fmaf(1.f - lxs[x], Vs[x * VP + c], sum);
+      if (j >= 1) {
+        const int xp = xst[j - 1];
+        for (int x = xp; x < xa; ++x) sum = __builtin_fmaf(lxs[x], Vs[x * VP + c], sum);
+      }
+      st1<T>(dz + ((b * C + c) * IH + row) * (int64_t)IW + s, sum);
     }
   };
-  constexpr int G = 16;                                // rows whose side data are fetched together
-  __shared__ float coef_s[G * kT];                     // g * w_t for kept pixels, 0 otherwise
-  __shared__ float lse_s[G * kT];
-  __shared__ uint8_t lab_s[G * kT];
-  const int tid = threadIdx.x;
-  for (int oyg = oy_lo; oyg <= oy_hi; oyg += G) {
-    // independent loads first; a thread only reads back its own column => no barrier
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const bool in = oyg + u <= oy_hi;
-      const int64_t gp = (b * OH + (in ? oyg + u : oy_hi)) * (int64_t)OW + ox;
-      const int64_t lab = in ? Lab<LT>::get(labels, gp) : ignore_label;
-      const float nl = nll[gp];
-      const float ls = lse[gp];
-      const bool valid = label_is_class(lab, ignore_label, C);
-      bool kept = valid;
-      if (valid && branch != 2) kept = prob_of_nll(nl) <= thr;
-      coef_s[u * kT + tid] = kept ? g * (weight ? weight[lab] : 1.f) : 0.f;
-      lse_s[u * kT + tid] = ls;
-      lab_s[u * kT + tid] = valid ? (uint8_t)lab : (uint8_t)255;
+  auto stage = [&](int slot, int y) {
+    for (int i = tid; i < CP * XS; i += NT) {
+      const int c = i / XS, xx = i % XS;
+      const int xg = xs_lo + xx < IW ? xs_lo + xx : IW - 1;
+      Zr[slot * CP * XS + i] = c < C ? ld1<T>(zb + c * plane + (int64_t)y * IW + xg) * kLog2e : kNegBig;
     }
-    const int oyg_end = (oyg + G - 1 < oy_hi) ? oyg + G - 1 : oy_hi;
-    for (int oy = oyg; oy <= oyg_end; ++oy) {
-      int y0, y1; float ly;
-      src_index(sy, oy, IH, y0, y1, ly);
-      if (y0 < r0 - 1 || y0 > r1 - 1) continue;
-      if (y0 != cur) {
-        if (cur >= 0) {
-          flush(cur, accA);
-          if (y0 == cur + 1) {
+  };
+  struct Side { int64_t lab; float nl, ls; };
+  auto load_side = [&](int oy) {
+    Side sd;
+    const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
+    sd.lab = live ? Lab<LT>::get(labels, gp) : ignore_label;
+    sd.nl = nll[gp];
+    sd.ls = lse[gp];
+    return sd;
+  };
+  Side nxt = load_side(oy_lo);
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const Side sd = nxt;
+    if (oy < oy_hi) nxt = load_side(oy + 1);
+    int y0, y1; float ly;
+    src_index0(g.sy, oy, IH, y0, y1, ly);
+    y0 = __builtin_amdgcn_readfirstlane(y0);
+    y1 = __builtin_amdgcn_readfirstlane(y1);
+    if (y0 < r0 - 1 || y0 > r1 - 1) continue;
+    if (y0 != cur) {
+      if (cur >= 0) {
+        flush(cur, accA);
+        if (y0 == cur + 1) {
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) { accA[c] = accB[c]; accB[c] = 0.f; }
-          } else {
-            flush(cur + 1, accB);
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c) { accA[c] = 0.f; accB[c] = 0.f; }
-          }
-        }
-        cur = y0;
-      }
-      if (y0 != cy0) {
-        if (y0 == cy1) {
-#pragma unroll
-          for (int c = 0; c < CMAX; ++c) H0[c] = H1[c];
+          for (int c = 0; c < CP; ++c) { accA[c] = accB[c]; accB[c] = 0.f; }
         } else {
-          load_hrow<T, CMAX>(zb, C, plane, IW, y0, x0, x1, lx, H0);
-        }
-        cy0 = y0; cy1 = -1;
-      }
-      if (y1 != cy1) {
-        if (y1 == cy0) {
+          flush(cur + 1, accB);
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c) H1[c] = H0[c];
-        } else {
-          load_hrow<T, CMAX>(zb, C, plane, IW, y1, x0, x1, lx, H1);
+          for (int c = 0; c < CP; ++c) { accA[c] = 0.f; accB[c] = 0.f; }
         }
-        cy1 = y1;
       }
-      const float coef = coef_s[(oy - oyg) * kT + tid];
-      if (coef != 0.f) {
-        const float ls = lse_s[(oy - oyg) * kT + tid];
-        const int t = lab_s[(oy - oyg) * kT + tid];
-        const float hy = 1.f - ly;
-        const bool same = (y1 == y0);
+      __syncthreads();                                // everybody has built H0 / D from the rows about to be replaced
+      if (((y0 & 1) ? staged1 : staged0) != y0) { stage(y0 & 1, y0); if (y0 & 1) staged1 = y0; else staged0 = y0; }
+      if (y1 != y0 && ((y1 & 1) ? staged1 : staged0) != y1) { stage(y1 & 1, y1); if (y1 & 1) staged1 = y1; else staged0 = y1; }
+      __syncthreads();
+      const float* za = Zr + (y0 & 1) * CP * XS;
+      const float* zc = Zr + (y1 & 1) * CP * XS;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-          if (c < C) {
-            const float v = hy * H0[c] + ly * H1[c];
-            const float gc = coef * (__expf(v - ls) - (c == t ? 1.f : 0.f));
-            if (same) accA[c] += hy * gc + ly * gc;
-            else { accA[c] += hy * gc; accB[c] += ly * gc; }
-          }
-        }
+      for (int c = 0; c < CP; ++c) {
+        const float a0 = za[c * XS + xl0], a1 = za[c * XS + xl1], b0 = zc[c * XS + xl0], b1 = zc[c * XS + xl1];
+        const float h0 = __builtin_fmaf(lx, a1 - a0, a0), h1 = __builtin_fmaf(lx, b1 - b0, b0);
+        H0[c] = h0; D[c] = h1 - h0;
+      }
+      cur = y0;
+    }
+    const bool valid = live && label_is_class(sd.lab, ignore_label, C);
+    bool kept = valid;
+    if (valid && branch != 2) kept = prob_of_nll(sd.nl) <= thr;
+    const int t = valid ? (int)sd.lab : 0;
+    const float coef = kept ? gs * (weight ? weight[t] : 1.f) : 0.f;
+    if (__builtin_amdgcn_ballot_w64(coef != 0.f) == 0) continue;      // nothing kept in this wave's 64 columns
+    const float l2 = sd.ls * kLog2e;
+    const float ca = coef - ly * coef, cb = ly * coef;
+    const float4* ohr = reinterpret_cast<const float4*>(oh + t * CP);
+#pragma unroll
+    for (int c4 = 0; c4 < CP / 4; ++c4) {
+      const float4 o = ohr[c4];
+      const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ly, D[c], H0[c]) - l2) - ov[k];
+        accA[c] = __builtin_fmaf(ca, e, accA[c]);
+        accB[c] = __builtin_fmaf(cb, e, accB[c]);
       }
     }
   }
   if (cur >= 0) { flush(cur, accA); flush(cur + 1, accB); }
 }
 
-// backward, horizontal part: dz[b,c,iy,ix] = sum_ox wx(ox, ix) * V[b,c,iy,ox]
-template <typename T, int MAXF>
-__global__ __launch_bounds__(kT) void ohem_up_bwd_h(const float* __restrict__ V, T* __restrict__ dz,
-                                                    int64_t rows, int IW, int OW, float sx) {
-  const int64_t total = rows * IW;
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
-    const int ix = (int)(i % IW);
-    const int64_t row = i / IW;
-    int xlo, xhi;
-    footprint(sx, ix, OW, xlo, xhi);
-    const float* v = V + row * OW + xlo;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXF; ++j)
-      if (xlo + j <= xhi) acc += tap_weight(sx, xlo + j, IW, ix) * v[j];
-    st1<T>(dz + i, acc);
+static int up_class_pad(int C) { return C <= 8 ? 8 : C <= 16 ? 16 : C <= 20 ? 20 : C <= 24 ? 24 : 32; }
+static int up_bwd_ntmax(int CP) { return CP <= 20 ? 1024 : 512; }   // 4 register arrays of CP floats per thread
+
+static UpFwdGeom up_fwd_geom(int C, int IH, int IW, int OH, int OW, int bins0) {
+  UpFwdGeom g;
+  g.C = C; g.IH = IH; g.IW = IW; g.OH = OH; g.OW = OW;
+  g.sy = ac_scale(IH, OH); g.sx = ac_scale(IW, OW);
+  g.WR = (int)floorf(g.sy * (float)(kFwdBand - 1)) + 3;
+  g.WC = (int)floorf(g.sx * (float)(kT - 1)) + 3;
+  g.xblocks = (OW + kT - 1) / kT;
+  g.bands = (OH + kFwdBand - 1) / kFwdBand;
+  g.hist_words = ((bins0 > 0 ? bins0 : 1) + 3) / 4 * 4;
+  return g;
+}
+static size_t up_fwd_lds(const UpFwdGeom& g, int CP) {
+  return (size_t)g.hist_words * 4 + (size_t)CP * g.WR * g.WC * 4 + (size_t)kFwdBand * kT;
+}
+
+// backward tiling: the fewest column tiles whose output-column footprint fits one block
+struct UpBwdCfg { UpBwdGeom g; int k, NT; size_t lds; bool ok; };
+static UpBwdCfg up_bwd_cfg(int64_t B, int C, int IH, int IW, int OH, int OW) {
+  UpBwdCfg cf;
+  cf.ok = false;
+  const int CP = up_class_pad(C), ntmax = up_bwd_ntmax(CP);
+  UpBwdGeom& g = cf.g;
+  g.C = C; g.IH = IH; g.IW = IW; g.OH = OH; g.OW = OW;
+  g.sy = ac_scale(IH, OH); g.sx = ac_scale(IW, OW);
+  for (int k = 1; k <= IW; ++k) {
+    const int SB = (IW + k - 1) / k;
+    int need = 0;
+    for (int s0 = 0; s0 < IW; s0 += SB) {
+      const int s1 = s0 + SB < IW ? s0 + SB : IW;
+      int lo, hi, t;
+      footprint(g.sx, s0, OW, lo, t);
+      footprint(g.sx, s1 - 1, OW, t, hi);
+      if (hi - lo + 1 > need) need = hi - lo + 1;
+    }
+    if (need > ntmax) continue;
+    const int NT = (need + 63) / 64 * 64;
+    const int XS = SB + 5;
+    const size_t lds = ((size_t)CP * CP + 2 * (size_t)CP * XS + NT + (size_t)NT * (CP + 1) + XS + 2 + 4) * 4;
+    if (lds > 150 * 1024) continue;
+    g.SB = SB; g.XS = XS;
+    cf.k = (IW + SB - 1) / SB; cf.NT = NT; cf.lds = lds; cf.ok = true;
+    break;
   }
+  if (!cf.ok) return cf;
+  g.RB = 8;
+  while (g.RB > 2 && (int64_t)cf.k * ((IH + g.RB - 1) / g.RB) * B < 256) g.RB /= 2;   // one block per CU at least
+  return cf;
 }
 
 static bool up_fused_ok(int C, int IH, int IW, int OH, int OW) {
   if (C > 32 || C < 1) return false;
-  if (OH < 2 * IH || OW < 2 * IW) return false;             // only genuine up-sampling is fused
+  if (IH < 1 || IW < 1 || OH < 2 * IH || OW < 2 * IW) return false;   // only genuine up-sampling is fused
   const float sx = ac_scale(IW, OW), sy = ac_scale(IH, OH);
-  if (sx <= 0.f || sy <= 0.f) return false;
-  return (int)floorf(2.f / sx) + 4 <= 37;                    // horizontal footprint the gather unrolls
+  if (sx <= 0.f || sy <= 0.f || sx > 0.5f || sy > 0.5f) return false;
+  // the forward's LDS window (z under a 256 x 32 output tile) must leave room for several blocks per CU
+  if (up_fwd_lds(up_fwd_geom(C, IH, IW, OH, OW, 2048), up_class_pad(C)) > 64 * 1024) return false;
+  return up_bwd_cfg(1, C, IH, IW, OH, OW).ok;
 }
 
 static int pixel_grid(int64_t nvec) {
@@ -818,6 +909,23 @@ __global__ __launch_bounds__(kT) void target_prob_k(const float* __restrict__ nl
                                                     int64_t P, int C, int64_t ignore_label, float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < P; i += (int64_t)gridDim.x * kT)
     out[i] = label_is_class(Lab<LT>::get(labels, i), ignore_label, C) ? prob_of_nll(nll[i]) : 1.f;
+}
+
+template <typename T, int LT, int CP, int NTMAX>
+static int launch_up_bwd(const UpBwdCfg& cf, int64_t B, const void* z, const void* labels, int64_t ignore_label,
+                         const float* weight, const float* nll, const float* lse, const int32_t* sel,
+                         const float* gscale, void* dz, hipStream_t st) {
+  static size_t granted = 0;                            // dynamic LDS above 64 KB has to be requested once
+  if (cf.lds > 64 * 1024 && cf.lds > granted) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ohem_up_bwd_k<T, LT, CP, NTMAX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds));
+    granted = cf.lds;
+  }
+  dim3 grid((unsigned)cf.k, (unsigned)((cf.g.IH + cf.g.RB - 1) / cf.g.RB), (unsigned)B);
+  hipLaunchKernelGGL((ohem_up_bwd_k<T, LT, CP, NTMAX>), grid, dim3(cf.NT), cf.lds, st, (const T*)z, labels, cf.g,
+                     ignore_label, weight, nll, lse, sel, gscale, (T*)dz);
+  TSG_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" {
@@ -918,7 +1026,7 @@ int tsg_ohem_up_supported(int C, int IH, int IW, int OH, int OW, float thresh) {
 
 size_t tsg_ohem_up_bwd_ws_bytes(int64_t B, int C, int IH, int OW) {
   if (B <= 0 || C <= 0 || IH <= 0 || OW <= 0) return 0;
-  return (size_t)B * C * IH * OW * sizeof(float);
+  return 256;                                          // the backward needs no scratch any more; kept for the ABI
 }
 
 int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype, int64_t B, int C, int IH,
@@ -939,13 +1047,14 @@ int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype, int
   OhemWs w = carve(ws, pl);
   TSG_HIP(hipMemsetAsync(ws, 0, w.zero_bytes, st));
   const int64_t tb = thresh_tb(thresh);
-  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
-  const size_t sh = (size_t)(bins0 > 0 ? bins0 : 1) * sizeof(uint32_t);
+  const UpFwdGeom g = up_fwd_geom(C, IH, IW, OH, OW, bins0);
+  const int CP = up_class_pad(C);
+  const size_t sh = up_fwd_lds(g, CP);
 #define PA(T, LTT, CM)                                                                                \
-  hipLaunchKernelGGL((ohem_up_pass_a<T, LTT, CM>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, C, \
-                     IH, IW, OH, OW, sy, sx, ignore_label, thresh, tb, pl.shift[0], bins0, weight, nll, \
-                     lse, w.hist[0], w.part)
-#define PC(T, LTT) do { if (C <= 20) PA(T, LTT, 20); else PA(T, LTT, 32); } while (0)
+  hipLaunchKernelGGL((ohem_up_fwd_k<T, LTT, CM>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, g, \
+                     ignore_label, thresh, tb, pl.shift[0], bins0, weight, nll, lse, w.hist[0], w.part)
+#define PC(T, LTT) do { switch (CP) { case 8: PA(T, LTT, 8); break; case 16: PA(T, LTT, 16); break; \
+    case 20: PA(T, LTT, 20); break; case 24: PA(T, LTT, 24); break; default: PA(T, LTT, 32); } } while (0)
   if (dtype == TSG_F32) { if (ltype == TSG_I64) PC(float, TSG_I64); else PC(float, TSG_U8); }
   else { if (ltype == TSG_I64) PC(bf16_t, TSG_I64); else PC(bf16_t, TSG_U8); }
 #undef PC
@@ -958,33 +1067,21 @@ int tsg_ohem_up_bwd(const void* z, int dtype, const void* labels, int ltype, int
                     int IW, int OH, int OW, int64_t ignore_label, const float* weight, const float* nll,
                     const float* lse, const int32_t* sel, const float* gscale, void* dz, void* ws,
                     size_t ws_bytes, void* stream) {
-  if (!z || !labels || !nll || !lse || !sel || !gscale || !dz || !ws) return TSG_E_NULL;
+  (void)ws; (void)ws_bytes;
+  if (!z || !labels || !nll || !lse || !sel || !gscale || !dz) return TSG_E_NULL;
   if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
   if (ltype != TSG_I64 && ltype != TSG_U8) return TSG_E_DTYPE;
   if (B <= 0 || !up_fused_ok(C, IH, IW, OH, OW)) return TSG_E_SHAPE;
-  if (ws_bytes < tsg_ohem_up_bwd_ws_bytes(B, C, IH, OW)) return TSG_E_WS;
   hipStream_t st = (hipStream_t)stream;
-  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
-  float* V = (float*)ws;
-  dim3 grid((unsigned)((OW + kT - 1) / kT), (unsigned)((IH + kBwdCH - 1) / kBwdCH), (unsigned)B);
-#define PB(T, LTT, CM)                                                                                \
-  hipLaunchKernelGGL((ohem_up_bwd_v<T, LTT, CM>), grid, dim3(kT), 0, st, (const T*)z, labels, C, IH, IW, OH, OW, \
-                     sy, sx, ignore_label, weight, nll, lse, sel, gscale, V)
-#define PC(T, LTT) do { if (C <= 20) PB(T, LTT, 20); else PB(T, LTT, 32); } while (0)
+  const UpBwdCfg cf = up_bwd_cfg(B, C, IH, IW, OH, OW);
+  if (!cf.ok) return TSG_E_SHAPE;
+#define PB(T, LTT, CM, NM) return launch_up_bwd<T, LTT, CM, NM>(cf, B, z, labels, ignore_label, weight, nll, lse, sel, gscale, dz, st)
+#define PC(T, LTT) do { switch (up_class_pad(C)) { case 8: PB(T, LTT, 8, 1024); case 16: PB(T, LTT, 16, 1024); \
+    case 20: PB(T, LTT, 20, 1024); case 24: PB(T, LTT, 24, 512); default: PB(T, LTT, 32, 512); } } while (0)
   if (dtype == TSG_F32) { if (ltype == TSG_I64) PC(float, TSG_I64); else PC(float, TSG_U8); }
   else { if (ltype == TSG_I64) PC(bf16_t, TSG_I64); else PC(bf16_t, TSG_U8); }
 #undef PC
 #undef PB
-  TSG_CHECK_LAUNCH();
-  const int64_t rows = B * C * IH;
-  const int need = (int)floorf(2.f / sx) + 4;
-  int64_t g2 = (rows * IW + kT - 1) / kT;
-  if (g2 > 8192) g2 = 8192;
-#define PH(T, F) hipLaunchKernelGGL((ohem_up_bwd_h<T, F>), dim3((unsigned)g2), dim3(kT), 0, st, V, (T*)dz, rows, IW, OW, sx)
-  if (dtype == TSG_F32) { if (need <= 9) PH(float, 9); else if (need <= 21) PH(float, 21); else PH(float, 37); }
-  else { if (need <= 9) PH(bf16_t, 9); else if (need <= 21) PH(bf16_t, 21); else PH(bf16_t, 37); }
-#undef PH
-  TSG_CHECK_LAUNCH();
   return 0;
 }
 

@@ -30,8 +30,9 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_FUSE_LOSS=1|0     (default 1 on GPU: nn.CrossEntropyLoss / F.cross_entropy heads, also behind F.log_softmax, run
                         on tsg_ohem_* in plain-CE mode; fusion.py)
   TSG_FUSE_ADD_UP=1|0   (default 1 on GPU: `fm += last_fm` followed by F.interpolate is one kernel; fusion.py)
-  TSG_FUSE_HEAD=1|0     (default 0: F.interpolate(x >= 4) feeding our criterion is fused into it; parity-tested,
-                        but on MI355X streaming the bf16 logits at ~4-5 TB/s is as fast as re-interpolating them)
+  TSG_FUSE_HEAD=1|0     (default 1 on GPU: a bilinear F.interpolate of <= 32-channel logits by >= 4 stays pending and is
+                        evaluated inside the criterion's kernels, tsg_ohem_up_*: 3x faster than writing and re-reading
+                        the full-resolution logits; any other consumer materialises it.  fusion.py)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
   TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
   TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw;
@@ -276,14 +277,12 @@ class DistributedDataParallel(nn.Module):
         self.fuse_psa = False
         self.fuse_loss = self.on_gpu and _env_flag("TSG_FUSE_LOSS", not native)
         self.fuse_add_up = self.on_gpu and _env_flag("TSG_FUSE_ADD_UP", not native)
+        self.fuse_head = self.on_gpu and _env_flag("TSG_FUSE_HEAD", not native)
         if self.on_gpu:
             from .upsample import install_aten_overrides
             install_aten_overrides()
             from .psa import model_has_psa
             self.fuse_psa = _env_flag("TSG_FUSE_PSA", model_has_psa(module) and not native)
-            if _env_flag("TSG_FUSE_HEAD", False):
-                from .upsample import install_deferred_interpolate
-                install_deferred_interpolate()
             if _env_flag("TSG_SPLIT_BIAS", True):
                 from .convbias import split_conv_bias
                 split_conv_bias(self.module)
@@ -308,8 +307,9 @@ class DistributedDataParallel(nn.Module):
         with contextlib.ExitStack() as stack:
             if self.on_gpu and self.compute_dtype != torch.float32:
                 stack.enter_context(torch.autocast("cuda", dtype=self.compute_dtype))
-            if self.fuse_psa or self.fuse_loss or self.fuse_add_up:
+            if self.fuse_psa or self.fuse_loss or self.fuse_add_up or self.fuse_head:
                 from .fusion import FuseMode, materialize
-                stack.enter_context(FuseMode(psa=self.fuse_psa, loss=self.fuse_loss, add_up=self.fuse_add_up))
+                stack.enter_context(FuseMode(psa=self.fuse_psa, loss=self.fuse_loss, add_up=self.fuse_add_up,
+                                             head=self.fuse_head))
                 return materialize(self.module(*inputs, **kwargs))
             return self.module(*inputs, **kwargs)

@@ -69,15 +69,16 @@ def materialize(v):
 
 
 class DeferredLogSoftmax(_Deferred):
-    """F.log_softmax(x, dim=1) of a [B,C,H,W] tensor, pending."""
+    """F.log_softmax(x, dim=1) of a [B,C,H,W] tensor (or of a pending up-sampling of one), pending."""
 
     def __init__(self, x):
         self.x = x
 
     def materialize(self):
         if self._value is None:
-            self._value = torch._log_softmax(self.x, 1, False) if self.x.dtype == torch.float32 \
-                else torch.log_softmax(self.x, 1)
+            from .upsample import DeferredUpsample
+            x = self.x.materialize() if isinstance(self.x, DeferredUpsample) else self.x
+            self._value = torch._log_softmax(x, 1, False) if x.dtype == torch.float32 else torch.log_softmax(x, 1)
         return self._value
 
 
@@ -124,6 +125,12 @@ def _is_map(t):
     return isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 4 and t.dtype in _FLOATS
 
 
+def _is_logits(t):
+    """A [B,C,H,W] map or the pending bilinear up-sampling of one (the criteria take both)."""
+    from .upsample import DeferredUpsample
+    return _is_map(t) or (isinstance(t, DeferredUpsample) and _is_map(t.z))
+
+
 _LOG_SOFTMAX_FUNCS = (F.log_softmax, torch.log_softmax, torch.Tensor.log_softmax)
 _IADD_FUNCS = (torch.Tensor.__iadd__, torch.Tensor.add_)
 _ADD_FUNCS = (torch.Tensor.__add__, torch.Tensor.__radd__, torch.Tensor.add, torch.add)
@@ -141,7 +148,7 @@ def _ce_args(args, kwargs):
         return None
     inp, tgt, w = a.get("input"), a.get("target"), a.get("weight")
     x = inp.x if isinstance(inp, DeferredLogSoftmax) else inp
-    if not _is_map(x) or not isinstance(tgt, torch.Tensor) or tgt.dim() != 3 or (_TARGET_ON_DEVICE and not tgt.is_cuda):
+    if not _is_logits(x) or not isinstance(tgt, torch.Tensor) or tgt.dim() != 3 or (_TARGET_ON_DEVICE and not tgt.is_cuda):
         return None
     if tgt.dtype not in (torch.int64, torch.uint8) or tuple(tgt.shape) != (x.shape[0], x.shape[2], x.shape[3]):
         return None
@@ -152,11 +159,12 @@ def _ce_args(args, kwargs):
 
 class FuseMode(TorchFunctionMode):
     """See the module docstring.  `psa`: defer column softmaxes for the PSA contraction; `loss`: plain CE heads on
-    the HIP kernels; `add_up`: `+=` -> interpolate fusion."""
+    the HIP kernels; `add_up`: `+=` -> interpolate fusion; `head`: bilinear up-sampling of <= 32-channel logits by >= 4 is
+    left pending for the criterion (fused upsample + CE / OHEM kernels)."""
 
-    def __init__(self, psa=False, loss=True, add_up=True):
+    def __init__(self, psa=False, loss=True, add_up=True, head=False):
         super().__init__()
-        self.psa, self.loss, self.add_up = bool(psa), bool(loss), bool(add_up)
+        self.psa, self.loss, self.add_up, self.head = bool(psa), bool(loss), bool(add_up), bool(head)
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -168,7 +176,7 @@ class FuseMode(TorchFunctionMode):
                 if dim == 1 and a.dim() == 3 and a.is_cuda and kwargs.get("dtype") is None and a.dtype in _FLOATS:
                     return _DeferredColSoftmax(a)
         if self.loss:
-            if func in _LOG_SOFTMAX_FUNCS and args and _is_map(args[0]) and torch.is_grad_enabled() \
+            if func in _LOG_SOFTMAX_FUNCS and args and _is_logits(args[0]) and torch.is_grad_enabled() \
                     and args[0].requires_grad:
                 dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
                 if dim == 1 and kwargs.get("dtype") is None:
@@ -189,4 +197,15 @@ class FuseMode(TorchFunctionMode):
                 if s._value is None and kwargs.get("mode") == "bilinear" and kwargs.get("align_corners") \
                         and not kwargs.get("antialias", False):
                     return upsample_presum(s.a, s.b, size=kwargs.get("size"), scale_factor=kwargs.get("scale_factor"))
+        if self.head and func is F.interpolate and args and _is_map(args[0]) and torch.is_grad_enabled() \
+                and args[0].requires_grad and kwargs.get("mode") == "bilinear" and kwargs.get("align_corners") \
+                and not kwargs.get("antialias", False):
+            # the last statement of a head: logits up-sampled by >= 4 for the criterion.  Returned pending: our
+            # criteria evaluate the interpolation inside their kernels (tsg_ohem_up_*), anything else materialises it
+            from .upsample import DeferredUpsample, _out_size
+            x = args[0]
+            OH, OW = _out_size(x, kwargs.get("size", args[1] if len(args) > 1 else None),
+                               kwargs.get("scale_factor", args[2] if len(args) > 2 else None))
+            if x.shape[1] <= 32 and OH >= 4 * x.shape[2] and OW >= 4 * x.shape[3]:
+                return DeferredUpsample(x, (OH, OW))
         return func(*args, **kwargs)

@@ -231,3 +231,13 @@ def install_deferred_interpolate(min_scale=4):
 
     F.interpolate = interpolate
     torch.nn.functional.interpolate = interpolate
+
+
+def uninstall_deferred_interpolate():
+    """Undo install_deferred_interpolate()."""
+    global _orig_interpolate
+    if _orig_interpolate is not None:
+        import torch.nn.functional as F
+        F.interpolate = _orig_interpolate
+        torch.nn.functional.interpolate = _orig_interpolate
+        _orig_interpolate = None

@@ -33,6 +33,22 @@ def add_then_upsample(fm, last_fm, size):
     return F.interpolate(fm, size=size, mode='bilinear', align_corners=True)
 
 
+def upsample_logits(x, size=None, scale=None):
+    """`F.interpolate(logits, ..., mode='bilinear', align_corners=True)` at the end of a head (bisenet network.py:164-166,
+    pspnet network.py:103-105).  On HIP tensors an up-sampling by >= 4 is returned DEFERRED: our criteria evaluate it
+    inside their kernels (tsg_ohem_up_fwd/bwd: the full-resolution logits are never written), any other consumer
+    materialises it through the normal differentiable kernel on first use."""
+    import torch
+    import torch.nn.functional as F
+    if (NATIVE_FUSIONS and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+            and os.environ.get("TSG_FUSE_HEAD", "1") == "1"):
+        from ..upsample import DeferredUpsample, _out_size
+        OH, OW = _out_size(x, size, scale)
+        if OH >= 4 * x.shape[2] and OW >= 4 * x.shape[3]:
+            return DeferredUpsample(x, (OH, OW))
+    return F.interpolate(x, size=size, scale_factor=scale, mode='bilinear', align_corners=True)
+
+
 def head_loss(criterion, logits, label, log_softmax=False):
     """`criterion(logits, label)` (dfn network.py:140-143) or `criterion(F.log_softmax(logits, 1), label)` (pspnet /
     psanet network.py:50-56).  A plain nn.CrossEntropyLoss on HIP logits runs on the CE kernels straight from the
@@ -40,7 +56,7 @@ def head_loss(criterion, logits, label, log_softmax=False):
     import torch.nn as nn
     import torch.nn.functional as F
     if (NATIVE_FUSIONS and logits.is_cuda and type(criterion) is nn.CrossEntropyLoss and criterion.reduction == 'mean'
-            and criterion.label_smoothing == 0.0 and logits.dim() == 4):
+            and criterion.label_smoothing == 0.0 and logits.dim() == 4):     # logits may be a DeferredUpsample
         from ..losses import cross_entropy_2d
         return cross_entropy_2d(logits, label, ignore_index=criterion.ignore_index, weight=criterion.weight)
     return criterion(F.log_softmax(logits, dim=1) if log_softmax else logits, label)

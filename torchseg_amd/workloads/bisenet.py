@@ -10,7 +10,7 @@ initialises both identically (tests/test_dropin_cpu.py checks both).
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import add_then_upsample, ensure_furnace_on_path
+from . import add_then_upsample, ensure_furnace_on_path, upsample_logits
 
 ensure_furnace_on_path()
 from base_model import resnet18  # noqa: E402
@@ -52,7 +52,7 @@ class BiSeNetHead(nn.Module):
 
     def forward(self, x):
         out = self.conv_1x1(self.conv_3x3(x))
-        return _up(out, scale=self.scale) if self.scale > 1 else out
+        return upsample_logits(out, scale=self.scale) if self.scale > 1 else out
 
 
 class BiSeNet(nn.Module):

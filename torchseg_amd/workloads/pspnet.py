@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ensure_furnace_on_path, head_loss, softmax_bmm
+from . import ensure_furnace_on_path, head_loss, softmax_bmm, upsample_logits
 
 ensure_furnace_on_path()
 from base_model import resnet50, resnet101  # noqa: E402
@@ -110,9 +110,9 @@ class _DilatedSegNet(nn.Module):
 
     def forward(self, data, label=None):
         blocks = self.backbone(data)
-        fm = _up(getattr(self, self._head_attr)(blocks[-1]), scale=8)
+        fm = upsample_logits(getattr(self, self._head_attr)(blocks[-1]), scale=8)
         if label is not None:                                                     # network.py:46-57
-            aux = _up(self.aux_layer(blocks[-2]), scale=8)
+            aux = upsample_logits(self.aux_layer(blocks[-2]), scale=8)
             return head_loss(self.criterion, fm, label, True) + 0.4 * head_loss(self.criterion, aux, label, True)
         return F.log_softmax(fm, dim=1)
 
