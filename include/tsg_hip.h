@@ -210,6 +210,32 @@ int tsg_stem_conv_fwd(const void* x, const float* w, void* y, int64_t B, int64_t
                       void* ws, size_t ws_bytes, void* stream);
 int tsg_stem_conv_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
                       void* ws, size_t ws_bytes, void* stream);
+/* The same forward with the statistics pass of the BatchNorm that follows every such stem (resnet.py:98,
+ * seg_oprs.py:27-31) folded into its epilogue: partial[S][2][64] fp32 = per-block sums / square sums of the
+ * bf16-rounded outputs, S = tsg_stem_conv_stats_partials(B, H, W) — the layout tsg_bn_finalize / tsg_bn_collapse
+ * take, so tsg_bn_stats (one more read of the 0.5 GB activation) is not run. */
+int tsg_stem_conv_stats_partials(int64_t B, int64_t H, int64_t W);
+int tsg_stem_conv_fwd_stats(const void* x, const float* w, void* y, float* partial, int64_t B, int64_t H,
+                            int64_t W, void* ws, size_t ws_bytes, void* stream);
+
+/* BatchNorm (statistics already folded into the packs of tsg_bn_finalize / tsg_bn_bwd_coeffs) + ReLU +
+ * MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem in one pass per direction — replaces
+ * `x = self.maxpool(self.relu(self.bn1(x)))` (furnace/base_model/resnet.py:98-100,131-133) for channels_last x
+ * [N, IH, IW, C], C % (16 / elem_size) == 0, OH = (IH - 1) / 2 + 1.  Forward: y [N, OH, OW, C] and the one-byte
+ * window position of each maximum: y is bit-equal to tsg_maxpool_nhwc_fwd(tsg_bn_apply_fwd(x, relu)); the maximum is
+ * ranked on the unrounded fp32 values, as the fp32 reference does, so in bf16 the position may differ from the unfused
+ * pair's where two elements of a window round to the same bf16 value.  Backward: the
+ * gradient of a stem pixel is gathered from dpool through argmax_u8, masked by the recomputed ReLU and consumed by
+ * the BN reduction (partial[S][2][C], S = tsg_bn_relu_pool_bwd_num_partials; then tsg_bn_bwd_coeffs) and by
+ * dx = a dy' + Bc (x - mean) + C2.  Neither relu(bn(x)) nor its gradient is ever written. */
+int tsg_bn_relu_pool_fwd(const void* x, void* y, void* argmax_u8, int dtype, int64_t N, int C, int IH, int IW,
+                         int OH, int OW, const float* fp, void* stream);
+int tsg_bn_relu_pool_bwd_num_partials(int dtype, int64_t N, int C, int IH, int IW);
+int tsg_bn_relu_pool_bwd_reduce(const void* dpool, const void* argmax_u8, const void* x, int dtype, int64_t N,
+                                int C, int IH, int IW, int OH, int OW, const float* fp, float* partial,
+                                void* stream);
+int tsg_bn_relu_pool_bwd_apply(const void* dpool, const void* argmax_u8, const void* x, void* dx, int dtype,
+                               int64_t N, int C, int IH, int IW, int OH, int OW, const float* bp, void* stream);
 
 /* Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / padding 1 convolutions (ResNet-18 layer1:
  * BasicBlock.conv1 / conv2, furnace/base_model/resnet.py:24-29,36-53) — replaces the cuDNN

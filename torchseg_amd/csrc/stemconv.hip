@@ -115,8 +115,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {      // v_cvt_
 // ---------------------------------------------------------------- forward
 // 4 waves: wave = (row pair wr) * 2 + (oc half wm).  A wave keeps the weights of its 32 output channels in
 // registers (11 K-fragments) and runs two pixel rows against them.
+// STATS: the per-channel sum / square sum of the (bf16-rounded) outputs ride along — what the BatchNorm that follows
+// every such stem would otherwise re-read the whole activation for (tsg_bn_stats).  partial[block][2][64], fp32.
+template <bool STATS>
 __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
-                                                  bf16_t* __restrict__ y, StemGeom g) {
+                                                  bf16_t* __restrict__ y, StemGeom g, float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) uint32_t patch[SC_NPD];                 // 5616 B
   __shared__ __attribute__((aligned(16))) bf16_t outs[SC_TH * SC_TW * 72];        // 18432 B: [pixel][64 oc + 8 pad]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, 
   PatchLane pl;
   patch_lane_init(g, tid, pl);
   uint32_t rp[SC_NPF];
+  float st1 = 0.f, st2 = 0.f;                          // STATS: channel tid & 63 over tile row tid >> 6
   int tile = blockIdx.x;
   TilePos tp = tile_pos(g, tile < g.ntiles ? tile : 0);
   if (tile < g.ntiles) fetch_patch(x, g, tp, pl, rp);
@@ -190,7 +194,31 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const bf16_t* __restrict__ x, 
       if (tp.oh0 + qd < g.OH && colok)
         *reinterpret_cast<uint4*>(yt + ((int64_t)qd * g.OW + spl) * SC_OC + spart * 8) =
             *reinterpret_cast<const uint4*>(outs + (qd * SC_TW + spl) * 72 + spart * 8);
+    if (STATS) {
+      const int c = tid & 63, qd = tid >> 6;
+      if (tp.oh0 + qd < g.OH) {
+        const int npx = g.OW - tp.ow0 < SC_TW ? g.OW - tp.ow0 : SC_TW;
+        const bf16_t* col = outs + qd * SC_TW * 72 + c;
+        if (npx == SC_TW) {
+#pragma unroll 8
+          for (int px = 0; px < SC_TW; ++px) { const float v = bf16_to_f32(col[px * 72]); st1 += v; st2 = fmaf(v, v, st2); }
+        } else {
+          for (int px = 0; px < npx; ++px) { const float v = bf16_to_f32(col[px * 72]); st1 += v; st2 = fmaf(v, v, st2); }
+        }
+      }
+    }
     tp = tn;
+  }
+  if (STATS) {                                         // fold the four tile rows in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(outs);
+    red[tid] = st1; red[256 + tid] = st2;
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;
+      const float* r = red + which * 256 + c;
+      partial[((int64_t)blockIdx.x * 2 + which) * SC_OC + c] = (r[0] + r[64]) + (r[128] + r[192]);
+    }
   }
 }
 
@@ -374,7 +402,32 @@ int tsg_stem_conv_fwd(const void* x, const float* w, void* y, int64_t B, int64_t
   hipLaunchKernelGGL(stem_pack_w, dim3((SC_OC * SC_KP + 255) / 256), dim3(256), 0, st, w, wp);
   TSG_CHECK_LAUNCH();
   const int grid = g.ntiles < 768 ? g.ntiles : 768;             // 3 resident blocks per CU (164 VGPRs)
-  hipLaunchKernelGGL(stem_fwd_k, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, (bf16_t*)y, g);
+  hipLaunchKernelGGL(stem_fwd_k<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, (bf16_t*)y, g,
+                     (float*)nullptr);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_stem_conv_stats_partials(int64_t B, int64_t H, int64_t W) {
+  StemGeom g;
+  if (!stem_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  return g.ntiles < 768 ? g.ntiles : 768;
+}
+
+int tsg_stem_conv_fwd_stats(const void* x, const float* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w || !y || !ws || !partial) return TSG_E_NULL;
+  StemGeom g;
+  if (!stem_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  if (ws_bytes < sc_align((size_t)SC_OC * SC_KP * sizeof(bf16_t))) return TSG_E_WS;
+  if (!aligned16(y) || !aligned16(ws) || (((uintptr_t)x) & 3u)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* wp = (bf16_t*)ws;
+  hipLaunchKernelGGL(stem_pack_w, dim3((SC_OC * SC_KP + 255) / 256), dim3(256), 0, st, w, wp);
+  TSG_CHECK_LAUNCH();
+  const int grid = g.ntiles < 768 ? g.ntiles : 768;
+  hipLaunchKernelGGL(stem_fwd_k<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, (bf16_t*)y, g,
+                     partial);
   TSG_CHECK_LAUNCH();
   return 0;
 }

@@ -121,6 +121,11 @@ class ResNet(nn.Module):
             x = c[6](x)
         else:
             x = self.conv1(x)
+        if x.is_cuda:
+            from torchseg_amd.syncbn import bn_relu_maxpool
+            y = bn_relu_maxpool(self.bn1, x, self.maxpool)          # one fused pass per direction on HIP tensors
+            if y is not None:
+                return y
         return self.maxpool(norm_act(self.bn1, self.relu, x))
 
     def forward(self, x):

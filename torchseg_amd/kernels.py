@@ -62,6 +62,16 @@ class HipKernels:
         self.lib = L.lib()
         self._npart = {}
 
+    def _count(self, key, fn, what):
+        """A (cached) geometry query of the library whose non-negative result is a count."""
+        v = self._npart.get(key)
+        if v is None:
+            v = fn()
+            if v <= 0:
+                L.check(v if v < 0 else -2, what)
+            self._npart[key] = v
+        return v
+
     def _num_partials(self, layout, N, Cc, HW):
         key = (layout, N, Cc, HW)
         v = self._npart.get(key)
@@ -229,6 +239,40 @@ class HipKernels:
                                               IH, IW, OH, OW, K_, S_, P_, L.stream_ptr(dy)), "tsg_maxpool_nhwc_bwd")
         return dx
 
+    # ---- BN + ReLU + MaxPool2d(3, 2, 1) of the ResNet stem, fused ------------------
+    def bn_relu_pool_fwd(self, x, fp):
+        """x channels_last-dense [N,C,IH,IW], fp = forward pack -> (y channels_last [N,C,OH,OW], argmax uint8 [N,OH,OW,C])"""
+        N, Cc, IH, IW = x.shape
+        OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+        y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_bn_relu_pool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), L.dtype_code(x), N, Cc, IH, IW,
+                                              OH, OW, fp.data_ptr(), L.stream_ptr(x)), "tsg_bn_relu_pool_fwd")
+        return y, idx
+
+    def bn_relu_pool_bwd_reduce(self, dpool, idx, x, fp):
+        """-> (partial fp32 [S,2,C] = {sum dy', sum dy'(x-mean)}, S) with dy' gathered from dpool through idx"""
+        N, Cc, IH, IW = x.shape
+        OH, OW = dpool.shape[2], dpool.shape[3]
+        dt = L.dtype_code(x)
+        S = self._count(("bn_pool", dt, N, Cc, IH, IW),
+                        lambda: self.lib.tsg_bn_relu_pool_bwd_num_partials(dt, N, Cc, IH, IW),
+                        "tsg_bn_relu_pool_bwd_num_partials")
+        partial = torch.empty((S, 2, Cc), dtype=torch.float32, device=x.device)
+        L.check(self.lib.tsg_bn_relu_pool_bwd_reduce(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), L.dtype_code(x), N, Cc,
+                                                     IH, IW, OH, OW, fp.data_ptr(), partial.data_ptr(), L.stream_ptr(x)),
+                "tsg_bn_relu_pool_bwd_reduce")
+        return partial, S
+
+    def bn_relu_pool_bwd_apply(self, dpool, idx, x, bp):
+        N, Cc, IH, IW = x.shape
+        OH, OW = dpool.shape[2], dpool.shape[3]
+        dx = torch.empty_like(x)
+        L.check(self.lib.tsg_bn_relu_pool_bwd_apply(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), dx.data_ptr(),
+                                                    L.dtype_code(x), N, Cc, IH, IW, OH, OW, bp.data_ptr(), L.stream_ptr(x)),
+                "tsg_bn_relu_pool_bwd_apply")
+        return dx
+
     # ---- stem convolution ----------------------------------------------------
     def stem_conv_supported(self, x, weight, stride, padding, dilation, groups):
         if x.dim() != 4 or weight.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous():
@@ -254,6 +298,20 @@ class HipKernels:
         L.check(self.lib.tsg_stem_conv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, H, W, ws.data_ptr(),
                                            ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_fwd")
         return y
+
+    def stem_conv_fwd_stats(self, x, weight):
+        """stem_conv_fwd + the BatchNorm statistics of its output: -> (y, partial fp32 [S,2,64] = {sum y, sum y^2})"""
+        _require_contiguous(x, weight)
+        B, _, H, W = x.shape
+        y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last)
+        S = self._count(("stem_stats", B, H, W), lambda: self.lib.tsg_stem_conv_stats_partials(B, H, W),
+                        "tsg_stem_conv_stats_partials")
+        partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_fwd_stats(x.data_ptr(), weight.data_ptr(), y.data_ptr(), partial.data_ptr(), B, H,
+                                                 W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_fwd_stats")
+        return y, partial
 
     def stem_conv_wrw(self, x, dy):
         """x as in stem_conv_fwd, dy [B,64,OH,OW] bf16 channels_last -> dw fp32 [64,3,7,7]"""
@@ -686,10 +744,24 @@ _ALGO_BYTES = {
     "maxpool_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "gap_fwd": lambda a, r: _nbytes(a[0]),
     "stem_conv_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "stem_conv_fwd_stats": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "bn_relu_pool_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r[0]) + _nbytes(r[1]),
+    "bn_relu_pool_bwd_reduce": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[2]),
+    "bn_relu_pool_bwd_apply": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 2 * _nbytes(a[2]),
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
+
+
+# algorithmic flops per launch of the MFMA kernels (2 * MACs of the convolution they compute)
+_ALGO_FLOPS = {
+    "conv3x3_wrw": lambda a, r: 2 * 9 * a[1].numel() * a[0].shape[1],          # dy elements x C_in x 9 taps
+    "stem_conv_fwd": lambda a, r: 2 * 147 * r.numel(),
+    "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
+    "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
+}
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 
 
 class KernelTimer:
@@ -710,6 +782,7 @@ class KernelTimer:
         self._orig[name] = fn
         rec = self.records[name]
         cost = _ALGO_BYTES[name]
+        flops = _ALGO_FLOPS.get(name)
 
         def timed(*args, **kw):
             s = torch.cuda.Event(enable_timing=True)
@@ -717,7 +790,8 @@ class KernelTimer:
             s.record()
             out = fn(*args, **kw)
             e.record()
-            rec.append((s, e, cost(args, out if name == "maxpool_fwd" else (out[0] if isinstance(out, tuple) else out))))
+            res = out if name in ("maxpool_fwd", "bn_relu_pool_fwd") else (out[0] if isinstance(out, tuple) else out)
+            rec.append((s, e, cost(args, res), flops(args, res) if flops else 0))
             return out
 
         setattr(self.prov, name, timed)
@@ -732,11 +806,15 @@ class KernelTimer:
         self.stats = {}
         for n, recs in self.records.items():
             if recs:
-                ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-                by = sum(b for _, _, b in recs)
+                ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+                by = sum(r[2] for r in recs)
+                fl = sum(r[3] for r in recs)
                 self.stats[n] = {"launches": len(recs), "total_ms": round(ms, 3), "avg_us": round(ms * 1e3 / len(recs), 2),
                                  "algo_MB_per_launch": round(by / len(recs) / 1e6, 3),
                                  "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+                if fl and ms > 0:
+                    self.stats[n]["algo_GFLOP_per_launch"] = round(fl / len(recs) / 1e9, 3)
+                    self.stats[n]["TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
 
     def summary(self):
         return self.stats
@@ -755,6 +833,13 @@ class KernelTimer:
             f = os.path.join(profiles_dir, "traffic.json")
             if os.path.exists(f):
                 traffic = json.load(open(f)).get(name)   # PMC bytes per launch, profiles/r01_pmc_summary.txt
-        return {"bound": "hbm", "kernel": name, "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
-                "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic,
-                "algo_bytes_per_launch": int(st["algo_MB_per_launch"] * 1e6), "avg_launch_us": st["avg_us"]}
+        out = {"bound": "hbm", "kernel": name, "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
+               "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic,
+               "algo_bytes_per_launch": int(st["algo_MB_per_launch"] * 1e6), "avg_launch_us": st["avg_us"]}
+        if "TFLOPs" in st and st["TFLOPs"] / MFMA_PEAK_TFLOPS > out["frac"]:
+            # a matrix kernel: the roof it is closer to is the MFMA one (the HBM figure stays alongside)
+            out.update({"bound": "mfma", "achieved": st["TFLOPs"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(st["TFLOPs"] / MFMA_PEAK_TFLOPS, 4),
+                        "algo_flops_per_launch": int(st["algo_GFLOP_per_launch"] * 1e9),
+                        "hbm_GBps": st["GBps"], "hbm_frac": round(st["GBps"] / peak_gbs, 4)})
+        return out

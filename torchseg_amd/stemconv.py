@@ -37,20 +37,45 @@ def _as_bf16_image(x):
 
 
 class _StemConvFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight):
-        y = K.provider().stem_conv_fwd(x, weight)
-        ctx.save_for_backward(x)
-        ctx.wdtype = weight.dtype
-        return y
+    """Returns (y, partial): `partial` holds the per-block sums / square sums of y that the kernel's epilogue collected
+    (tsg_stem_conv_fwd_stats), i.e. the statistics pass of the BatchNorm that follows (None when not requested)."""
 
     @staticmethod
-    def backward(ctx, dy):
+    def forward(ctx, x, weight, with_stats):
+        kp = K.provider()
+        if with_stats:
+            y, partial = kp.stem_conv_fwd_stats(x, weight)
+            ctx.mark_non_differentiable(partial)
+        else:
+            y, partial = kp.stem_conv_fwd(x, weight), None
+        ctx.save_for_backward(x)
+        ctx.wdtype = weight.dtype
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, dy, _dpartial):
         (x,) = ctx.saved_tensors
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        return None, K.provider().stem_conv_wrw(x, dy).to(ctx.wdtype)
+        return None, K.provider().stem_conv_wrw(x, dy).to(ctx.wdtype), None
+
+
+import os as _os
+_STEM_STATS = _os.environ.get("TSG_STEM_STATS", "1") != "0"
+
+
+def attach_bn_partial(y, partial):
+    """Leave the statistics the producer of `y` already has for the SyncBatchNorm that consumes it (syncbn.py reads
+    them back with take_bn_partial; the tensor's version counter guards against an in-place change in between)."""
+    y._tsg_bn_partial = (partial, y._version)
+
+
+def take_bn_partial(x):
+    h = getattr(x, "_tsg_bn_partial", None)
+    if h is None or h[1] != x._version or h[0].shape[2] != x.shape[1]:
+        return None
+    return h[0]
 
 
 def _wants_bf16(x):
@@ -66,7 +91,11 @@ class StemConv2d(nn.Conv2d):
             xb = _as_bf16_image(x)
             w = self.weight if self.weight.is_contiguous() else self.weight.contiguous()
             if K.provider().stem_conv_supported(xb, w, self.stride[0], self.padding[0], self.dilation[0], self.groups):
-                return _StemConvFn.apply(xb, w)
+                with_stats = _STEM_STATS and self.training and torch.is_grad_enabled()
+                y, partial = _StemConvFn.apply(xb, w, with_stats)
+                if partial is not None:
+                    attach_bn_partial(y, partial)
+                return y
         return super().forward(x)
 
 

@@ -74,13 +74,17 @@ def _like(t, ref):
     return t
 
 
-def _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world):
-    """stats -> (all-reduce) -> finalize.  Returns (invstd, fwd_pack, count_dev)."""
+def _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world, hint=None):
+    """stats -> (all-reduce) -> finalize.  Returns (invstd, fwd_pack, count_dev).  `hint`: per-block sums [S,2,C] the
+    producer of x collected in its epilogue (stemconv.attach_bn_partial); the statistics pass over x is then skipped."""
     n_local = N * HW
     if world == 1 and n_local <= 1:
         raise ValueError("Expected more than 1 value per channel when training, got input size {}"
                          .format(tuple(x.shape)))
-    partial, S = kp.bn_stats(x, layout, N, C, HW)
+    if hint is not None:
+        partial, S = hint, hint.shape[0]
+    else:
+        partial, S = kp.bn_stats(x, layout, N, C, HW)
     rm = mod.running_mean if mod.track_running_stats else None
     rv = mod.running_var if mod.track_running_stats else None
     nbt = mod.num_batches_tracked if mod.track_running_stats else None
@@ -112,7 +116,7 @@ def _backward_pack(kp, partial, S, C, n_local, invstd, fp, count_dev, use_batch_
 
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, mod, relu, use_batch_stats, group):
+    def forward(ctx, x, residual, weight, bias, mod, relu, use_batch_stats, group, hint=None):
         kp = K.provider()
         x, (layout, N, C, HW) = _dense(x)
         if residual is not None:
@@ -122,7 +126,7 @@ class _SyncBNFn(torch.autograd.Function):
         gamma = weight.float() if weight is not None else None
         beta = bias.float() if bias is not None else None
         if use_batch_stats:
-            invstd, fp, count_dev = _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world)
+            invstd, fp, count_dev = _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world, hint)
         else:
             mean = mod.running_mean.float()
             invstd = torch.rsqrt(mod.running_var.float() + mod.eps)
@@ -162,7 +166,76 @@ class _SyncBNFn(torch.autograd.Function):
         else:
             dgamma = dgamma.to(weight.dtype)
             dbeta = dbeta.to(bias.dtype) if bias is not None else None
-        return dx, dres, dgamma, dbeta, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
+
+
+class _BnReluPoolFn(torch.autograd.Function):
+    """maxpool_3x3/2/1(relu(bn(x))) of the ResNet stem in one pass per direction (csrc/bnpool.hip): neither the
+    normalised activation nor its gradient is written.  x channels_last-dense."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod, use_batch_stats, group, hint):
+        kp = K.provider()
+        layout, N, C, HW = K.bn_layout(x)
+        world = _world(group) if use_batch_stats else 1
+        count_dev = None
+        gamma = weight.float() if weight is not None else None
+        beta = bias.float() if bias is not None else None
+        if use_batch_stats:
+            invstd, fp, count_dev = _batch_statistics(kp, x, layout, N, C, HW, mod, gamma, beta, group, world, hint)
+        else:
+            mean = mod.running_mean.float()
+            invstd = torch.rsqrt(mod.running_var.float() + mod.eps)
+            fp = kp.bn_affine(mean, invstd, gamma, beta)
+        y, idx = kp.bn_relu_pool_fwd(x, fp)
+        ctx.save_for_backward(x, idx, weight, bias, invstd, fp, count_dev)
+        ctx.cfg = (N, C, HW, use_batch_stats, group, world)
+        return y
+
+    @staticmethod
+    def backward(ctx, dpool):
+        kp = K.provider()
+        x, idx, weight, bias, invstd, fp, count_dev = ctx.saved_tensors
+        N, C, HW, use_batch_stats, group, world = ctx.cfg
+        if dpool.dtype != x.dtype:
+            dpool = dpool.to(x.dtype)
+        dpool = dpool.contiguous(memory_format=torch.channels_last)
+        partial, S = kp.bn_relu_pool_bwd_reduce(dpool, idx, x, fp)
+        dgamma, dbeta, bp = _backward_pack(kp, partial, S, C, N * HW, invstd, fp, count_dev,
+                                           use_batch_stats, group, world, x.device)
+        dx = kp.bn_relu_pool_bwd_apply(dpool, idx, x, bp)
+        if weight is None:
+            dgamma = dbeta = None
+        else:
+            dgamma = dgamma.to(weight.dtype)
+            dbeta = dbeta.to(bias.dtype) if bias is not None else None
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+_FUSE_STEM_POOL = os.environ.get("TSG_FUSE_STEM_POOL", "1") != "0"
+
+
+def bn_relu_maxpool(bn, x, pool):
+    """`pool(relu(bn(x)))` (furnace/base_model/resnet.py:98-100,131-133).  One fused pass per direction when `bn` is
+    our SyncBatchNorm, `pool` is MaxPool2d(3, 2, 1) and x is a channels_last HIP activation; None otherwise (the
+    caller then runs the three modules)."""
+    def one(v):
+        return v[0] if isinstance(v, (tuple, list)) and len(set(v)) == 1 else v
+    if not (_FUSE_STEM_POOL and isinstance(bn, SyncBatchNorm) and isinstance(pool, torch.nn.MaxPool2d)
+            and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4
+            and x.dtype in (torch.float32, torch.bfloat16)):
+        return None
+    if (one(pool.kernel_size), one(pool.stride), one(pool.padding), one(pool.dilation)) != (3, 2, 1, 1) \
+            or pool.ceil_mode or pool.return_indices or bn.momentum is None:
+        return None
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if x.shape[1] % vec or x.is_contiguous() or not x.is_contiguous(memory_format=torch.channels_last):
+        return None
+    bn._check_input_dim(x)
+    use_batch_stats = bn.training or not bn.track_running_stats
+    from .stemconv import take_bn_partial
+    hint = take_bn_partial(x) if use_batch_stats else None
+    return _BnReluPoolFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, hint)
 
 
 class SyncBatchNorm(_BatchNorm):
@@ -196,8 +269,12 @@ class SyncBatchNorm(_BatchNorm):
             raise NotImplementedError("cumulative moving average (momentum=None) is not supported")
         relu = self.fuse_relu if relu is None else bool(relu)
         use_batch_stats = self.training or not self.track_running_stats
+        hint = None
+        if use_batch_stats and hasattr(input, "_tsg_bn_partial"):
+            from .stemconv import take_bn_partial
+            hint = take_bn_partial(input)
         return _SyncBNFn.apply(input, residual, self.weight, self.bias, self, relu,
-                               use_batch_stats, self.process_group)
+                               use_batch_stats, self.process_group, hint)
 
 
 def convert_syncbn_model(module, process_group=None, channel_last=False):
