@@ -266,6 +266,18 @@ int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int
 /* out[ci][kh][kw][oc] (bf16) = w[oc][2-kh][2-kw][ci] (fp32 or bf16, the channels_last filter layout): the filter with
  * which the DATA gradient of a stride-1 / padding-1 3x3 convolution is itself a forward convolution of dy — what
  * autograd's cuDNN backward-data call computes for resnet.py:24-29 — so that it can run on the (faster) forward kernels. */
+/* Forward of the 64 -> 64 channel 3x3 / stride 1 / padding 1 convolutions (ResNet-18 layer1, resnet.py:24-29,36-53) —
+ * replaces the cuDNN forward call, and, fed dy and tsg_conv3x3_weight_rot180_t(w), the backward-data call.  x, y
+ * [B,H,W,64] bf16 channels_last; w bf16 [oc][kh][kw][ci] (the channels_last filter layout); fp32 accumulation.
+ * partial (may be NULL): [S][2][64] fp32 per-block sums / square sums of the bf16-rounded outputs, S =
+ * tsg_conv3x3_c64_stats_partials(B, H, W) — the layout tsg_bn_finalize / tsg_bn_collapse take, so the BatchNorm that
+ * follows does not re-read y for its statistics. */
+int tsg_conv3x3_c64_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
+                              int groups);
+int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W);
+int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
+                        void* stream);
+
 int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int I, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -32,11 +32,21 @@ _DGRAD_FWD = _DGRAD_MODE not in ("0", "false", "no", "off", "")
 _DGRAD_ANY = _DGRAD_MODE == "2"
 
 
+# TSG_CONV_C64=1|0 (default 1): forward and data gradient of the 64 -> 64 stride-1 layers on tsg_conv3x3_c64_fwd
+# (104 us against 172 us for the library's kernel at [16, 64, 256, 256], tools/bench_conv64.py)
+_OWN_C64 = _os.environ.get("TSG_CONV_C64", "1") != "0"
+
+
 class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, wb, stride):
         # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
-        y = F.conv2d(x, wb, None, stride, 1)
+        ctx.own = _OWN_C64 and stride == 1 and K.provider().conv3x3_c64_supported(x, wb, stride, 1, 1, 1) \
+            and wb.is_contiguous(memory_format=torch.channels_last)
+        if ctx.own:
+            y = K.provider().conv3x3_c64_fwd(x, wb)          # 64 -> 64: our forward kernel (csrc/conv64.hip)
+        else:
+            y = F.conv2d(x, wb, None, stride, 1)
         ctx.stride = stride
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
@@ -52,7 +62,9 @@ class _ConvWrwFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
         if ctx.need_dx:
-            if ctx.dgrad_fwd:
+            if ctx.own:
+                dx = K.provider().conv3x3_c64_fwd(dy, K.provider().conv3x3_weight_rot180_t(wb))
+            elif ctx.dgrad_fwd:
                 # dx = conv(dy, rot180(w)^T): the library's forward kernels beat its backward-data kernels on the
                 # symmetric layers (tools/probe_conv2.py); same bf16 operands, fp32 accumulation
                 dx = F.conv2d(dy, K.provider().conv3x3_weight_rot180_t(wb), None, 1, 1)

@@ -538,6 +538,27 @@ class HipKernels:
                                           float(grad_scale), L.stream_ptr(param)), "tsg_sgd_step_dev")
 
     # ---- 3x3 weight gradient ----------------------------------------------------
+    def conv3x3_c64_supported(self, x, weight, stride, padding, dilation, groups):
+        if x.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+            return False
+        return bool(self.lib.tsg_conv3x3_c64_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
+                                                       weight.shape[3], stride, padding, dilation, groups))
+
+    def conv3x3_c64_fwd(self, x, wb, with_stats=False):
+        """x [B,64,H,W] bf16 channels_last, wb bf16 [64,64,3,3] channels_last -> y (channels_last) or (y, partial [S,2,64])"""
+        if not x.is_contiguous(memory_format=torch.channels_last) or not wb.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("conv3x3_c64_fwd expects channels_last operands")
+        B, _, H, W = x.shape
+        y = torch.empty_like(x)
+        partial = None
+        if with_stats:
+            S = self._count(("c64_stats", B, H, W), lambda: self.lib.tsg_conv3x3_c64_stats_partials(B, H, W),
+                            "tsg_conv3x3_c64_stats_partials")
+            partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
+        L.check(self.lib.tsg_conv3x3_c64_fwd(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), B, H, W,
+                                             L.stream_ptr(x)), "tsg_conv3x3_c64_fwd")
+        return (y, partial) if with_stats else y
+
     def conv3x3_wrw_supported(self, x, weight, stride, padding, dilation, groups):
         if x.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
             return False
@@ -750,6 +771,7 @@ _ALGO_BYTES = {
     "bn_relu_pool_bwd_apply": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 2 * _nbytes(a[2]),
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
+    "conv3x3_c64_fwd": lambda a, r: 2 * _nbytes(a[0]),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
 
@@ -758,6 +780,7 @@ _ALGO_BYTES = {
 _ALGO_FLOPS = {
     "conv3x3_wrw": lambda a, r: 2 * 9 * a[1].numel() * a[0].shape[1],          # dy elements x C_in x 9 taps
     "stem_conv_fwd": lambda a, r: 2 * 147 * r.numel(),
+    "conv3x3_c64_fwd": lambda a, r: 2 * 9 * 64 * a[0].numel(),
     "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
     "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
 }
