@@ -277,6 +277,15 @@ int tsg_conv3x3_c64_supported(int dtype, int Cin, int Cout, int kh, int kw, int 
 int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W);
 int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
                         void* stream);
+/* The same for stride 2 (BiSeNet SpatialPath.conv_3x3_1 / conv_3x3_2, network.py:117-118): x [B,H,W,64] ->
+ * y [B,OH,OW,64], OH = (H - 1) / 2 + 1; and its data gradient dx [B,H,W,64] from dy [B,OH,OW,64] and the transposed
+ * filter wt = tsg_conv3x3_weight_rot180_t(w), evaluated per output parity (9 tap products per 2 x 2 block of dx, every
+ * element written once, no atomics).  Both stream the large tensor once; fp32 accumulation, bf16 results. */
+int tsg_conv3x3_c64_s2_stats_partials(int64_t B, int64_t H, int64_t W);
+int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
+                           void* stream);
+int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B, int64_t H, int64_t W,
+                             void* stream);
 
 int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int I, void* stream);
 

@@ -69,3 +69,39 @@ def test_conv64_is_the_data_gradient_with_the_rotated_filter(cuda):
 def test_conv64_full_size(cuda):
     """BASELINE config 2 geometry of layer1 ([B, 64, 256, 256]; B = 2 keeps the fp64 oracle to seconds)."""
     _run(cuda, 2, 256, 256, seed=5)
+
+
+S2_SHAPES = [(2, 8, 32), (1, 5, 37), (2, 9, 64), (1, 33, 70), (2, 64, 64), (1, 1, 1), (1, 2, 2), (1, 130, 66)]
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES)
+def test_conv64_stride2_forward_and_data_gradient_vs_fp64(cuda, shape):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, 64, OH, OW, generator=g)
+    xb = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    wb = w.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert kp.conv3x3_c64_supported(xb, wb, 2, 1, 1, 1)
+    y, partial = kp.conv3x3_c64_fwd(xb, wb, True, stride=2)
+    assert tuple(y.shape) == (B, 64, OH, OW) and y.is_contiguous(memory_format=torch.channels_last)
+    xr = conv_ref.bf16_round(x).requires_grad_(True)
+    y_ref = torch.nn.functional.conv2d(xr, conv_ref.bf16_round(w), None, 2, 1)
+    err = (y.double().cpu() - y_ref.detach()).abs()
+    assert bool((err <= y_ref.detach().abs() * 2.0 ** -8 + 1e-3 * y_ref.detach().abs().max()).all()), err.max().item()
+    np.testing.assert_allclose(conv_ref.conv2d_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(w), stride=2, pad=1).numpy(),
+                               y_ref.detach().numpy(), rtol=1e-10, atol=1e-10)       # the oracle states the same thing
+    yf = y.double().cpu()
+    np.testing.assert_allclose(partial.double().sum(0).cpu().numpy(),
+                               torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).numpy(), rtol=2e-5, atol=1e-3)
+    assert torch.equal(y, kp.conv3x3_c64_fwd(xb, wb, stride=2))
+    y_ref.backward(conv_ref.bf16_round(dy))
+    dx = kp.conv3x3_c64_s2_dgrad(dyb, kp.conv3x3_weight_rot180_t(wb), (H, W))
+    assert tuple(dx.shape) == (B, 64, H, W) and dx.is_contiguous(memory_format=torch.channels_last)
+    err = (dx.double().cpu() - xr.grad).abs()
+    assert bool((err <= xr.grad.abs() * 2.0 ** -8 + 1e-3 * xr.grad.abs().max()).all()), err.max().item()

@@ -1,0 +1,1 @@
+for occ in 1 2; do echo "== OCC=$occ"; TSG_C64_OCC=$occ timeout 200 python tools/bench_conv64.py 2>&1 | grep "H="; done

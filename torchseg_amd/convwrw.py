@@ -41,10 +41,11 @@ class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, wb, stride):
         # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
-        ctx.own = _OWN_C64 and stride == 1 and K.provider().conv3x3_c64_supported(x, wb, stride, 1, 1, 1) \
+        ctx.own = _OWN_C64 and K.provider().conv3x3_c64_supported(x, wb, stride, 1, 1, 1) \
             and wb.is_contiguous(memory_format=torch.channels_last)
+        ctx.in_hw = (x.shape[2], x.shape[3])
         if ctx.own:
-            y = K.provider().conv3x3_c64_fwd(x, wb)          # 64 -> 64: our forward kernel (csrc/conv64.hip)
+            y = K.provider().conv3x3_c64_fwd(x, wb, stride=stride)     # 64 -> 64: our kernels (csrc/conv64.hip)
         else:
             y = F.conv2d(x, wb, None, stride, 1)
         ctx.stride = stride
@@ -62,7 +63,9 @@ class _ConvWrwFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
         if ctx.need_dx:
-            if ctx.own:
+            if ctx.own and ctx.stride == 2:
+                dx = K.provider().conv3x3_c64_s2_dgrad(dy, K.provider().conv3x3_weight_rot180_t(wb), ctx.in_hw)
+            elif ctx.own:
                 dx = K.provider().conv3x3_c64_fwd(dy, K.provider().conv3x3_weight_rot180_t(wb))
             elif ctx.dgrad_fwd:
                 # dx = conv(dy, rot180(w)^T): the library's forward kernels beat its backward-data kernels on the

@@ -591,7 +591,8 @@ __device__ __forceinline__ void tail_sums(const float* __restrict__ partial, int
   c = (int64_t)blockIdx.x * kTc + tc;
   double p1 = 0.0, p2 = 0.0;
   if (c < C) {
-#pragma unroll 4
+    // 16 independent row pairs in flight per thread: these kernels are pure load latency (S / 32 rounds of it)
+#pragma unroll 16
     for (int s = ts; s < S; s += kTs) {
       p1 += (double)partial[((int64_t)s * 2 + 0) * C + c];
       p2 += (double)partial[((int64_t)s * 2 + 1) * C + c];

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_fold(const float* __restric
   const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
   const float* src = part + (int64_t)pair * g.bpp * W3_C * W3_N + run * 64 + c4 * 4;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
+#pragma unroll 16
   for (int s = gs; s < g.bpp; s += 16) {
     const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * W3_C * W3_N);
     a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void conv3_wrw_fold(const float* __restrict__ 
   const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
   const float* src = part + blockIdx.x * 64 + c4 * 4;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
+#pragma unroll 16
   for (int gidx = gs; gidx < nparts; gidx += 16) {
     const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)gidx * stride);
     a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;

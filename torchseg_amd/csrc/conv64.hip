@@ -18,6 +18,7 @@
 //     BatchNorm that follows every one of these convolutions), partial[block][2][64].
 // x, y: NHWC bf16.  w: bf16 [oc][kh][kw][ci] (the channels_last filter layout).
 #include "tsg_common.h"
+#include <stdlib.h>
 
 namespace tsg {
 
@@ -30,7 +31,6 @@ constexpr int C6_PH = C6_TH + 2, C6_PW = C6_TW + 2;      // input patch, pixels
 constexpr int C6_PS = 72;                                // LDS pixel stride in bf16 (144 B)
 constexpr int C6_NV = C6_PH * C6_PW * 8;                 // 16-byte vectors of a patch: 1632
 constexpr int C6_NF = (C6_NV + 255) / 256;               // 7 per thread (the last one partly)
-constexpr int C6_BLOCKS = 512;                           // persistent blocks: 2 per CU (~230 VGPRs)
 
 struct C6Geom { int B, H, W, tiles_h, tiles_w, ntiles; };
 
@@ -68,8 +68,8 @@ __device__ __forceinline__ void c6_fetch(const bf16_t* __restrict__ x, const C6G
 }
 
 // 4 waves: wave = (row pair wr) * 2 + (oc half wm)
-template <bool STATS>
-__global__ __launch_bounds__(256, 2) void conv64_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+template <bool STATS, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                     bf16_t* __restrict__ y, C6Geom g, float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) bf16_t patch[C6_PH * C6_PW * C6_PS];     // 29376 B
   __shared__ __attribute__((aligned(16))) bf16_t outs[C6_TH * C6_TW * C6_PS];      // 18432 B: [pixel][64 oc + 8 pad]
@@ -171,6 +171,261 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_k(const bf16_t* __restrict_
   }
 }
 
+// =====================================================================================================================
+// Stride 2 (BiSeNet's SpatialPath.conv_3x3_1 / conv_3x3_2, network.py:117-118: 64 -> 64, 3x3 / 2 / 1, on the 512^2 and
+// 256^2 maps).  Both directions move 5 bytes of activation per 2 flops/byte of MFMA work: memory-bound, so the aim is
+// to stream the big tensor exactly once at the HBM rate, which the vendor kernels miss by 1.7x (forward) and 3x (data
+// gradient, tools/probe_conv2.py).
+//   forward  : tile = 2 output rows x 32 columns from a 5 x 65 input patch; the patch is stored as an EVEN-column and an
+//              ODD-column plane per row, so that the 32 lanes of a B fragment (output columns q .. q+31, input columns
+//              2q + kw) read 32 consecutive pixels of one plane (144-byte stride: conflict-free).
+//   backward : by output parity.  dx[2m+a][2q+b] only sees the taps with kh = 1 - a (mod 2), kw = 1 - b (mod 2):
+//                (0,0) 1 tap, (0,1) 2, (1,0) 2, (1,1) 4 — 9 tap-products per 2 x 2 block of dx instead of 36, no zero
+//              insertion, no atomics, every dx element written once.  Tile = 2 dy rows x 32 dy columns (3 x 33 patch)
+//              -> 4 x 64 pixels of dx, the four parities computed one after the other into one staging tile.
+//              The A operand is the transposed filter: tsg_conv3x3_weight_rot180_t's output, indexed back by tap.
+// =====================================================================================================================
+constexpr int S2_TH = 2, S2_TW = 32;
+constexpr int S2_PH = 2 * S2_TH + 1, S2_PW = 2 * S2_TW + 1;      // 5 x 65 input pixels
+constexpr int S2_NE = S2_TW + 1;                                 // even-plane pixels per row (33), odd plane: 32
+constexpr int S2_NV = S2_PH * S2_PW * 8;                         // 2600 vectors
+constexpr int S2_NF = (S2_NV + 255) / 256;                       // 11
+
+struct S2Geom { int B, H, W, OH, OW, tiles_h, tiles_w, ntiles; };
+__device__ __forceinline__ C6Tile s2_tile(const S2Geom& g, int tile, int th, int tw) {
+  C6Tile t;
+  t.ow0 = (tile % g.tiles_w) * tw;
+  t.oh0 = ((tile / g.tiles_w) % g.tiles_h) * th;
+  t.b = tile / (g.tiles_w * g.tiles_h);
+  return t;
+}
+
+template <int NF, int NV, int PW>
+struct S2Lane {
+  int rc[NF];
+  __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int v = tid + 256 * u, px = v >> 3;
+      rc[u] = v < NV ? ((px / PW) | ((px % PW) << 8)) : -1;
+    }
+  }
+};
+
+template <bool STATS, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv64_fwd_s2_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, S2Geom g, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) bf16_t patch[S2_PH * S2_PW * C6_PS];     // 46800 B
+  __shared__ __attribute__((aligned(16))) bf16_t outs[S2_TH * S2_TW * C6_PS];      // 9216 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int wm = wave & 1, wr = wave >> 1;
+  c6_bf16x8 fw[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      fw[t][kc] = *reinterpret_cast<const c6_bf16x8*>(w + ((wm * 32 + p) * 9 + t) * C6_C + kc * 16 + half * 8);
+  const int part8 = (tid & 7) * 8;
+  S2Lane<S2_NF, S2_NV, S2_PW> ln;
+  ln.init(tid);
+  uint4 rp[S2_NF];
+  auto fetch = [&](const C6Tile& t) {
+    const bf16_t* xb = x + (int64_t)t.b * g.H * g.W * C6_C + part8;
+#pragma unroll
+    for (int u = 0; u < S2_NF; ++u) {
+      const int ih = 2 * t.oh0 - 1 + (ln.rc[u] & 0xff), iw = 2 * t.ow0 - 1 + (ln.rc[u] >> 8);
+      rp[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (ln.rc[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+        rp[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)ih * g.W + iw) * C6_C);
+    }
+  };
+  float st1 = 0.f, st2 = 0.f;
+  int tile = blockIdx.x;
+  C6Tile tp = s2_tile(g, tile < g.ntiles ? tile : 0, S2_TH, S2_TW);
+  if (tile < g.ntiles) fetch(tp);
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < S2_NF; ++u) {
+      if (u < S2_NF - 1 || ln.rc[u] >= 0) {
+        const int pr = ln.rc[u] & 0xff, pc = ln.rc[u] >> 8;
+        const int pix = pr * S2_PW + ((pc & 1) ? S2_NE + (pc >> 1) : (pc >> 1));     // even plane, then odd plane
+        *reinterpret_cast<uint4*>(patch + pix * C6_PS + part8) = rp[u];
+      }
+    }
+    __syncthreads();
+    C6Tile tn = tp;
+    if (tile + (int)gridDim.x < g.ntiles) {
+      tn = s2_tile(g, tile + gridDim.x, S2_TH, S2_TW);
+      fetch(tn);
+    }
+    c6_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int kh = t / 3, kw = t % 3;
+      const bf16_t* pb = patch + ((2 * wr + kh) * S2_PW + (kw == 1 ? S2_NE + p : p + (kw >> 1))) * C6_PS + half * 8;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const c6_bf16x8 fb = *reinterpret_cast<const c6_bf16x8*>(pb + kc * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[t][kc], fb, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int oc0 = 32 * wm + 8 * gq + 4 * half;
+      uint2 v;
+      v.x = pack2_bf16(acc[4 * gq + 0], acc[4 * gq + 1]);
+      v.y = pack2_bf16(acc[4 * gq + 2], acc[4 * gq + 3]);
+      *reinterpret_cast<uint2*>(outs + (wr * S2_TW + p) * C6_PS + oc0) = v;
+    }
+    __syncthreads();
+    bf16_t* yt = y + (((int64_t)tp.b * g.OH + tp.oh0) * g.OW + tp.ow0) * C6_C;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = tid + 256 * k, qd = v >> 8, spl = (v >> 3) & 31, spart = v & 7;
+      if (tp.oh0 + qd < g.OH && tp.ow0 + spl < g.OW)
+        *reinterpret_cast<uint4*>(yt + ((int64_t)qd * g.OW + spl) * C6_C + spart * 8) =
+            *reinterpret_cast<const uint4*>(outs + (qd * S2_TW + spl) * C6_PS + spart * 8);
+    }
+    if (STATS) {
+      const int c = tid & 63, grp = tid >> 6;              // channel c over 16 of the tile's 64 pixels
+      const int qd = grp >> 1, px0 = (grp & 1) * 16;
+      if (tp.oh0 + qd < g.OH) {
+        const bf16_t* col = outs + (qd * S2_TW + px0) * C6_PS + c;
+#pragma unroll 8
+        for (int px = 0; px < 16; ++px)
+          if (tp.ow0 + px0 + px < g.OW) { const float v = bf16_to_f32(col[px * C6_PS]); st1 += v; st2 = fmaf(v, v, st2); }
+      }
+    }
+    tp = tn;
+  }
+  if (STATS) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(patch);
+    red[tid] = st1; red[256 + tid] = st2;
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;
+      const float* r = red + which * 256 + c;
+      partial[((int64_t)blockIdx.x * 2 + which) * C6_C + c] = (r[0] + r[64]) + (r[128] + r[192]);
+    }
+  }
+}
+
+// ---- data gradient, stride 2.  g.H / g.W: dx (= the forward input) size; g.OH / g.OW: dy size; tiles over dy.
+constexpr int D2_TH = 2, D2_TW = 32;
+constexpr int D2_PH = D2_TH + 1, D2_PW = D2_TW + 1;              // 3 x 33 dy pixels
+constexpr int D2_NV = D2_PH * D2_PW * 8;                         // 792
+constexpr int D2_NF = (D2_NV + 255) / 256;                       // 4
+constexpr int D2_OW = 2 * D2_TW;                                 // 64 dx columns per tile
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void conv64_dgrad_s2_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wt,
+                                                            bf16_t* __restrict__ dx, S2Geom g) {
+  __shared__ __attribute__((aligned(16))) bf16_t patch[D2_PH * D2_PW * C6_PS];             // 14256 B
+  __shared__ __attribute__((aligned(16))) bf16_t outs[2 * D2_TH * D2_OW * C6_PS];          // 36864 B: 4 x 64 dx pixels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int wm = wave & 1, wr = wave >> 1;
+  // transposed filter: wt[ci][kh'][kw'][co] = w[co][2 - kh'][2 - kw'][ci]; fragment of forward tap (kh, kw): rows ci, K = co
+  c6_bf16x8 fw[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      fw[t][kc] = *reinterpret_cast<const c6_bf16x8*>(wt + ((wm * 32 + p) * 9 + (8 - t)) * C6_C + kc * 16 + half * 8);
+  const int part8 = (tid & 7) * 8;
+  S2Lane<D2_NF, D2_NV, D2_PW> ln;
+  ln.init(tid);
+  uint4 rp[D2_NF];
+  auto fetch = [&](const C6Tile& t) {
+    const bf16_t* db = dy + (int64_t)t.b * g.OH * g.OW * C6_C + part8;
+#pragma unroll
+    for (int u = 0; u < D2_NF; ++u) {
+      const int oh = t.oh0 + (ln.rc[u] & 0xff), ow = t.ow0 + (ln.rc[u] >> 8);
+      rp[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (ln.rc[u] >= 0 && oh < g.OH && ow < g.OW)
+        rp[u] = *reinterpret_cast<const uint4*>(db + ((int64_t)oh * g.OW + ow) * C6_C);
+    }
+  };
+  int tile = blockIdx.x;
+  C6Tile tp = s2_tile(g, tile < g.ntiles ? tile : 0, D2_TH, D2_TW);
+  if (tile < g.ntiles) fetch(tp);
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < D2_NF; ++u)
+      if (u < D2_NF - 1 || ln.rc[u] >= 0)
+        *reinterpret_cast<uint4*>(patch + ((ln.rc[u] & 0xff) * D2_PW + (ln.rc[u] >> 8)) * C6_PS + part8) = rp[u];
+    __syncthreads();
+    C6Tile tn = tp;
+    if (tile + (int)gridDim.x < g.ntiles) {
+      tn = s2_tile(g, tile + gridDim.x, D2_TH, D2_TW);
+      fetch(tn);
+    }
+    // B fragment of dy pixel (row wr + dr, column p + dc)
+    const bf16_t* pb = patch + (wr * D2_PW + p) * C6_PS + half * 8;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int a = ph >> 1, b = ph & 1;
+      c6_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ih = 0; ih <= a; ++ih) {
+        const int kh = a ? (ih ? 0 : 2) : 1, dr = a ? ih : 0;          // a = 1: kh = 2 reads dy[m], kh = 0 reads dy[m+1]
+#pragma unroll
+        for (int iw = 0; iw <= b; ++iw) {
+          const int kw = b ? (iw ? 0 : 2) : 1, dc = b ? iw : 0;
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            const c6_bf16x8 fb = *reinterpret_cast<const c6_bf16x8*>(pb + (dr * D2_PW + dc) * C6_PS + kc * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kh * 3 + kw][kc], fb, acc, 0, 0, 0);
+          }
+        }
+      }
+      // acc[r]: ci = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, dx pixel (row 2 wr + a, column 2 p + b) of the tile
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int c0 = 32 * wm + 8 * gq + 4 * half;
+        uint2 v;
+        v.x = pack2_bf16(acc[4 * gq + 0], acc[4 * gq + 1]);
+        v.y = pack2_bf16(acc[4 * gq + 2], acc[4 * gq + 3]);
+        *reinterpret_cast<uint2*>(outs + ((2 * wr + a) * D2_OW + 2 * p + b) * C6_PS + c0) = v;
+      }
+    }
+    __syncthreads();
+    bf16_t* xt = dx + (((int64_t)tp.b * g.H + 2 * tp.oh0) * g.W + 2 * tp.ow0) * C6_C;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int v = tid + 256 * k, qd = v >> 9, spl = (v >> 3) & 63, spart = v & 7;
+      if (2 * tp.oh0 + qd < g.H && 2 * tp.ow0 + spl < g.W)
+        *reinterpret_cast<uint4*>(xt + ((int64_t)qd * g.W + spl) * C6_C + spart * 8) =
+            *reinterpret_cast<const uint4*>(outs + (qd * D2_OW + spl) * C6_PS + spart * 8);
+    }
+    tp = tn;
+  }
+}
+
+static bool s2_geom(int64_t B, int64_t H, int64_t W, int th, int tw, S2Geom* g) {
+  if (B <= 0 || H <= 0 || W <= 0) return false;
+  const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t nh = (OH + th - 1) / th, nw = (OW + tw - 1) / tw;
+  if (B * nh * nw > 0x7fffffffLL || H * W * C6_C > 0x7fffffffLL) return false;
+  g->B = (int)B; g->H = (int)H; g->W = (int)W; g->OH = (int)OH; g->OW = (int)OW;
+  g->tiles_h = (int)nh; g->tiles_w = (int)nw; g->ntiles = (int)(B * nh * nw);
+  return true;
+}
+
+// TSG_C64_OCC=1 (default): one block per CU with the whole register file — the 144 filter registers leave no room for
+// two waves per SIMD without spilling, and a kernel that touches scratch memory lost 60 % here (98 -> 162 us);
+// 2: two blocks per CU (spills)
+static int c6_occ() {
+  static const int occ = [] { const char* e = getenv("TSG_C64_OCC"); return e ? atoi(e) : 1; }();
+  return occ == 2 ? 2 : 1;
+}
+
 static bool c6_geom(int64_t B, int64_t H, int64_t W, C6Geom* g) {
   if (B <= 0 || H <= 0 || W <= 0) return false;
   const int64_t th = (H + C6_TH - 1) / C6_TH, tw = (W + C6_TW - 1) / C6_TW;
@@ -187,14 +442,14 @@ extern "C" {
 
 int tsg_conv3x3_c64_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
                               int groups) {
-  return dtype == TSG_BF16 && Cin == C6_C && Cout == C6_C && kh == 3 && kw == 3 && stride == 1 && pad == 1 &&
-         dilation == 1 && groups == 1;
+  return dtype == TSG_BF16 && Cin == C6_C && Cout == C6_C && kh == 3 && kw == 3 && (stride == 1 || stride == 2) &&
+         pad == 1 && dilation == 1 && groups == 1;
 }
 
 int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W) {
   C6Geom g;
   if (!c6_geom(B, H, W, &g)) return TSG_E_SHAPE;
-  return g.ntiles < C6_BLOCKS ? g.ntiles : C6_BLOCKS;
+  return g.ntiles < 256 * c6_occ() ? g.ntiles : 256 * c6_occ();
 }
 
 int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
@@ -204,13 +459,54 @@ int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, i
   if (!c6_geom(B, H, W, &g)) return TSG_E_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = g.ntiles < C6_BLOCKS ? g.ntiles : C6_BLOCKS;
-  if (partial)
-    hipLaunchKernelGGL(conv64_fwd_k<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, g,
-                       partial);
+  const int occ = c6_occ();
+  const int per_cu = occ == 1 ? 1 : 2;
+  const int grid = g.ntiles < 256 * per_cu ? g.ntiles : 256 * per_cu;
+#define C6_GO(ST, OC) hipLaunchKernelGGL((conv64_fwd_k<ST, OC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
+                                         (const bf16_t*)w, (bf16_t*)y, g, partial)
+  if (partial) { if (occ == 1) C6_GO(true, 1); else C6_GO(true, 2); }
+  else { if (occ == 1) C6_GO(false, 1); else C6_GO(false, 2); }
+#undef C6_GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_conv3x3_c64_s2_stats_partials(int64_t B, int64_t H, int64_t W) {
+  S2Geom g;
+  if (!s2_geom(B, H, W, S2_TH, S2_TW, &g)) return TSG_E_SHAPE;
+  return g.ntiles < 256 * c6_occ() ? g.ntiles : 256 * c6_occ();
+}
+
+int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
+                           void* stream) {
+  if (!x || !w || !y) return TSG_E_NULL;
+  S2Geom g;
+  if (!s2_geom(B, H, W, S2_TH, S2_TW, &g)) return TSG_E_SHAPE;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int occ = c6_occ();
+  const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
+#define C6_GO(ST, OC) hipLaunchKernelGGL((conv64_fwd_s2_k<ST, OC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
+                                         (const bf16_t*)w, (bf16_t*)y, g, partial)
+  if (partial) { if (occ == 1) C6_GO(true, 1); else C6_GO(true, 2); }
+  else { if (occ == 1) C6_GO(false, 1); else C6_GO(false, 2); }
+#undef C6_GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B, int64_t H, int64_t W, void* stream) {
+  if (!dy || !wt || !dx) return TSG_E_NULL;
+  S2Geom g;
+  if (!s2_geom(B, H, W, D2_TH, D2_TW, &g)) return TSG_E_SHAPE;
+  if (!aligned16(dy) || !aligned16(wt) || !aligned16(dx)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int occ = c6_occ();
+  const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
+  if (occ == 1)
+    hipLaunchKernelGGL(conv64_dgrad_s2_k<1>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, g);
   else
-    hipLaunchKernelGGL(conv64_fwd_k<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
-                       g, (float*)nullptr);
+    hipLaunchKernelGGL(conv64_dgrad_s2_k<2>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, g);
   TSG_CHECK_LAUNCH();
   return 0;
 }

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kT) void gap_finish(const float* __restrict__ parti
   if (i >= NC) return;
   const int64_t n = i / C, c = i - n * C;
   float s = 0.f;
+#pragma unroll 16
   for (int q = 0; q < S; ++q) s += partial[(n * S + q) * C + c];
   st1<T>(out + i, s * inv);
 }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void stem_wrw_fold(const float* __restrict__ p
   const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
   const float* src = part + blockIdx.x * 64 + c4 * 4;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
+#pragma unroll 16
   for (int gidx = gs; gidx < nparts; gidx += 16) {
     const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)gidx * SC_OC * SC_KP);
     a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;

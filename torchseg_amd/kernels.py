@@ -544,20 +544,39 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_c64_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                        weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_c64_fwd(self, x, wb, with_stats=False):
-        """x [B,64,H,W] bf16 channels_last, wb bf16 [64,64,3,3] channels_last -> y (channels_last) or (y, partial [S,2,64])"""
+    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1):
+        """x [B,64,H,W] bf16 channels_last, wb bf16 [64,64,3,3] channels_last, 3x3 / stride 1 or 2 / padding 1
+        -> y (channels_last) or (y, partial [S,2,64])"""
         if not x.is_contiguous(memory_format=torch.channels_last) or not wb.is_contiguous(memory_format=torch.channels_last):
             raise ValueError("conv3x3_c64_fwd expects channels_last operands")
         B, _, H, W = x.shape
-        y = torch.empty_like(x)
+        lib = self.lib
+        if stride == 1:
+            y = torch.empty_like(x)
+            fn, cnt, what = lib.tsg_conv3x3_c64_fwd, lib.tsg_conv3x3_c64_stats_partials, "tsg_conv3x3_c64_fwd"
+        else:
+            y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device,
+                            memory_format=torch.channels_last)
+            fn, cnt, what = lib.tsg_conv3x3_c64_s2_fwd, lib.tsg_conv3x3_c64_s2_stats_partials, "tsg_conv3x3_c64_s2_fwd"
         partial = None
         if with_stats:
-            S = self._count(("c64_stats", B, H, W), lambda: self.lib.tsg_conv3x3_c64_stats_partials(B, H, W),
-                            "tsg_conv3x3_c64_stats_partials")
+            S = self._count(("c64_stats", stride, B, H, W), lambda: cnt(B, H, W), what)
             partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
-        L.check(self.lib.tsg_conv3x3_c64_fwd(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), B, H, W,
-                                             L.stream_ptr(x)), "tsg_conv3x3_c64_fwd")
+        L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), B, H, W, L.stream_ptr(x)), what)
         return (y, partial) if with_stats else y
+
+    def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw):
+        """dy [B,64,OH,OW] bf16 channels_last, wt = conv3x3_weight_rot180_t(w) -> dx [B,64,H,W] of the stride-2 convolution"""
+        if not dy.is_contiguous(memory_format=torch.channels_last) or not wt.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("conv3x3_c64_s2_dgrad expects channels_last operands")
+        B = dy.shape[0]
+        H, W = in_hw
+        if (H - 1) // 2 + 1 != dy.shape[2] or (W - 1) // 2 + 1 != dy.shape[3]:
+            raise ValueError("conv3x3_c64_s2_dgrad: dy does not belong to an input of that size")
+        dx = torch.empty((B, 64, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_conv3x3_c64_s2_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), B, H, W, L.stream_ptr(dy)),
+                "tsg_conv3x3_c64_s2_dgrad")
+        return dx
 
     def conv3x3_wrw_supported(self, x, weight, stride, padding, dilation, groups):
         if x.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
@@ -771,7 +790,8 @@ _ALGO_BYTES = {
     "bn_relu_pool_bwd_apply": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 2 * _nbytes(a[2]),
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
-    "conv3x3_c64_fwd": lambda a, r: 2 * _nbytes(a[0]),
+    "conv3x3_c64_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "conv3x3_c64_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
 
@@ -780,7 +800,8 @@ _ALGO_BYTES = {
 _ALGO_FLOPS = {
     "conv3x3_wrw": lambda a, r: 2 * 9 * a[1].numel() * a[0].shape[1],          # dy elements x C_in x 9 taps
     "stem_conv_fwd": lambda a, r: 2 * 147 * r.numel(),
-    "conv3x3_c64_fwd": lambda a, r: 2 * 9 * 64 * a[0].numel(),
+    "conv3x3_c64_fwd": lambda a, r: 2 * 9 * 64 * r.numel(),
+    "conv3x3_c64_s2_dgrad": lambda a, r: 2 * 9 * 64 * a[0].numel(),
     "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
     "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
 }
