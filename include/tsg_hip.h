@@ -501,6 +501,15 @@ int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* grads, const 
 int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, const int64_t* numel, int nseg,
                        const int* blockmap_dev, int64_t nblocks, float scale, void* stream);
 
+/* bf16 shadows of the fp32 master filters, all refreshed by ONE launch (after the optimizer step) instead of one cast
+ * (+ one rotate/transpose) launch per convolution and step.  table_dev: device array of
+ *   struct { const float* w; uint16_t* wb; uint16_t* wrt; int32_t n, O, I, pad; }   (tsg_weight_shadow_entry_bytes())
+ * wb[i] = bf16(w[i]); for channels_last 3x3 filters (memory [O][kh][kw][I]) and wrt != NULL also
+ * wrt[ci][2-kh][2-kw][o] = bf16(w[o][kh][kw][ci]) — what tsg_conv3x3_weight_rot180_t writes.  blockmap_dev / nblocks:
+ * tsg_sgd_multi_blockmap over the entries' n. */
+size_t tsg_weight_shadow_entry_bytes(void);
+int tsg_weight_shadow_refresh(const void* table_dev, const int* blockmap_dev, int64_t nblocks, void* stream);
+
 /* ------------------------------------------------------------------------
  * Training pre-processing on the GPU — replaces TrainPre.__call__ of the reference's dataloaders
  * (model/bisenet/cityscapes.bisenet.R18/dataloader.py:16-35) = furnace/utils/img_utils.py random_mirror (:138-143),

@@ -62,6 +62,8 @@ _PROTOS = {
     "tsg_stem_conv_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64]),
     "tsg_stem_conv_ws_bytes": (_sz, []),
     "tsg_stem_conv_fwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_weight_shadow_entry_bytes": (_sz, []),
+    "tsg_weight_shadow_refresh": (_i, [_p, _p, _i64, _p]),
     "tsg_stem_conv_stats_partials": (_i, [_i64, _i64, _i64]),
     "tsg_conv3x3_c64_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tsg_conv3x3_c64_stats_partials": (_i, [_i64, _i64, _i64]),

@@ -35,11 +35,15 @@ _DGRAD_ANY = _DGRAD_MODE == "2"
 # TSG_CONV_C64=1|0 (default 1): forward and data gradient of the 64 -> 64 stride-1 layers on tsg_conv3x3_c64_fwd
 # (104 us against 172 us for the library's kernel at [16, 64, 256, 256], tools/bench_conv64.py)
 _OWN_C64 = _os.environ.get("TSG_CONV_C64", "1") != "0"
+# TSG_WEIGHT_SHADOW=0|1 (default 0): bf16 / rotated filters from torchseg_amd.shadow (one refresh launch per step instead
+# of ~45 cast / rotate launches).  Measured neutral on one MI355X (1032.5 vs 1035.5 img/s: the 4-us launches it removes sit
+# back to back in the queue and cost the GPU almost nothing), so it stays opt-in for hosts that are launch-bound.
+_SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "0") == "1"
 
 
 class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, wb, stride):
+    def forward(ctx, x, weight, wb, stride, wrt=None):
         # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
         ctx.own = _OWN_C64 and K.provider().conv3x3_c64_supported(x, wb, stride, 1, 1, 1) \
             and wb.is_contiguous(memory_format=torch.channels_last)
@@ -49,6 +53,7 @@ class _ConvWrwFn(torch.autograd.Function):
         else:
             y = F.conv2d(x, wb, None, stride, 1)
         ctx.stride = stride
+        ctx.wrt = wrt                                  # not a graph tensor: a shadow owned by torchseg_amd.shadow
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
@@ -62,21 +67,22 @@ class _ConvWrwFn(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
+        rot = (lambda: ctx.wrt) if ctx.wrt is not None else (lambda: K.provider().conv3x3_weight_rot180_t(wb))
         if ctx.need_dx:
             if ctx.own and ctx.stride == 2:
-                dx = K.provider().conv3x3_c64_s2_dgrad(dy, K.provider().conv3x3_weight_rot180_t(wb), ctx.in_hw)
+                dx = K.provider().conv3x3_c64_s2_dgrad(dy, rot(), ctx.in_hw)
             elif ctx.own:
-                dx = K.provider().conv3x3_c64_fwd(dy, K.provider().conv3x3_weight_rot180_t(wb))
+                dx = K.provider().conv3x3_c64_fwd(dy, rot())
             elif ctx.dgrad_fwd:
                 # dx = conv(dy, rot180(w)^T): the library's forward kernels beat its backward-data kernels on the
                 # symmetric layers (tools/probe_conv2.py); same bf16 operands, fp32 accumulation
-                dx = F.conv2d(dy, K.provider().conv3x3_weight_rot180_t(wb), None, 1, 1)
+                dx = F.conv2d(dy, rot(), None, 1, 1)
             else:
                 st = ctx.stride
                 dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [st, st], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         dw = K.provider().conv3x3_wrw(x, dy, stride=ctx.stride)
-        return dx, dw.to(ctx.wdtype), None, None
+        return dx, dw.to(ctx.wdtype), None, None, None
 
 
 class WrwConv2d(nn.Conv2d):
@@ -90,8 +96,12 @@ class WrwConv2d(nn.Conv2d):
             if K.provider().conv3x3_wrw_supported(xb, self.weight, self.stride[0], self.padding[0], self.dilation[0],
                                                   self.groups):
                 with torch.autocast("cuda", enabled=False):
-                    wb = self.weight.detach().to(torch.bfloat16)
-                    return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0])
+                    if _SHADOW and self.weight.is_contiguous(memory_format=torch.channels_last):
+                        from .shadow import bank           # bf16 (and rotated) filters kept fresh once per step
+                        wb, wrt = bank.get(self.weight, want_rot=True)
+                    else:
+                        wb, wrt = self.weight.detach().to(torch.bfloat16), None
+                    return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt)
         return super().forward(x)
 
 

@@ -580,9 +580,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_mixed(
 }
 
 // =========================================================================
-// per-channel tail kernels: block = 32 channels x 32 slice-lanes, fp64, fixed order
+// per-channel tail kernels: block = 8 channels x 64 slice-lanes, fp64, fixed order
 // =========================================================================
-constexpr int kTc = 32, kTs = 32;
+// Latency-bound (S x 2C floats, S <= ~1024): few channels per block so that even C = 64 spreads over 8 CUs, many slice
+// lanes so that a thread has at most two rounds of 8 predicated loads.  512 threads: bn_finalize_k's fp64 tail needs > 128 registers.
+constexpr int kTc = 8, kTs = 64;
 
 __device__ __forceinline__ void tail_sums(const float* __restrict__ partial, int S, int64_t C,
                                           double& t1, double& t2, bool& owner, int64_t& c) {
@@ -591,11 +593,21 @@ __device__ __forceinline__ void tail_sums(const float* __restrict__ partial, int
   c = (int64_t)blockIdx.x * kTc + tc;
   double p1 = 0.0, p2 = 0.0;
   if (c < C) {
-    // 16 independent row pairs in flight per thread: these kernels are pure load latency (S / 32 rounds of it)
-#pragma unroll 16
-    for (int s = ts; s < S; s += kTs) {
-      p1 += (double)partial[((int64_t)s * 2 + 0) * C + c];
-      p2 += (double)partial[((int64_t)s * 2 + 1) * C + c];
+    // these kernels are pure load latency: 8 row pairs in flight per thread, predicated (not a remainder loop: the
+    // usual trip count is 2 .. 32), summed in row order
+    for (int s0 = ts; s0 < S; s0 += kTs * 8) {
+      float v1[8], v2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * kTs;
+        const bool ok = s < S;
+        const int64_t row = ok ? s : ts;
+        v1[u] = partial[(row * 2 + 0) * C + c];
+        v2[u] = partial[(row * 2 + 1) * C + c];
+        if (!ok) { v1[u] = 0.f; v2[u] = 0.f; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { p1 += (double)v1[u]; p2 += (double)v2[u]; }
     }
   }
   sh[0][ts][tc] = p1;

@@ -247,3 +247,47 @@ extern "C" int tsg_multi_copy_f32(const uint64_t* src, const uint64_t* dst, cons
   TSG_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ---------------------------------------------------------------- bf16 shadows of the fp32 master filters
+// The convolutions compute in bf16 (autocast), so every step each fp32 filter used to be cast to bf16 again (one tiny
+// launch per convolution) and, for the layers whose data gradient runs as a forward convolution, rotated / transposed
+// by another one.  This kernel refreshes all of them in ONE launch, right after the optimizer step: table[e] (device
+// memory, static per model) = {w, wb, wrt, n, O, I}; wb[i] = bf16(w[i]) in the filter's own memory order; for 3x3
+// filters stored [O][kh][kw][I] (channels_last) also wrt[ci][2 - kh][2 - kw][o] = bf16(w[o][kh][kw][ci]) when wrt != 0.
+namespace tsg {
+struct ShadowEntry {
+  const float* w;
+  bf16_t* wb;
+  bf16_t* wrt;
+  int n, O, I, pad;
+};
+static_assert(sizeof(ShadowEntry) == 40 || sizeof(ShadowEntry) == 48, "layout shared with torchseg_amd/shadow.py");
+
+__global__ __launch_bounds__(256) void weight_shadow_k(const ShadowEntry* __restrict__ table, const int2* __restrict__ map) {
+  const int2 m = map[blockIdx.x];
+  const ShadowEntry e = table[m.x];
+  const int base = m.y * kSgdChunk;
+  const int end = base + kSgdChunk < e.n ? base + kSgdChunk : e.n;
+  const int tapI = 9 * e.I;
+  for (int i = base + threadIdx.x; i < end; i += 256) {
+    const bf16_t v = f32_to_bf16(e.w[i]);
+    e.wb[i] = v;
+    if (e.wrt) {
+      const int o = i / tapI, r = i - o * tapI, tap = r / e.I, ci = r - tap * e.I;
+      e.wrt[(ci * 9 + (8 - tap)) * e.O + o] = v;
+    }
+  }
+}
+}  // namespace tsg
+
+extern "C" size_t tsg_weight_shadow_entry_bytes(void) { return sizeof(tsg::ShadowEntry); }
+
+extern "C" int tsg_weight_shadow_refresh(const void* table_dev, const int* blockmap_dev, int64_t nblocks, void* stream) {
+  if (!table_dev || !blockmap_dev) return TSG_E_NULL;
+  if (nblocks <= 0 || nblocks > 0x7fffffffLL) return TSG_E_SHAPE;
+  hipLaunchKernelGGL(tsg::weight_shadow_k, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                     (const tsg::ShadowEntry*)table_dev, reinterpret_cast<const int2*>(blockmap_dev));
+  TSG_CHECK_LAUNCH();
+  return 0;
+}

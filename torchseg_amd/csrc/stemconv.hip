@@ -346,10 +346,16 @@ __global__ __launch_bounds__(256) void stem_wrw_fold(const float* __restrict__ p
   const int c4 = threadIdx.x & 15, gs = threadIdx.x >> 4;
   const float* src = part + blockIdx.x * 64 + c4 * 4;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 16
-  for (int gidx = gs; gidx < nparts; gidx += 16) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)gidx * SC_OC * SC_KP);
-    a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  for (int s0 = gs; s0 < nparts; s0 += 16 * 8) {            // 8 predicated loads in flight, summed in order
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gidx = s0 + 16 * u;
+      v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(gidx < nparts ? gidx : gs) * SC_OC * SC_KP);
+      if (gidx >= nparts) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
   }
   sm[gs][c4 * 4 + 0] = a0; sm[gs][c4 * 4 + 1] = a1; sm[gs][c4 * 4 + 2] = a2; sm[gs][c4 * 4 + 3] = a3;
   __syncthreads();

@@ -117,4 +117,7 @@ class FusedSGD(torch.optim.Optimizer):
             ptrs = np.array([[t[0].data_ptr() for t in chunk], [t[1].data_ptr() for t in chunk],
                              [t[2].data_ptr() for t in chunk]], dtype=np.uint64)
             kp.sgd_multi_step_dev(ptrs, plan[0], plan[1], self._lr_dev, mom, wd, plan[2])
+        if first.is_cuda:
+            from . import shadow                     # the kernel above changed parameters behind torch's back
+            shadow.after_external_update(first.device)
         return None

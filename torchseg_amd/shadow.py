@@ -1,0 +1,116 @@
+"""bf16 shadows of the fp32 master filters, refreshed by one kernel launch per optimizer step.
+
+Under bf16 autocast every convolution used to cast its fp32 filter to bf16 on every forward (one 4 us launch each), and
+the layers whose data gradient runs as a forward convolution rotated / transposed it with a second one: ~45 launches per
+BiSeNet-R18 step that move 22 MB in total.  The modules of torchseg_amd.convwrw register their filters here instead;
+`tsg_weight_shadow_refresh` rewrites every shadow in ONE launch.
+
+Freshness: a shadow is valid for the version counter its parameter had when it was written.  Anything that changes the
+parameter through torch (load_state_dict, an eager optimizer, init functions) bumps that counter, and the next `get`
+refreshes.  FusedSGD updates parameters from its own kernel, which torch does not see — it therefore calls
+`after_external_update()` at the end of every step (also inside a captured graph, where the refresh launch is captured with
+the step)."""
+import weakref
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+_CHUNK = 4096          # elements per block (kSgdChunk of csrc/sgd.hip)
+
+
+class _Entry(object):
+    __slots__ = ("ref", "wb", "wrt", "version")
+
+    def __init__(self, param, want_rot):
+        self.ref = weakref.ref(param)
+        self.wb = torch.empty_like(param, dtype=torch.bfloat16)                       # same strides as the parameter
+        self.wrt = None
+        if want_rot:
+            O, I = param.shape[0], param.shape[1]
+            self.wrt = torch.empty((I, O, 3, 3), dtype=torch.bfloat16, device=param.device,
+                                   memory_format=torch.channels_last)
+        self.version = -1
+
+
+class _Bank(object):
+    def __init__(self):
+        self.entries = {}            # id(param) -> _Entry
+        self._table = None           # (device table, block map, n_entries)
+
+    def _prune(self):
+        dead = [k for k, e in self.entries.items() if e.ref() is None]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self._table = None
+
+    def register(self, param, want_rot):
+        e = self.entries.get(id(param))
+        if e is not None and e.ref() is param and (e.wrt is not None or not want_rot) and e.wb.device == param.device \
+                and e.wb.stride() == param.stride():
+            return e
+        if param.dtype != torch.float32 or not param.is_cuda:
+            raise K.L.TsgError("weight shadows are kept for fp32 parameters on the GPU")
+        if want_rot and not (param.dim() == 4 and tuple(param.shape[2:]) == (3, 3)
+                             and param.is_contiguous(memory_format=torch.channels_last)):
+            raise K.L.TsgError("the rotated shadow needs a channels_last [O, I, 3, 3] filter")
+        if not (param.is_contiguous() or (param.dim() == 4 and param.is_contiguous(memory_format=torch.channels_last))):
+            raise K.L.TsgError("weight shadows need a dense parameter")
+        self._prune()
+        e = self.entries[id(param)] = _Entry(param, want_rot)
+        self._table = None
+        return e
+
+    def _build(self, device):
+        ents = [e for e in self.entries.values() if e.ref() is not None and e.wb.device == device]
+        dt = np.dtype([("w", "<u8"), ("wb", "<u8"), ("wrt", "<u8"), ("n", "<i4"), ("O", "<i4"), ("I", "<i4"), ("pad", "<i4")])
+        assert dt.itemsize == K.provider().lib.tsg_weight_shadow_entry_bytes()
+        tab = np.zeros(len(ents), dtype=dt)
+        maps = []
+        for i, e in enumerate(ents):
+            p = e.ref()
+            tab[i] = (p.data_ptr(), e.wb.data_ptr(), 0 if e.wrt is None else e.wrt.data_ptr(), p.numel(),
+                      p.shape[0], p.shape[1] if p.dim() > 1 else 1, 0)
+            nb = (p.numel() + _CHUNK - 1) // _CHUNK
+            maps.append(np.stack([np.full(nb, i, dtype=np.int32), np.arange(nb, dtype=np.int32)], 1))
+        bmap = np.concatenate(maps, 0)
+        table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        return table, torch.from_numpy(np.ascontiguousarray(bmap)).to(device), ents
+
+    def refresh_all(self, device):
+        """One launch: every shadow on `device` from its parameter's current value."""
+        self._prune()
+        if not self.entries:
+            return
+        t = self._table
+        if t is None or t[0].device != device or any(e.ref() is None or e.ref().data_ptr() != ptr for e, ptr in t[3]):
+            table, bmap, ents = self._build(device)
+            t = self._table = (table, bmap, ents, [(e, e.ref().data_ptr()) for e in ents])
+        table, bmap, ents = t[0], t[1], t[2]
+        if not ents:
+            return
+        L = K.L
+        L.check(K.provider().lib.tsg_weight_shadow_refresh(table.data_ptr(), bmap.data_ptr(), bmap.shape[0],
+                                                           L.stream_ptr(table)), "tsg_weight_shadow_refresh")
+        for e in ents:
+            p = e.ref()
+            if p is not None:
+                e.version = p._version
+
+    def get(self, param, want_rot=False):
+        """(bf16 filter, rotated / transposed bf16 filter or None) of `param`, refreshed if the parameter changed."""
+        e = self.register(param, want_rot)
+        if e.version != param._version:
+            self.refresh_all(param.device)
+        return e.wb, e.wrt
+
+
+bank = _Bank()
+
+
+def after_external_update(device):
+    """Called by an optimizer that writes parameters without torch noticing (FusedSGD): all shadows are rewritten."""
+    if bank.entries:
+        bank.refresh_all(device)
