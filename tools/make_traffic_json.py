@@ -11,8 +11,13 @@ FAMILIES = [("bn_stats", r"bn_reduce_(nhwc|nchw)<[^,]+, \d+, 0,"), ("bn_bwd_redu
             ("upsample_fwd_nhwc", r"up_fwd_nhwc<"), ("upsample_bwd_nhwc", r"up_bwd_nhwc<"),
             ("chanscale_fwd", r"cs_fwd_"), ("chanscale_bwd", r"cs_bwd_"), ("gap_fwd", r"gap_fwd"), ("gap_bwd", r"gap_bwd"),
             ("maxpool_fwd", r"maxpool_fwd_nhwc<"), ("maxpool_bwd", r"maxpool_bwd_nhwc<"),
-            ("stem_conv_fwd", r"stem_fwd_k"), ("stem_conv_wrw", r"stem_wrw_k"), ("sgd_multi_step", r"sgd_multi_k")]
-UNCORRECTED = {"ohem_bwd", "stem_conv_fwd"}          # scalar side-array loads / 4-B-per-lane patch loads
+            ("stem_conv_fwd", r"stem_fwd_k<false>"), ("stem_conv_fwd_stats", r"stem_fwd_k<true>"), ("stem_conv_wrw", r"stem_wrw_k"),
+            ("sgd_multi_step", r"sgd_multi_k"),
+            ("conv3x3_wrw", r"conv3_wrw_(gen_k<|tr_k|k\()"), ("conv3x3_c64_fwd", r"conv64_fwd(_s2)?_k<"),
+            ("conv3x3_c64_s2_dgrad", r"conv64_dgrad_s2_k<"), ("ohem_up_fwd", r"ohem_up_fwd_k<"), ("ohem_up_bwd", r"ohem_up_bwd_k<"),
+            ("bn_relu_pool_fwd", r"bn_relu_pool_fwd_k<"), ("bn_relu_pool_bwd_reduce", r"bn_relu_pool_bwd_reduce_k<"),
+            ("bn_relu_pool_bwd_apply", r"bn_relu_pool_bwd_apply_k<")]
+UNCORRECTED = {"ohem_bwd", "stem_conv_fwd", "stem_conv_fwd_stats", "ohem_up_fwd", "ohem_up_bwd"}   # scalar side-array loads / 4-B-per-lane loads
 out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 2`, "
                   "MI355X, tools/pmc_traffic.sh + tools/make_traffic_json.py; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                   "(KiB units, FETCH_SIZE counts 1/2 of 16-B/lane streams on gfx950: MI355X_MICROARCH.md), uncorrected sum for "

@@ -288,8 +288,11 @@ template <int S> struct W3S {
   static constexpr size_t LDS = (size_t)(T3_DY + NPX * T3_RBE) * sizeof(bf16_t);    // 63,744 B / 136,896 B
 };
 
-template <int S>
-__global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+// PF = true: one block per CU, the next tile's operands are prefetched into registers while the MFMAs run.
+// PF = false: no register prefetch (the 44 registers it costs go), two blocks per CU that cover for each other's loads,
+// staging and barriers — with one block per CU the MFMA pipe idles ~2/3 of the time during those phases.
+template <int S, bool PF>
+__global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ part, W3GenGeom g) {
   typedef W3S<S> P;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -342,8 +345,9 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
   };
 
   int tile = slot;
-  if (tile < g.ntiles) fetch(tile);
+  if (PF && tile < g.ntiles) fetch(tile);
   for (; tile < g.ntiles; tile += g.bpp) {
+    if (!PF) fetch(tile);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < W3_TH; ++u)
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_k(const bf16_t* __restrict_
       if (u < P::XU - 1 || xr[u] >= 0)
         *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = rx[u];
     __syncthreads();
-    if (tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
+    if (PF && tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {                  // 16 output pixels: tile row ks >> 1, columns 16 (ks & 1) + 8 half ..
       union { v4i16 q[2]; bf16x8 v; } fa;
@@ -497,6 +501,15 @@ int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int6
   return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream);
 }
 
+// TSG_CONV_WRW_OCC=2 (default) | 1: stride-1 layers with >= 1024 pixel tiles run the two-blocks-per-CU variant of the
+// kernel (no register prefetch).  tools/bench_conv3wrw.py, us per layer, 1 -> 2: layer2 97 -> 88, layer3 107 -> 87,
+// layer4 127 -> 104, head1 193 -> 156 (0.99 PF), head2 99 -> 89; the 64^2 / 32^2 maps (<= 512 tiles) are a few us better
+// with one prefetching block per CU and keep it.
+static bool w3_occ2(int64_t ntiles) {
+  static const int v = [] { const char* e = getenv("TSG_CONV_WRW_OCC"); return e ? atoi(e) : 2; }();
+  return v == 2 && ntiles >= 1024;
+}
+
 static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout, int stride) {
   if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || Cin % W3_C || Cout % W3_C) return TSG_E_SHAPE;
   if (stride != 1 && stride != 2) return TSG_E_SHAPE;
@@ -510,7 +523,7 @@ static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t Hin, int64_t Win, int Cin
   // (measured: 256 blocks 826 img/s, 512 blocks 815, 128 blocks 789)
   static int target = 0;
   if (!target) { const char* e = getenv("TSG_CONV_WRW_BLOCKS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
-  int bpp = (target + g->npairs - 1) / g->npairs;
+  int bpp = ((stride == 1 && w3_occ2(g->ntiles) ? 2 * target : target) + g->npairs - 1) / g->npairs;
   if (bpp > g->ntiles) bpp = g->ntiles;
   if (bpp < 1) bpp = 1;
   g->bpp = bpp;
@@ -538,15 +551,20 @@ int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int
   if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, Hin, Win, Cin, Cout, stride)) return TSG_E_WS;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 1) {
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<1>),
+  if (stride == 1 && w3_occ2(g.ntiles)) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<1, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<1>::LDS));
-    hipLaunchKernelGGL(conv3_wrw_gen_k<1>, dim3(g.npairs * g.bpp), dim3(256), W3S<1>::LDS, st, (const bf16_t*)x,
+    hipLaunchKernelGGL((conv3_wrw_gen_k<1, false>), dim3(g.npairs * g.bpp), dim3(256), W3S<1>::LDS, st, (const bf16_t*)x,
+                       (const bf16_t*)dy, (float*)ws, g);
+  } else if (stride == 1) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<1>::LDS));
+    hipLaunchKernelGGL((conv3_wrw_gen_k<1, true>), dim3(g.npairs * g.bpp), dim3(256), W3S<1>::LDS, st, (const bf16_t*)x,
                        (const bf16_t*)dy, (float*)ws, g);
   } else {
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<2>),
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<2>::LDS));
-    hipLaunchKernelGGL(conv3_wrw_gen_k<2>, dim3(g.npairs * g.bpp), dim3(256), W3S<2>::LDS, st, (const bf16_t*)x,
+    hipLaunchKernelGGL((conv3_wrw_gen_k<2, true>), dim3(g.npairs * g.bpp), dim3(256), W3S<2>::LDS, st, (const bf16_t*)x,
                        (const bf16_t*)dy, (float*)ws, g);
   }
   TSG_CHECK_LAUNCH();

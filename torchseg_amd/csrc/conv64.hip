@@ -31,6 +31,7 @@ constexpr int C6_PH = C6_TH + 2, C6_PW = C6_TW + 2;      // input patch, pixels
 constexpr int C6_PS = 72;                                // LDS pixel stride in bf16 (144 B)
 constexpr int C6_NV = C6_PH * C6_PW * 8;                 // 16-byte vectors of a patch: 1632
 constexpr int C6_NF = (C6_NV + 255) / 256;               // 7 per thread (the last one partly)
+constexpr int C6_AHEAD = 12;                             // B fragments in flight ahead of the MFMA that consumes them
 
 struct C6Geom { int B, H, W, tiles_h, tiles_w, ntiles; };
 
@@ -91,8 +92,12 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
   int tile = blockIdx.x;
   C6Tile tp = c6_tile(g, tile < g.ntiles ? tile : 0);
   const int part8 = (tid & 7) * 8;
-  if (tile < g.ntiles) c6_fetch(x, g, tp, ln, part8, rp);
+  // OCC == 1: one block per CU, the next tile's patch is prefetched into registers during the MFMAs.
+  // OCC == 2: no register prefetch (its 28 registers are what does not fit twice), two blocks per CU cover for each
+  // other's loads, staging and epilogue.
+  if (OCC == 1 && tile < g.ntiles) c6_fetch(x, g, tp, ln, part8, rp);
   for (; tile < g.ntiles; tile += gridDim.x) {
+    if (OCC != 1) c6_fetch(x, g, tp, ln, part8, rp);
     __syncthreads();                                     // the previous tile's reads of patch / outs are done
 #pragma unroll
     for (int u = 0; u < C6_NF; ++u)
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
     C6Tile tn = tp;
     if (tile + (int)gridDim.x < g.ntiles) {              // in flight during the MFMAs below
       tn = c6_tile(g, tile + gridDim.x);
-      c6_fetch(x, g, tn, ln, part8, rp);
+      if (OCC == 1) c6_fetch(x, g, tn, ln, part8, rp);
     }
 
     c6_f32x16 acc[2];
@@ -111,17 +116,24 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const bf16_t* pb = patch + ((2 * wr) * C6_PW + p) * C6_PS + half * 8;
+    // 72 (tap, channel chunk, row) steps, software-pipelined by hand: the B fragment of step s + C6_AHEAD is requested
+    // before the MFMA of step s issues, and the scheduler is told not to move anything across a step.  With one wave per
+    // SIMD nothing else hides the ~130-cycle LDS latency; left to itself the compiler serialised load -> wait -> MFMA over
+    // the last third of the loop.
+    auto frag = [&](int s) {
+      const int t = s >> 3, kc = (s >> 1) & 3, i = s & 1, kh = t / 3, kw = t % 3;
+      return *reinterpret_cast<const c6_bf16x8*>(pb + ((i + kh) * C6_PW + kw) * C6_PS + kc * 16);
+    };
+    constexpr int AHEAD = OCC == 1 ? C6_AHEAD : 4;       // two waves per SIMD hide most of the latency themselves
+    c6_bf16x8 ring[AHEAD];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int kh = t / 3, kw = t % 3;
+    for (int s = 0; s < AHEAD; ++s) ring[s] = frag(s);
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const c6_bf16x8 fb = *reinterpret_cast<const c6_bf16x8*>(pb + ((i + kh) * C6_PW + kw) * C6_PS + kc * 16);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[t][kc], fb, acc[i], 0, 0, 0);
-        }
-      }
+    for (int s = 0; s < 72; ++s) {
+      const c6_bf16x8 fb = ring[s % AHEAD];
+      if (s + AHEAD < 72) ring[s % AHEAD] = frag(s + AHEAD);
+      acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s >> 3][(s >> 1) & 3], fb, acc[s & 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // acc[i][r]: oc = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, pixel = (row 2 wr + i, column p).  Re-lay as [pixel][oc].
@@ -242,8 +254,9 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_s2_k(const bf16_t* __rest
   float st1 = 0.f, st2 = 0.f;
   int tile = blockIdx.x;
   C6Tile tp = s2_tile(g, tile < g.ntiles ? tile : 0, S2_TH, S2_TW);
-  if (tile < g.ntiles) fetch(tp);
+  if (OCC == 1 && tile < g.ntiles) fetch(tp);
   for (; tile < g.ntiles; tile += gridDim.x) {
+    if (OCC != 1) fetch(tp);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < S2_NF; ++u) {
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_s2_k(const bf16_t* __rest
     C6Tile tn = tp;
     if (tile + (int)gridDim.x < g.ntiles) {
       tn = s2_tile(g, tile + gridDim.x, S2_TH, S2_TW);
-      fetch(tn);
+      if (OCC == 1) fetch(tn);
     }
     c6_f32x16 acc;
 #pragma unroll
@@ -351,8 +364,9 @@ __global__ __launch_bounds__(256, OCC) void conv64_dgrad_s2_k(const bf16_t* __re
   };
   int tile = blockIdx.x;
   C6Tile tp = s2_tile(g, tile < g.ntiles ? tile : 0, D2_TH, D2_TW);
-  if (tile < g.ntiles) fetch(tp);
+  if (OCC == 1 && tile < g.ntiles) fetch(tp);
   for (; tile < g.ntiles; tile += gridDim.x) {
+    if (OCC != 1) fetch(tp);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < D2_NF; ++u)
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(256, OCC) void conv64_dgrad_s2_k(const bf16_t* __re
     C6Tile tn = tp;
     if (tile + (int)gridDim.x < g.ntiles) {
       tn = s2_tile(g, tile + gridDim.x, D2_TH, D2_TW);
-      fetch(tn);
+      if (OCC == 1) fetch(tn);
     }
     // B fragment of dy pixel (row wr + dr, column p + dc)
     const bf16_t* pb = patch + (wr * D2_PW + p) * C6_PS + half * 8;
@@ -418,12 +432,15 @@ static bool s2_geom(int64_t B, int64_t H, int64_t W, int th, int tw, S2Geom* g) 
   return true;
 }
 
-// TSG_C64_OCC=1 (default): one block per CU with the whole register file — the 144 filter registers leave no room for
-// two waves per SIMD without spilling, and a kernel that touches scratch memory lost 60 % here (98 -> 162 us);
-// 2: two blocks per CU (spills)
+// TSG_C64_OCC=2 (default): two blocks per CU WITHOUT the register prefetch of the next patch — the 28-44 registers it
+// costs are what keeps two waves per SIMD from fitting next to the 144 filter registers, and a second block hides a
+// block's loads, staging, barriers and epilogue better than the prefetch hid its loads (tools/bench_conv64.py, us:
+// stride 1 at 256^2 105 -> 84 (0.92 PF), stride 2 at 512^2 forward 173 -> 144, data gradient 173 -> 155).
+// 1: one prefetching block per CU.  Either way no spills: with __launch_bounds__(256, 2) AND the prefetch the compiler
+// spilled ~35 registers to scratch and the stride-1 kernel took 162 us.
 static int c6_occ() {
-  static const int occ = [] { const char* e = getenv("TSG_C64_OCC"); return e ? atoi(e) : 1; }();
-  return occ == 2 ? 2 : 1;
+  static const int occ = [] { const char* e = getenv("TSG_C64_OCC"); return e ? atoi(e) : 2; }();
+  return occ == 1 ? 1 : 2;
 }
 
 static bool c6_geom(int64_t B, int64_t H, int64_t W, C6Geom* g) {
