@@ -266,24 +266,36 @@ int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int
 /* out[ci][kh][kw][oc] (bf16) = w[oc][2-kh][2-kw][ci] (fp32 or bf16, the channels_last filter layout): the filter with
  * which the DATA gradient of a stride-1 / padding-1 3x3 convolution is itself a forward convolution of dy — what
  * autograd's cuDNN backward-data call computes for resnet.py:24-29 — so that it can run on the (faster) forward kernels. */
+/* The same weight gradients when the convolution's input was relu(a x + b) of a tensor x that is still around — the
+ * BatchNorm + ReLU in front of it, which tsg_conv3x3_c64_*_fwd(in_ab) applied on load without storing the result: x is
+ * transformed the same way (same arithmetic and bf16 rounding as tsg_bn_apply_fwd) while its patch is staged.  in_ab:
+ * fp32 [2][Cin] = rows a, b of the BatchNorm forward pack. */
+int tsg_conv3x3_wrw_tr_norm(const void* x, const float* in_ab, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
+                            void* ws, size_t ws_bytes, void* stream);
+int tsg_conv3x3_wrw_gen_norm(const void* x, const float* in_ab, const void* dy, float* dw, int64_t B, int64_t Hin,
+                             int64_t Win, int Cin, int Cout, int stride, void* ws, size_t ws_bytes, void* stream);
+
 /* Forward of the 64 -> 64 channel 3x3 / stride 1 / padding 1 convolutions (ResNet-18 layer1, resnet.py:24-29,36-53) —
  * replaces the cuDNN forward call, and, fed dy and tsg_conv3x3_weight_rot180_t(w), the backward-data call.  x, y
  * [B,H,W,64] bf16 channels_last; w bf16 [oc][kh][kw][ci] (the channels_last filter layout); fp32 accumulation.
  * partial (may be NULL): [S][2][64] fp32 per-block sums / square sums of the bf16-rounded outputs, S =
  * tsg_conv3x3_c64_stats_partials(B, H, W) — the layout tsg_bn_finalize / tsg_bn_collapse take, so the BatchNorm that
- * follows does not re-read y for its statistics. */
+ * follows does not re-read y for its statistics.  in_ab (may be NULL): [2][64] fp32 = the a, b rows of a BatchNorm
+ * forward pack (tsg_bn_finalize): the convolution then reads relu(a x + b) of x — the BatchNorm + ReLU in front of it
+ * (seg_oprs.py:39-46, resnet.py:36-46) applied while the input patch is staged, bit-equal to what tsg_bn_apply_fwd
+ * would have written, without writing it; zero padding stays zero. */
 int tsg_conv3x3_c64_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
                               int groups);
 int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W);
-int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
-                        void* stream);
+int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, int64_t B,
+                        int64_t H, int64_t W, void* stream);
 /* The same for stride 2 (BiSeNet SpatialPath.conv_3x3_1 / conv_3x3_2, network.py:117-118): x [B,H,W,64] ->
  * y [B,OH,OW,64], OH = (H - 1) / 2 + 1; and its data gradient dx [B,H,W,64] from dy [B,OH,OW,64] and the transposed
  * filter wt = tsg_conv3x3_weight_rot180_t(w), evaluated per output parity (9 tap products per 2 x 2 block of dx, every
  * element written once, no atomics).  Both stream the large tensor once; fp32 accumulation, bf16 results. */
 int tsg_conv3x3_c64_s2_stats_partials(int64_t B, int64_t H, int64_t W);
-int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
-                           void* stream);
+int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, int64_t B,
+                           int64_t H, int64_t W, void* stream);
 int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B, int64_t H, int64_t W,
                              void* stream);
 

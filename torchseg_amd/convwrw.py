@@ -105,6 +105,95 @@ class WrwConv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class _BnReluConvFn(torch.autograd.Function):
+    """conv(relu(bn(x))) for the 64 -> 64 3x3 layers with the normalised activation never stored: the convolution
+    (tsg_conv3x3_c64_*_fwd) and its weight gradient (tsg_conv3x3_wrw_*_norm) apply a x + b, ReLU while they stage x; the
+    data gradient of the convolution feeds the ordinary SyncBN backward, which needs dy and x only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, use_batch_stats, group, hint, weight, wb, stride, wrt):
+        from . import syncbn as S
+        kp = K.provider()
+        layout, N, C, HW = K.bn_layout(x)
+        world = S._world(group) if use_batch_stats else 1
+        count_dev = None
+        g32 = gamma.float() if gamma is not None else None
+        b32 = beta.float() if beta is not None else None
+        if use_batch_stats:
+            invstd, fp, count_dev = S._batch_statistics(kp, x, layout, N, C, HW, bn, g32, b32, group, world, hint)
+        else:
+            mean = bn.running_mean.float()
+            invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+            fp = kp.bn_affine(mean, invstd, g32, b32)
+        y = kp.conv3x3_c64_fwd(x, wb, stride=stride, in_ab=fp)
+        ctx.save_for_backward(x, wb, gamma, beta, invstd, fp, count_dev)
+        ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype)
+        ctx.wrt = wrt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import syncbn as S
+        kp = K.provider()
+        x, wb, gamma, beta, invstd, fp, count_dev = ctx.saved_tensors
+        layout, N, C, HW, use_batch_stats, group, world, stride, wdtype = ctx.cfg
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dw = kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp)
+        rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
+        if stride == 2:
+            da = kp.conv3x3_c64_s2_dgrad(dy, rot, (x.shape[2], x.shape[3]))
+        else:
+            da = kp.conv3x3_c64_fwd(dy, rot)
+        partial, Sn = kp.bn_bwd_reduce(da, x, None, layout, N, C, HW, fp, True)
+        dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
+                                             world, x.device)
+        dx, _ = kp.bn_bwd_apply(da, x, None, layout, N, C, HW, bp, True, False)
+        if gamma is None:
+            dgamma = dbeta = None
+        else:
+            dgamma = dgamma.to(gamma.dtype)
+            dbeta = dbeta.to(beta.dtype) if beta is not None else None
+        return dx, dgamma, dbeta, None, None, None, None, dw.to(wdtype), None, None, None
+
+
+# TSG_BN_ON_LOAD=1|0 (default 1): BatchNorm + ReLU in front of a 64 -> 64 3x3 convolution applied while that convolution
+# (and its weight gradient) load their input, instead of as a pass of its own
+_BN_ON_LOAD = _os.environ.get("TSG_BN_ON_LOAD", "1") != "0"
+
+
+def bn_relu_conv(bn, relu, x, conv):
+    """`conv(relu(bn(x)))` — seg_oprs.py:39-46 followed by the next ConvBnRelu's convolution (bisenet network.py:117-118),
+    BasicBlock's bn1 -> relu -> conv2 (resnet.py:36-46).  One fused autograd node on HIP tensors when `bn` is our
+    SyncBatchNorm and `conv` one of the 64 -> 64 3x3 layers the conv64 kernels cover; the three modules otherwise."""
+    from .syncbn import SyncBatchNorm
+    from .furnace_glue import norm_act
+    if (_BN_ON_LOAD and _OWN_C64 and relu is not None and isinstance(bn, SyncBatchNorm) and isinstance(conv, WrwConv2d)
+            and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16
+            and x.shape[1] == 64 and conv.in_channels == 64 and conv.out_channels == 64 and conv.bias is None
+            and conv.weight.dtype == torch.float32 and conv.weight.requires_grad and torch.is_grad_enabled()
+            and bn.momentum is not None and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and conv.weight.is_contiguous(memory_format=torch.channels_last)
+            and K.provider().conv3x3_c64_supported(x, conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
+                                                   conv.groups)):
+        bn._check_input_dim(x)
+        use_batch_stats = bn.training or not bn.track_running_stats
+        hint = None
+        if use_batch_stats and hasattr(x, "_tsg_bn_partial"):
+            from .stemconv import take_bn_partial
+            hint = take_bn_partial(x)
+        with torch.autocast("cuda", enabled=False):
+            if _SHADOW:
+                from .shadow import bank
+                wb, wrt = bank.get(conv.weight, want_rot=True)
+            else:
+                wb, wrt = conv.weight.detach().to(torch.bfloat16), None
+            return _BnReluConvFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, hint, conv.weight,
+                                       wb, conv.stride[0], wrt)
+    return conv(norm_act(bn, relu, x))
+
+
 def _eligible(m):
     return (type(m) is nn.Conv2d and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.kernel_size == (3, 3)
             and m.stride in ((1, 1), (2, 2)) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None)

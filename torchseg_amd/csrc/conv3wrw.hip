@@ -174,8 +174,29 @@ constexpr int T3_DY = W3_TH * W3_TW * T3_RBE;       // elements of the dy tile
 constexpr int T3_XU = (T3_NPX * 8 + 255) / 256;     // 7 x chunks (16 B) per thread
 constexpr size_t T3_LDS = (size_t)(T3_DY + T3_NPX * T3_RBE) * sizeof(bf16_t);   // 63,744 B
 
+// Normalise-on-load (AFF): x is the input of a BatchNorm + ReLU whose output the convolution consumed (csrc/conv64.hip):
+// the x patch is transformed to relu(a x + b) — with tsg_bn_apply_fwd's arithmetic and rounding — while it is staged, so
+// the weight gradient sees the activation the forward convolution saw without that activation ever being stored.
+__device__ __forceinline__ uint4 w3_affine_relu(uint4 v, const float* __restrict__ ab, int part8) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  const float4 a0 = *reinterpret_cast<const float4*>(ab + part8), a1 = *reinterpret_cast<const float4*>(ab + part8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(ab + W3_C + part8), b1 = *reinterpret_cast<const float4*>(ab + W3_C + part8 + 4);
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+    const float y0 = fmaf(x0, a[2 * i], b[2 * i]), y1 = fmaf(x1, a[2 * i + 1], b[2 * i + 1]);
+    w[i] = pack2_bf16(y0 > 0.f ? y0 : 0.f, y1 > 0.f ? y1 : 0.f);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool AFF>
 __global__ __launch_bounds__(256) void conv3_wrw_tr_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                      float* __restrict__ part, W3Geom g) {
+                                                      float* __restrict__ part, W3Geom g, const float* __restrict__ in_ab) {
+  __shared__ __attribute__((aligned(16))) float abs_[AFF ? 2 * W3_C : 4];
+  if (AFF && threadIdx.x < 2 * W3_C) abs_[threadIdx.x] = in_ab[threadIdx.x];   // visible after the tile loop's first barrier
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   bf16_t* dyL = reinterpret_cast<bf16_t*>(lds);       // [128 pixels][T3_RBE]
   bf16_t* xL = dyL + T3_DY;                           // [204 pixels][T3_RBE]
@@ -231,10 +252,17 @@ __global__ __launch_bounds__(256) void conv3_wrw_tr_k(const bf16_t* __restrict__
 #pragma unroll
     for (int u = 0; u < W3_TH; ++u)
       *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = rd[u];
+    const int cur_ow0 = (tile % g.tiles_w) * W3_TW, cur_oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
 #pragma unroll
     for (int u = 0; u < T3_XU; ++u)
-      if (u < T3_XU - 1 || xr[u] >= 0)
-        *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = rx[u];
+      if (u < T3_XU - 1 || xr[u] >= 0) {
+        uint4 v = rx[u];
+        if (AFF) {
+          const int ih = cur_oh0 - 1 + xr[u], iw = cur_ow0 - 1 + xc[u];
+          if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v = w3_affine_relu(v, abs_, spart * 8);
+        }
+        *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = v;
+      }
     __syncthreads();
     if (tile + (int)gridDim.x < g.ntiles) fetch(tile + gridDim.x);       // in flight during the MFMAs
 #pragma unroll
@@ -291,10 +319,11 @@ template <int S> struct W3S {
 // PF = true: one block per CU, the next tile's operands are prefetched into registers while the MFMAs run.
 // PF = false: no register prefetch (the 44 registers it costs go), two blocks per CU that cover for each other's loads,
 // staging and barriers — with one block per CU the MFMA pipe idles ~2/3 of the time during those phases.
-template <int S, bool PF>
+template <int S, bool PF, bool AFF>
 __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                       float* __restrict__ part, W3GenGeom g) {
+                                                       float* __restrict__ part, W3GenGeom g, const float* __restrict__ in_ab) {
   typedef W3S<S> P;
+  __shared__ __attribute__((aligned(16))) float abs_[AFF ? 2 * W3_C : 4];
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   bf16_t* dyL = reinterpret_cast<bf16_t*>(lds);       // [128 pixels][T3_RBE]
   bf16_t* xL = dyL + T3_DY;                           // [P::NPX pixels][T3_RBE]
@@ -303,6 +332,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
   const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
   const int pair = blockIdx.x % g.npairs, slot = blockIdx.x / g.npairs;
   const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
+  if (AFF && tid < 2 * W3_C) abs_[tid] = in_ab[(tid >> 6) * g.Cin + ci0 + (tid & 63)];   // a / b rows of this ci tile
 
   const int spart = tid & 7, spix = tid >> 3;
   int xr[P::XU], xc[P::XU];
@@ -352,10 +382,17 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
 #pragma unroll
     for (int u = 0; u < W3_TH; ++u)
       *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = rd[u];
+    const int cur_ow0 = (tile % g.tiles_w) * W3_TW, cur_oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
 #pragma unroll
     for (int u = 0; u < P::XU; ++u)
-      if (u < P::XU - 1 || xr[u] >= 0)
-        *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = rx[u];
+      if (u < P::XU - 1 || xr[u] >= 0) {
+        uint4 v = rx[u];
+        if (AFF) {
+          const int ih = S * cur_oh0 - 1 + xr[u], iw = S * cur_ow0 - 1 + xc[u];
+          if (ih >= 0 && ih < g.Hin && iw >= 0 && iw < g.Win) v = w3_affine_relu(v, abs_, spart * 8);
+        }
+        *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = v;
+      }
     __syncthreads();
     if (PF && tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
 #pragma unroll
@@ -462,8 +499,9 @@ int tsg_conv3x3_wrw_supported(int dtype, int Cin, int Cout, int kh, int kw, int 
 size_t tsg_conv3x3_wrw_ws_bytes(void) { return (size_t)W3_NPART * W3_C * W3_N * sizeof(float); }
 
 static int conv3_wrw_common(int variant, const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
-                            void* ws, size_t ws_bytes, void* stream) {
+                            void* ws, size_t ws_bytes, void* stream, const float* in_ab = nullptr) {
   if (!x || !dy || !dw || !ws) return TSG_E_NULL;
+  if (in_ab && (variant != 1 || !aligned16(in_ab))) return in_ab && variant != 1 ? TSG_E_SHAPE : TSG_E_ALIGN;
   if (B <= 0 || H <= 0 || W <= 0) return TSG_E_SHAPE;
   const int64_t th = (H + W3_TH - 1) / W3_TH, tw = (W + W3_TW - 1) / W3_TW;
   if (B * th * tw > 0x7fffffffLL || H * W * W3_C > 0x7fffffffLL) return TSG_E_SHAPE;
@@ -475,11 +513,16 @@ static int conv3_wrw_common(int variant, const void* x, const void* dy, float* d
   TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)W3_LDS));
   const int grid = g.ntiles < W3_NPART ? g.ntiles : W3_NPART;
-  if (variant == 1) {
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_tr_k),
+  if (variant == 1 && in_ab) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_tr_k<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
-    hipLaunchKernelGGL(conv3_wrw_tr_k, dim3(grid), dim3(256), T3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       (float*)ws, g);
+    hipLaunchKernelGGL(conv3_wrw_tr_k<true>, dim3(grid), dim3(256), T3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (float*)ws, g, in_ab);
+  } else if (variant == 1) {
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_tr_k<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
+    hipLaunchKernelGGL(conv3_wrw_tr_k<false>, dim3(grid), dim3(256), T3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (float*)ws, g, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL(conv3_wrw_k, dim3(grid), dim3(256), W3_LDS, st, (const bf16_t*)x, (const bf16_t*)dy, (float*)ws,
                        g);
@@ -499,6 +542,12 @@ int tsg_conv3x3_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t
 int tsg_conv3x3_wrw_tr(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W, void* ws,
                        size_t ws_bytes, void* stream) {
   return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream);
+}
+
+int tsg_conv3x3_wrw_tr_norm(const void* x, const float* in_ab, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!in_ab) return TSG_E_NULL;
+  return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream, in_ab);
 }
 
 // TSG_CONV_WRW_OCC=2 (default) | 1: stride-1 layers with >= 1024 pixel tiles run the two-blocks-per-CU variant of the
@@ -542,35 +591,42 @@ size_t tsg_conv3x3_wrw_gen_ws_bytes(int64_t B, int64_t Hin, int64_t Win, int Cin
   return (size_t)g.npairs * g.bpp * W3_C * W3_N * sizeof(float);
 }
 
-int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout,
-                        int stride, void* ws, size_t ws_bytes, void* stream) {
+static int conv3_wrw_gen_common(const void* x, const float* in_ab, const void* dy, float* dw, int64_t B, int64_t Hin,
+                                int64_t Win, int Cin, int Cout, int stride, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dw || !ws) return TSG_E_NULL;
+  if (in_ab && !aligned16(in_ab)) return TSG_E_ALIGN;
   W3GenGeom g;
   int e = w3gen_geom(&g, B, Hin, Win, Cin, Cout, stride);
   if (e) return e;
   if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, Hin, Win, Cin, Cout, stride)) return TSG_E_WS;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 1 && w3_occ2(g.ntiles)) {
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<1, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<1>::LDS));
-    hipLaunchKernelGGL((conv3_wrw_gen_k<1, false>), dim3(g.npairs * g.bpp), dim3(256), W3S<1>::LDS, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, (float*)ws, g);
-  } else if (stride == 1) {
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<1, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<1>::LDS));
-    hipLaunchKernelGGL((conv3_wrw_gen_k<1, true>), dim3(g.npairs * g.bpp), dim3(256), W3S<1>::LDS, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, (float*)ws, g);
-  } else {
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<2>::LDS));
-    hipLaunchKernelGGL((conv3_wrw_gen_k<2, true>), dim3(g.npairs * g.bpp), dim3(256), W3S<2>::LDS, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, (float*)ws, g);
-  }
+#define W3_GO(SS, PFF, AF)                                                                                        \
+  do {                                                                                                            \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<SS>::LDS));                  \
+    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,       \
+                       (const bf16_t*)x, (const bf16_t*)dy, (float*)ws, g, in_ab);                                \
+  } while (0)
+  if (stride == 1 && w3_occ2(g.ntiles)) { if (in_ab) W3_GO(1, false, true); else W3_GO(1, false, false); }
+  else if (stride == 1) { if (in_ab) W3_GO(1, true, true); else W3_GO(1, true, false); }
+  else { if (in_ab) W3_GO(2, true, true); else W3_GO(2, true, false); }
+#undef W3_GO
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
   TSG_CHECK_LAUNCH();
   return 0;
+}
+
+int tsg_conv3x3_wrw_gen(const void* x, const void* dy, float* dw, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout,
+                        int stride, void* ws, size_t ws_bytes, void* stream) {
+  return conv3_wrw_gen_common(x, nullptr, dy, dw, B, Hin, Win, Cin, Cout, stride, ws, ws_bytes, stream);
+}
+
+int tsg_conv3x3_wrw_gen_norm(const void* x, const float* in_ab, const void* dy, float* dw, int64_t B, int64_t Hin,
+                             int64_t Win, int Cin, int Cout, int stride, void* ws, size_t ws_bytes, void* stream) {
+  if (!in_ab) return TSG_E_NULL;
+  return conv3_wrw_gen_common(x, in_ab, dy, dw, B, Hin, Win, Cin, Cout, stride, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

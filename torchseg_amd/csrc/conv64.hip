@@ -68,14 +68,36 @@ __device__ __forceinline__ void c6_fetch(const bf16_t* __restrict__ x, const C6G
   }
 }
 
+// Normalise-on-load (AFF): the input of the convolution is relu(a x + b) of the tensor that is read — the BatchNorm + ReLU
+// that precedes these convolutions in the spatial path and inside a BasicBlock (seg_oprs.py:39-46, resnet.py:36-46) —
+// applied while the patch is written to LDS, with the values tsg_bn_apply_fwd would have stored (same fma, same
+// rounding to bf16), so the normalised activation is never written or re-read.  Padding pixels stay exactly zero.
+__device__ __forceinline__ uint4 c6_affine_relu(uint4 v, const float* __restrict__ ab, int part8) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  const float4 a0 = *reinterpret_cast<const float4*>(ab + part8), a1 = *reinterpret_cast<const float4*>(ab + part8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(ab + C6_C + part8), b1 = *reinterpret_cast<const float4*>(ab + C6_C + part8 + 4);
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+    const float y0 = fmaf(x0, a[2 * i], b[2 * i]), y1 = fmaf(x1, a[2 * i + 1], b[2 * i + 1]);
+    w[i] = pack2_bf16(y0 > 0.f ? y0 : 0.f, y1 > 0.f ? y1 : 0.f);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // 4 waves: wave = (row pair wr) * 2 + (oc half wm)
-template <bool STATS, int OCC>
+template <bool STATS, int OCC, bool AFF>
 __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                    bf16_t* __restrict__ y, C6Geom g, float* __restrict__ partial) {
+                                                    bf16_t* __restrict__ y, C6Geom g, float* __restrict__ partial,
+                                                    const float* __restrict__ in_ab) {
   __shared__ __attribute__((aligned(16))) bf16_t patch[C6_PH * C6_PW * C6_PS];     // 29376 B
   __shared__ __attribute__((aligned(16))) bf16_t outs[C6_TH * C6_TW * C6_PS];      // 18432 B: [pixel][64 oc + 8 pad]
+  __shared__ __attribute__((aligned(16))) float abs_[AFF ? 2 * C6_C : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int wm = wave & 1, wr = wave >> 1;
+  if (AFF && tid < 2 * C6_C) abs_[tid] = in_ab[tid];      // visible after the first barrier of the tile loop
 
   c6_bf16x8 fw[9][4];                                    // filter fragments: oc = 32 wm + p, ci = 16 kc + 8 half ..
 #pragma unroll
@@ -101,8 +123,14 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
     __syncthreads();                                     // the previous tile's reads of patch / outs are done
 #pragma unroll
     for (int u = 0; u < C6_NF; ++u)
-      if (u < C6_NF - 1 || ln.rc[u] >= 0)
-        *reinterpret_cast<uint4*>(patch + ((tid + 256 * u) >> 3) * C6_PS + part8) = rp[u];
+      if (u < C6_NF - 1 || ln.rc[u] >= 0) {
+        uint4 v = rp[u];
+        if (AFF) {
+          const int ih = tp.oh0 - 1 + (ln.rc[u] & 0xff), iw = tp.ow0 - 1 + (ln.rc[u] >> 8);
+          if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v = c6_affine_relu(v, abs_, part8);
+        }
+        *reinterpret_cast<uint4*>(patch + ((tid + 256 * u) >> 3) * C6_PS + part8) = v;
+      }
     __syncthreads();
     C6Tile tn = tp;
     if (tile + (int)gridDim.x < g.ntiles) {              // in flight during the MFMAs below
@@ -224,13 +252,16 @@ struct S2Lane {
   }
 };
 
-template <bool STATS, int OCC>
+template <bool STATS, int OCC, bool AFF>
 __global__ __launch_bounds__(256, OCC) void conv64_fwd_s2_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                          bf16_t* __restrict__ y, S2Geom g, float* __restrict__ partial) {
+                                                          bf16_t* __restrict__ y, S2Geom g, float* __restrict__ partial,
+                                                          const float* __restrict__ in_ab) {
   __shared__ __attribute__((aligned(16))) bf16_t patch[S2_PH * S2_PW * C6_PS];     // 46800 B
   __shared__ __attribute__((aligned(16))) bf16_t outs[S2_TH * S2_TW * C6_PS];      // 9216 B
+  __shared__ __attribute__((aligned(16))) float abs_[AFF ? 2 * C6_C : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int wm = wave & 1, wr = wave >> 1;
+  if (AFF && tid < 2 * C6_C) abs_[tid] = in_ab[tid];
   c6_bf16x8 fw[9][4];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -256,6 +287,37 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_s2_k(const bf16_t* __rest
   C6Tile tp = s2_tile(g, tile < g.ntiles ? tile : 0, S2_TH, S2_TW);
   if (OCC == 1 && tile < g.ntiles) fetch(tp);
   for (; tile < g.ntiles; tile += gridDim.x) {
+    if (AFF) {
+      // normalise-on-load variant: the patch is loaded, transformed and written four vectors at a time (all eleven in
+      // registers next to the transform's temporaries would spill)
+      __syncthreads();
+      const bf16_t* xb = x + (int64_t)tp.b * g.H * g.W * C6_C + part8;
+#pragma unroll
+      for (int u0 = 0; u0 < S2_NF; u0 += 4) {
+        uint4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = u0 + k < S2_NF ? u0 + k : S2_NF - 1;
+          const int ih = 2 * tp.oh0 - 1 + (ln.rc[u] & 0xff), iw = 2 * tp.ow0 - 1 + (ln.rc[u] >> 8);
+          ok[k] = u0 + k < S2_NF && ln.rc[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+          v[k] = make_uint4(0u, 0u, 0u, 0u);
+          if (ok[k]) v[k] = *reinterpret_cast<const uint4*>(xb + ((int64_t)ih * g.W + iw) * C6_C);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = u0 + k;
+          if (u < S2_NF && (u < S2_NF - 1 || ln.rc[u] >= 0)) {
+            const int pr = ln.rc[u] & 0xff, pc = ln.rc[u] >> 8;
+            const int pix = pr * S2_PW + ((pc & 1) ? S2_NE + (pc >> 1) : (pc >> 1));
+            if (ok[k]) v[k] = c6_affine_relu(v[k], abs_, part8);
+            *reinterpret_cast<uint4*>(patch + pix * C6_PS + part8) = v[k];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    } else {
     if (OCC != 1) fetch(tp);
     __syncthreads();
 #pragma unroll
@@ -267,6 +329,7 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_s2_k(const bf16_t* __rest
       }
     }
     __syncthreads();
+    }
     C6Tile tn = tp;
     if (tile + (int)gridDim.x < g.ntiles) {
       tn = s2_tile(g, tile + gridDim.x, S2_TH, S2_TW);
@@ -469,20 +532,21 @@ int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W) {
   return g.ntiles < 256 * c6_occ() ? g.ntiles : 256 * c6_occ();
 }
 
-int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
-                        void* stream) {
+int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, int64_t B, int64_t H,
+                        int64_t W, void* stream) {
   if (!x || !w || !y) return TSG_E_NULL;
+  if (in_ab && !aligned16(in_ab)) return TSG_E_ALIGN;
   C6Geom g;
   if (!c6_geom(B, H, W, &g)) return TSG_E_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  const int occ = c6_occ();
-  const int per_cu = occ == 1 ? 1 : 2;
-  const int grid = g.ntiles < 256 * per_cu ? g.ntiles : 256 * per_cu;
-#define C6_GO(ST, OC) hipLaunchKernelGGL((conv64_fwd_k<ST, OC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
-                                         (const bf16_t*)w, (bf16_t*)y, g, partial)
-  if (partial) { if (occ == 1) C6_GO(true, 1); else C6_GO(true, 2); }
-  else { if (occ == 1) C6_GO(false, 1); else C6_GO(false, 2); }
+  const int occ = c6_occ();                              // also fixes the number of statistics partials
+  const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
+#define C6_GO(ST, OC, AF) hipLaunchKernelGGL((conv64_fwd_k<ST, OC, AF>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
+                                             (const bf16_t*)w, (bf16_t*)y, g, partial, in_ab)
+  if (in_ab) { if (partial) C6_GO(true, 2, true); else C6_GO(false, 2, true); }
+  else if (partial) { if (occ == 1) C6_GO(true, 1, false); else C6_GO(true, 2, false); }
+  else { if (occ == 1) C6_GO(false, 1, false); else C6_GO(false, 2, false); }
 #undef C6_GO
   TSG_CHECK_LAUNCH();
   return 0;
@@ -494,19 +558,21 @@ int tsg_conv3x3_c64_s2_stats_partials(int64_t B, int64_t H, int64_t W) {
   return g.ntiles < 256 * c6_occ() ? g.ntiles : 256 * c6_occ();
 }
 
-int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial, int64_t B, int64_t H, int64_t W,
-                           void* stream) {
+int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, int64_t B,
+                           int64_t H, int64_t W, void* stream) {
   if (!x || !w || !y) return TSG_E_NULL;
+  if (in_ab && !aligned16(in_ab)) return TSG_E_ALIGN;
   S2Geom g;
   if (!s2_geom(B, H, W, S2_TH, S2_TW, &g)) return TSG_E_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int occ = c6_occ();
   const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
-#define C6_GO(ST, OC) hipLaunchKernelGGL((conv64_fwd_s2_k<ST, OC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
-                                         (const bf16_t*)w, (bf16_t*)y, g, partial)
-  if (partial) { if (occ == 1) C6_GO(true, 1); else C6_GO(true, 2); }
-  else { if (occ == 1) C6_GO(false, 1); else C6_GO(false, 2); }
+#define C6_GO(ST, OC, AF) hipLaunchKernelGGL((conv64_fwd_s2_k<ST, OC, AF>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
+                                             (const bf16_t*)w, (bf16_t*)y, g, partial, in_ab)
+  if (in_ab) { if (partial) C6_GO(true, 2, true); else C6_GO(false, 2, true); }
+  else if (partial) { if (occ == 1) C6_GO(true, 1, false); else C6_GO(true, 2, false); }
+  else { if (occ == 1) C6_GO(false, 1, false); else C6_GO(false, 2, false); }
 #undef C6_GO
   TSG_CHECK_LAUNCH();
   return 0;

@@ -47,8 +47,12 @@ class BasicBlock(_Block):
         self.inplace = inplace
 
     def forward(self, x):
-        out = norm_act(self.bn1, self.relu, self.conv1(x))
-        return norm_act(self.bn2, self.relu_inplace, self.conv2(out), residual=self._identity(x))
+        if x.is_cuda:                                   # bn1 + relu applied while conv2 loads its input, where covered
+            from torchseg_amd.convwrw import bn_relu_conv
+            out = bn_relu_conv(self.bn1, self.relu, self.conv1(x), self.conv2)
+        else:
+            out = self.conv2(norm_act(self.bn1, self.relu, self.conv1(x)))
+        return norm_act(self.bn2, self.relu_inplace, out, residual=self._identity(x))
 
 
 class Bottleneck(_Block):
@@ -116,8 +120,12 @@ class ResNet(nn.Module):
     def _stem(self, x):
         if isinstance(self.conv1, nn.Sequential):
             c = self.conv1
-            x = norm_act(c[1], c[2], c[0](x))
-            x = norm_act(c[4], c[5], c[3](x))
+            if x.is_cuda:
+                from torchseg_amd.convwrw import bn_relu_conv
+                x = bn_relu_conv(c[1], c[2], c[0](x), c[3])
+            else:
+                x = c[3](norm_act(c[1], c[2], c[0](x)))
+            x = norm_act(c[4], c[5], x)
             x = c[6](x)
         else:
             x = self.conv1(x)

@@ -50,6 +50,26 @@ class _ConvNormAct(nn.Module):
         return relu(x) if relu is not None else x
 
 
+def cbr_chain(mods, x):
+    """`mods[-1](... mods[1](mods[0](x)))` for consecutive ConvBnRelu modules (bisenet network.py:133-137, SpatialPath).
+    Between two of them the BatchNorm + ReLU of the first is handed to the convolution of the second
+    (torchseg_amd.convwrw.bn_relu_conv: applied while that convolution loads its input when both are on the HIP path, the
+    plain module sequence otherwise); results are those of calling the modules one after the other."""
+    if not (x.is_cuda and all(isinstance(m, ConvBnRelu) and m.has_bn and m.has_relu for m in mods[:-1])):
+        for m in mods:
+            x = m(x)
+        return x
+    from torchseg_amd.convwrw import bn_relu_conv
+    x = mods[0].conv(x)
+    for prev, m in zip(mods[:-1], mods[1:]):
+        x = bn_relu_conv(prev.bn, prev.relu, x, m.conv)
+    last = mods[-1]
+    relu = last.relu if last.has_relu else None
+    if last.has_bn:
+        return norm_act(last.bn, relu, x)
+    return relu(x) if relu is not None else x
+
+
 class ConvBnRelu(_ConvNormAct):
     def __init__(self, in_planes, out_planes, ksize, stride, pad, dilation=1, groups=1, has_bn=True,
                  norm_layer=nn.BatchNorm2d, bn_eps=1e-5, has_relu=True, inplace=True, has_bias=False):

@@ -544,9 +544,12 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_c64_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                        weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1):
+    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1, in_ab=None):
         """x [B,64,H,W] bf16 channels_last, wb bf16 [64,64,3,3] channels_last, 3x3 / stride 1 or 2 / padding 1
-        -> y (channels_last) or (y, partial [S,2,64])"""
+        -> y (channels_last) or (y, partial [S,2,64]).  in_ab: fp32 [>=2, 64] whose rows 0 / 1 are the a / b of a BN forward
+        pack: the convolution reads relu(a x + b) (normalise-on-load)."""
+        if in_ab is not None and (in_ab.dtype != torch.float32 or not in_ab.is_contiguous() or in_ab.shape[-1] != 64):
+            raise ValueError("conv3x3_c64_fwd: in_ab must be a contiguous fp32 [>=2, 64] pack")
         if not x.is_contiguous(memory_format=torch.channels_last) or not wb.is_contiguous(memory_format=torch.channels_last):
             raise ValueError("conv3x3_c64_fwd expects channels_last operands")
         B, _, H, W = x.shape
@@ -562,7 +565,7 @@ class HipKernels:
         if with_stats:
             S = self._count(("c64_stats", stride, B, H, W), lambda: cnt(B, H, W), what)
             partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
-        L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), B, H, W, L.stream_ptr(x)), what)
+        L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), B, H, W, L.stream_ptr(x)), what)
         return (y, partial) if with_stats else y
 
     def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw):
@@ -584,13 +587,18 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_wrw_gen_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                            weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_wrw(self, x, dy, variant=None, stride=1):
+    def conv3x3_wrw(self, x, dy, variant=None, stride=1, in_ab=None):
         """x [B,Cin,Hin,Win], dy [B,Cout,OH,OW] bf16 channels_last (Cin, Cout multiples of 64; 3x3, padding 1, stride 1 or
         2) -> dw fp32 [Cout,Cin,3,3] channels_last.  64 -> 64 / stride 1 takes the single-pair kernel (variant "tr", or
         "v1" = the transposed-staging kernel, TSG_CONV_WRW_IMPL); everything else the pair-tiled kernel ("gen"; also
         selectable for 64 -> 64 with variant="gen")."""
         if variant is None:
             variant = os.environ.get("TSG_CONV_WRW_IMPL", "tr")
+        if in_ab is not None:                 # normalise-on-load: x is the input of the BN + ReLU in front of the convolution
+            if in_ab.dtype != torch.float32 or not in_ab.is_contiguous() or in_ab.shape[-1] != x.shape[1]:
+                raise ValueError("conv3x3_wrw: in_ab must be a contiguous fp32 [>=2, Cin] pack")
+            if variant == "v1":
+                variant = "tr"
         for t in (x, dy):
             if not t.is_contiguous(memory_format=torch.channels_last) or t.dtype != torch.bfloat16:
                 raise ValueError("conv3x3_wrw expects bf16 channels_last tensors")
@@ -604,8 +612,12 @@ class HipKernels:
             ws = getattr(self, "_c3_ws", None)
             if ws is None or ws.device != x.device:
                 ws = self._c3_ws = torch.empty(self.lib.tsg_conv3x3_wrw_ws_bytes(), dtype=torch.uint8, device=x.device)
-            L.check(fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
-                    "tsg_conv3x3_wrw")
+            if in_ab is not None:
+                L.check(self.lib.tsg_conv3x3_wrw_tr_norm(x.data_ptr(), in_ab.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W,
+                                                         ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_tr_norm")
+            else:
+                L.check(fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
+                        "tsg_conv3x3_wrw")
             return dw
         wsb = self.lib.tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout, stride)
         if wsb == 0:
@@ -613,8 +625,13 @@ class HipKernels:
         ws = getattr(self, "_c3g_ws", None)                       # one buffer, grown to the largest layer (<= 38 MB)
         if ws is None or ws.device != x.device or ws.numel() < wsb:
             ws = self._c3g_ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-        L.check(self.lib.tsg_conv3x3_wrw_gen(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, int(stride),
-                                             ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_gen")
+        if in_ab is not None:
+            L.check(self.lib.tsg_conv3x3_wrw_gen_norm(x.data_ptr(), in_ab.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin,
+                                                      Cout, int(stride), ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
+                    "tsg_conv3x3_wrw_gen_norm")
+        else:
+            L.check(self.lib.tsg_conv3x3_wrw_gen(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, int(stride),
+                                                 ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_gen")
         return dw
 
     def conv3x3_weight_rot180_t(self, w):

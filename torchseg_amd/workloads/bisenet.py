@@ -14,7 +14,7 @@ from . import add_then_upsample, ensure_furnace_on_path, upsample_logits
 
 ensure_furnace_on_path()
 from base_model import resnet18  # noqa: E402
-from seg_opr.seg_oprs import AttentionRefinement, ConvBnRelu, FeatureFusion  # noqa: E402
+from seg_opr.seg_oprs import AttentionRefinement, ConvBnRelu, FeatureFusion, cbr_chain  # noqa: E402
 
 
 def _cbr(cin, cout, k, s, p, norm_layer, relu=True):
@@ -37,7 +37,7 @@ class SpatialPath(nn.Module):
         self.conv_1x1 = _cbr(mid, out_planes, 1, 1, 0, norm_layer)
 
     def forward(self, x):
-        return self.conv_1x1(self.conv_3x3_2(self.conv_3x3_1(self.conv_7x7(x))))
+        return cbr_chain([self.conv_7x7, self.conv_3x3_1, self.conv_3x3_2, self.conv_1x1], x)
 
 
 class BiSeNetHead(nn.Module):
