@@ -193,3 +193,22 @@ def test_iadd_interpolate_pattern_is_fused_under_the_ddp_wrapper(cuda):
     assert abs(l.item() - lr.item()) <= 1e-5 * max(1.0, abs(lr.item()))
     for (n, p), (_, q) in zip(net.module.named_parameters(), ref.named_parameters()):
         torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-6, msg=n)
+
+
+def test_override_leaves_uncovered_cases_to_aten(cuda):
+    """The aten override is process-wide: bilinear resizes our kernels do not cover (align_corners=False, fp16 / fp64) must
+    keep working for unrelated code in the process, forward and backward."""
+    import torch.nn.functional as F
+    from torchseg_amd.upsample import install_aten_overrides
+    install_aten_overrides()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 5, 7, generator=g)
+    for dtype, ac, tol in ((torch.float32, False, 1e-5), (torch.float64, True, 1e-12), (torch.float16, True, 2e-2)):
+        xr = x.to(dtype).requires_grad_(True)
+        ref = F.interpolate(xr, size=(11, 13), mode="bilinear", align_corners=ac)
+        ref.sum().backward()
+        xg = x.to(cuda).to(dtype).requires_grad_(True)
+        out = F.interpolate(xg, size=(11, 13), mode="bilinear", align_corners=ac)
+        (out * 1.0).sum().backward()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=tol, atol=tol)
+        torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=tol, atol=tol)

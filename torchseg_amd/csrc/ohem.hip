@@ -528,6 +528,8 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 constexpr float kNegBig = -1.0e30f;
 
+typedef __attribute__((ext_vector_type(2))) float up_f2;
+
 struct UpFwdGeom { int C, IH, IW, OH, OW; float sy, sx; int WR, WC, xblocks, bands, hist_words; };
 
 __device__ __forceinline__ void src_index0(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(kT) void ohem_up_fwd_k(
     int x0, x1; float lx;
     src_index0(g.sx, ox, IW, x0, x1, lx);
     const int xl0 = x0 - xs_lo, xl1 = x1 - xs_lo;
-    float H0[CP], D[CP];
+    up_f2 H0[CP / 2], D[CP / 2];                       // class pairs: the lerp / subtract / sum chain runs on v_pk_* (two classes per instruction)
     int cy0 = -1, ro0 = 0, ro1 = 0;
     for (int oy = oy_beg; oy < oy_end; ++oy) {
       int y0, y1; float ly;
@@ -606,17 +608,26 @@ __global__ __launch_bounds__(kT) void ohem_up_fwd_k(
           const float* zr = Zw + c * WR * WC;
           const float a0 = zr[ro0 + xl0], a1 = zr[ro0 + xl1], b0 = zr[ro1 + xl0], b1 = zr[ro1 + xl1];
           const float h0 = __builtin_fmaf(lx, a1 - a0, a0), h1 = __builtin_fmaf(lx, b1 - b0, b0);
-          H0[c] = h0; D[c] = h1 - h0;
+          if (c & 1) { H0[c >> 1].y = h0; D[c >> 1].y = h1 - h0; } else { H0[c >> 1].x = h0; D[c >> 1].x = h1 - h0; }
         }
         cy0 = y0;
       }
-      float v[CP];
+      up_f2 v[CP / 2];
+      const up_f2 ly2 = {ly, ly};
       float m = kNegBig;
 #pragma unroll
-      for (int c = 0; c < CP; ++c) { v[c] = __builtin_fmaf(ly, D[c], H0[c]); m = fmaxf(m, v[c]); }
-      float ssum = 0.f;
+      for (int c = 0; c < CP / 2; ++c) {
+        v[c] = __builtin_elementwise_fma(ly2, D[c], H0[c]);
+        m = fmaxf(m, fmaxf(v[c].x, v[c].y));
+      }
+      const up_f2 m2 = {m, m};
+      up_f2 s2 = {0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < CP; ++c) ssum += __builtin_amdgcn_exp2f(v[c] - m);
+      for (int c = 0; c < CP / 2; ++c) {
+        const up_f2 d = v[c] - m2;
+        s2 += up_f2{__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+      }
+      const float ssum = s2.x + s2.y;
       const float l2 = m + __builtin_amdgcn_logf(ssum);
       const int lab = lab_s[(oy - oy_beg) * kT + tid];
       const bool valid = lab != 255;
@@ -693,17 +704,22 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
     oy_lo = l < 0 ? 0 : l;
     oy_hi = h > OH - 1 ? OH - 1 : h;
   }
-  float H0[CP], D[CP], accA[CP], accB[CP];
+  // class pairs in even-aligned register pairs: the per-pixel chain (lerp, subtract lse, subtract one-hot, two
+  // accumulations) runs on v_pk_fma_f32 / v_pk_add_f32, two classes per instruction; only the exp2 stays scalar
+  up_f2 H0[CP / 2], D[CP / 2], accA[CP / 2], accB[CP / 2];
 #pragma unroll
-  for (int c = 0; c < CP; ++c) { accA[c] = 0.f; accB[c] = 0.f; H0[c] = 0.f; D[c] = 0.f; }
+  for (int c = 0; c < CP / 2; ++c) { accA[c] = up_f2{0.f, 0.f}; accB[c] = up_f2{0.f, 0.f}; H0[c] = up_f2{0.f, 0.f}; D[c] = up_f2{0.f, 0.f}; }
   int cur = -2;                                       // source row accA belongs to (accB: cur + 1)
   int staged0 = -1, staged1 = -1;                     // source rows held by the two ring slots
 
-  auto flush = [&](int row, const float (&a)[CP]) {   // block-uniform
+  auto flush = [&](int row, const up_f2 (&a)[CP / 2]) {   // block-uniform
     if (row < r0 || row >= r1) return;
     __syncthreads();                                  // the previous horizontal pass has read Vs
 #pragma unroll
-    for (int c = 0; c < CP; ++c) Vs[tid * VP + c] = live ? a[c] : 0.f;
+    for (int c = 0; c < CP / 2; ++c) {
+      Vs[tid * VP + 2 * c] = live ? a[c].x : 0.f;
+      Vs[tid * VP + 2 * c + 1] = live ? a[c].y : 0.f;
+    }
     __syncthreads();
     const int nS = s1 - s0;
     for (int idx = tid; idx < C * nS; idx += NT) {
@@ -748,11 +764,11 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
         flush(cur, accA);
         if (y0 == cur + 1) {
 #pragma unroll
-          for (int c = 0; c < CP; ++c) { accA[c] = accB[c]; accB[c] = 0.f; }
+          for (int c = 0; c < CP / 2; ++c) { accA[c] = accB[c]; accB[c] = up_f2{0.f, 0.f}; }
         } else {
           flush(cur + 1, accB);
 #pragma unroll
-          for (int c = 0; c < CP; ++c) { accA[c] = 0.f; accB[c] = 0.f; }
+          for (int c = 0; c < CP / 2; ++c) { accA[c] = up_f2{0.f, 0.f}; accB[c] = up_f2{0.f, 0.f}; }
         }
       }
       __syncthreads();                                // everybody has built H0 / D from the rows about to be replaced
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
       for (int c = 0; c < CP; ++c) {
         const float a0 = za[c * XS + xl0], a1 = za[c * XS + xl1], b0 = zc[c * XS + xl0], b1 = zc[c * XS + xl1];
         const float h0 = __builtin_fmaf(lx, a1 - a0, a0), h1 = __builtin_fmaf(lx, b1 - b0, b0);
-        H0[c] = h0; D[c] = h1 - h0;
+        if (c & 1) { H0[c >> 1].y = h0; D[c >> 1].y = h1 - h0; } else { H0[c >> 1].x = h0; D[c >> 1].x = h1 - h0; }
       }
       cur = y0;
     }
@@ -778,16 +794,18 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
     const float l2 = sd.ls * kLog2e;
     const float ca = coef - ly * coef, cb = ly * coef;
     const float4* ohr = reinterpret_cast<const float4*>(oh + t * CP);
+    const up_f2 ly2 = {ly, ly}, l22 = {l2, l2}, ca2 = {ca, ca}, cb2 = {cb, cb};
 #pragma unroll
     for (int c4 = 0; c4 < CP / 4; ++c4) {
       const float4 o = ohr[c4];
-      const float ov[4] = {o.x, o.y, o.z, o.w};
+      const up_f2 ov[2] = {up_f2{o.x, o.y}, up_f2{o.z, o.w}};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = c4 * 4 + k;
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ly, D[c], H0[c]) - l2) - ov[k];
-        accA[c] = __builtin_fmaf(ca, e, accA[c]);
-        accB[c] = __builtin_fmaf(cb, e, accB[c]);
+      for (int k = 0; k < 2; ++k) {
+        const int c = c4 * 2 + k;
+        const up_f2 v = __builtin_elementwise_fma(ly2, D[c], H0[c]) - l22;
+        const up_f2 e = up_f2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)} - ov[k];
+        accA[c] = __builtin_elementwise_fma(ca2, e, accA[c]);
+        accB[c] = __builtin_elementwise_fma(cb2, e, accB[c]);
       }
     }
   }

@@ -92,7 +92,7 @@ def install_aten_overrides():
     """Route aten::upsample_bilinear2d{,_backward} on HIP tensors to libtsg_hip.
 
     Idempotent.  Only align_corners=True float32/bfloat16 4-D inputs are on the
-    reference's path; anything else raises instead of silently using ATen.
+    reference's path and on our kernels; anything else is computed by ATen's decomposition of the operator.
     """
     global _lib_handle
     if _lib_handle is not None:
@@ -100,14 +100,48 @@ def install_aten_overrides():
     import warnings
     lib = torch.library.Library("aten", "IMPL")
 
+    # What the HIP kernels do not cover (align_corners=False, fp16 / fp64: nothing on the reference's path, but the
+    # override is process-wide and evaluation / visualisation code shares the process) runs ATen's own decomposition of
+    # the operator into index / lerp ops on the same device instead of raising.
+    from torch._decomp import decompositions as _dec
+
+    def _ours(t, align_corners):
+        return bool(align_corners) and t.dim() == 4 and t.dtype in (torch.float32, torch.bfloat16)
+
     def fwd(x, output_size, align_corners, scales_h=None, scales_w=None):
-        if not align_corners:
-            raise NotImplementedError("torchseg_amd overrides upsample_bilinear2d for align_corners=True only")
+        if not _ours(x, align_corners):
+            return _dec.upsample_bilinear2d(x, output_size, align_corners, scales_h, scales_w)
         return _forward_any_layout(x, None, int(output_size[0]), int(output_size[1]))
 
+    def _taps(out_size, in_size, align_corners, scale, device, dtype):
+        # source index / weight of every output index, as at::native::area_pixel_compute_source_index
+        dst = torch.arange(out_size, device=device, dtype=dtype)
+        if align_corners:
+            src = dst * ((in_size - 1) / (out_size - 1) if out_size > 1 else 0.0)
+        else:
+            s = (1.0 / scale) if (scale is not None and scale > 0) else in_size / out_size
+            src = ((dst + 0.5) * s - 0.5).clamp_(min=0.0)
+        i0 = src.floor().clamp_(max=in_size - 1)
+        l1 = src - i0
+        i0 = i0.long()
+        i1 = (i0 + 1).clamp_(max=in_size - 1)
+        return i0, i1, l1
+
     def bwd(grad_output, output_size, input_size, align_corners, scales_h=None, scales_w=None):
-        if not align_corners:
-            raise NotImplementedError("torchseg_amd overrides upsample_bilinear2d for align_corners=True only")
+        if not _ours(grad_output, align_corners):
+            # the adjoint of the separable interpolation, written out (autograd is not available below the dispatcher)
+            N, Cc, IH, IW = (int(v) for v in input_size)
+            acc = torch.float64 if grad_output.dtype == torch.float64 else torch.float32
+            g = grad_output.to(acc)
+            y0, y1, ly = _taps(int(output_size[0]), IH, align_corners, scales_h, g.device, acc)
+            x0, x1, lx = _taps(int(output_size[1]), IW, align_corners, scales_w, g.device, acc)
+            rows = torch.zeros((N, Cc, IH, g.shape[3]), dtype=acc, device=g.device)
+            rows.index_add_(2, y0, g * (1 - ly).view(1, 1, -1, 1))
+            rows.index_add_(2, y1, g * ly.view(1, 1, -1, 1))
+            out = torch.zeros((N, Cc, IH, IW), dtype=acc, device=g.device)
+            out.index_add_(3, x0, rows * (1 - lx).view(1, 1, 1, -1))
+            out.index_add_(3, x1, rows * lx.view(1, 1, 1, -1))
+            return out.to(grad_output.dtype)
         return _backward_any_layout(grad_output, int(input_size[2]), int(input_size[3]))
 
     # torch's autocast up-casts upsample inputs to fp32; BASELINE config 2 keeps
