@@ -204,10 +204,10 @@ def test_override_leaves_uncovered_cases_to_aten(cuda):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 3, 5, 7, generator=g)
     for dtype, ac, tol in ((torch.float32, False, 1e-5), (torch.float64, True, 1e-12), (torch.float16, True, 2e-2)):
-        xr = x.to(dtype).requires_grad_(True)
+        xr = x.clone().to(dtype).requires_grad_(True)          # clone: .to() of the same dtype returns x itself
         ref = F.interpolate(xr, size=(11, 13), mode="bilinear", align_corners=ac)
         ref.sum().backward()
-        xg = x.to(cuda).to(dtype).requires_grad_(True)
+        xg = x.detach().to(cuda).to(dtype).requires_grad_(True)
         out = F.interpolate(xg, size=(11, 13), mode="bilinear", align_corners=ac)
         (out * 1.0).sum().backward()
         torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=tol, atol=tol)
