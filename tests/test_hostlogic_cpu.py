@@ -69,3 +69,41 @@ def test_fused_sgd_group_keys_match_torch_sgd():
     theirs.load_state_dict(ours.state_dict())
     ours.load_state_dict(theirs.state_dict())
     assert ours.param_groups[0]["momentum"] == 0.9 and ours.param_groups[0]["nesterov"] is False
+
+
+def test_cbr_chain_and_bn_relu_conv_are_the_module_sequence_on_cpu():
+    """seg_oprs.cbr_chain / convwrw.bn_relu_conv only re-associate BN + ReLU with the NEXT convolution on the HIP path; on
+    CPU tensors (and for anything the conv64 kernels do not cover) they must be exactly the modules called in order."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torchseg_amd", "furnace"))
+    from seg_opr.seg_oprs import ConvBnRelu, cbr_chain
+    from torchseg_amd.convwrw import bn_relu_conv
+    torch.manual_seed(2)
+    mods = [ConvBnRelu(3, 64, 7, 2, 3), ConvBnRelu(64, 64, 3, 2, 1), ConvBnRelu(64, 64, 3, 2, 1),
+            ConvBnRelu(64, 128, 1, 1, 0, has_relu=False)]
+    x = torch.randn(2, 3, 40, 32)
+    ref = x
+    for m in mods:
+        ref = m(ref)
+    for m in mods:                                   # the reference pass updated the running statistics: rewind them
+        m.bn.reset_running_stats()
+    out = cbr_chain(mods, x)
+    assert torch.equal(out, ref)
+    bn, relu, conv = nn.BatchNorm2d(64), nn.ReLU(), nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+    h = torch.randn(2, 64, 9, 7)
+    want = conv(relu(bn(h)))
+    bn.reset_running_stats()
+    assert torch.equal(bn_relu_conv(bn, relu, h, conv), want)
+
+
+def test_native_builders_defer_only_hip_logits_and_shadows_refuse_cpu_parameters():
+    import pytest
+    from torchseg_amd import workloads
+    from torchseg_amd._lib import TsgError
+    from torchseg_amd.shadow import _Bank
+    z = torch.randn(1, 19, 4, 4)
+    up = workloads.upsample_logits(z, scale=8)
+    assert isinstance(up, torch.Tensor) and tuple(up.shape) == (1, 19, 32, 32)
+    assert torch.equal(up, nn.functional.interpolate(z, scale_factor=8, mode="bilinear", align_corners=True))
+    with pytest.raises(TsgError):
+        _Bank().register(nn.Parameter(torch.randn(64, 64, 3, 3)), want_rot=True)
