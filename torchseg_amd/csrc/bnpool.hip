@@ -16,7 +16,6 @@
 namespace tsg {
 
 constexpr int kBpT = 256;
-constexpr int kBpUnroll = 2;
 
 template <int V>
 __device__ __forceinline__ void bp_ldc(const float* __restrict__ p, int c0, float (&o)[V]) {
@@ -326,12 +325,6 @@ static int bp_check(int dtype, int64_t N, int C, int IH, int IW, int OH, int OW)
   if (N <= 0 || C <= 0 || C % V || IH <= 0 || IW <= 0) return TSG_E_SHAPE;
   if (OH != (IH - 1) / 2 + 1 || OW != (IW - 1) / 2 + 1) return TSG_E_SHAPE;       // K = 3, S = 2, P = 1
   return 0;
-}
-
-static int bp_grid(int64_t items) {
-  int64_t g = (items + kBpT - 1) / kBpT;
-  if (g > 16384) g = 16384;
-  return (int)(g < 1 ? 1 : g);
 }
 
 }  // namespace tsg
