@@ -210,6 +210,13 @@ int tsg_stem_conv_fwd(const void* x, const float* w, void* y, int64_t B, int64_t
                       void* ws, size_t ws_bytes, void* stream);
 int tsg_stem_conv_wrw(const void* x, const void* dy, float* dw, int64_t B, int64_t H, int64_t W,
                       void* ws, size_t ws_bytes, void* stream);
+/* The weight gradient with the BatchNorm + ReLU backward of the layer behind the stem folded into its staging: instead
+ * of dy it takes da (gradient w.r.t. relu(bn(xc))), the stem's own output xc and the backward pack bp[5][64] of
+ * tsg_bn_bwd_coeffs, and evaluates dy = a dv + Bc (xc - mean) + C2, dv = [a xc + b > 0] da (tsg_bn_bwd_apply's
+ * arithmetic and bf16 rounding) while the tile is staged.  The image needs no gradient, so this kernel is the only
+ * consumer of dy: the 0.5 GB tensor is never written (resnet.py:96-98 / bisenet network.py:116 with seg_oprs.py:27-46). */
+int tsg_stem_conv_wrw_bn(const void* x, const void* da, const void* xc, const float* bp, float* dw, int64_t B,
+                         int64_t H, int64_t W, void* ws, size_t ws_bytes, void* stream);
 /* The same forward with the statistics pass of the BatchNorm that follows every such stem (resnet.py:98,
  * seg_oprs.py:27-31) folded into its epilogue: partial[S][2][64] fp32 = per-block sums / square sums of the
  * bf16-rounded outputs, S = tsg_stem_conv_stats_partials(B, H, W) — the layout tsg_bn_finalize / tsg_bn_collapse

@@ -93,3 +93,65 @@ def test_fused_node_equals_module_sequence_and_fp64(cuda, stride):
     for name, got, want in zip(names, res[True], refs):
         err = ((got.double() - want).norm() / want.norm()).item()
         assert err <= (2e-2 if name in ("out", "dx", "dw", "dgamma", "dbeta") else 1e-3), (name, err)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 70, 96), (2, 22, 130)])
+def test_stem_weight_gradient_with_bn_backward_on_load(cuda, shape):
+    """tsg_stem_conv_wrw_bn(img, da, xc, bp) == tsg_stem_conv_wrw(img, tsg_bn_bwd_apply(da, xc, bp)), bit for bit."""
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H + 2 * W)
+    img = torch.randn(B, 3, H, W, generator=g).to(cuda).bfloat16()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(cuda)
+    xc = kp.stem_conv_fwd(img, w)
+    da = torch.randn(xc.shape, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    bp = torch.stack([torch.randn(64, generator=g) * 0.5 + 1.0, torch.randn(64, generator=g) * 0.3,
+                      torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.05,
+                      torch.randn(64, generator=g) * 0.05]).to(cuda).contiguous()
+    bp[0, ::9] *= -1.0
+    layout, n, c, hw = K.bn_layout(xc)
+    dy, _ = kp.bn_bwd_apply(da, xc, None, layout, n, c, hw, bp, True, False)
+    assert torch.equal(kp.stem_conv_wrw_bn(img, da, xc, bp), kp.stem_conv_wrw(img, dy))
+
+
+def test_spatial_path_chain_with_and_without_the_stem_node(cuda):
+    """cbr_chain over [7x7/2 stem, 3x3/2, 3x3/2, 1x1] ConvBnRelu modules under the wrapper's bf16 autocast: the one-node
+    stem -> BN -> conv form (TSG_STEM_BN_WRW) equals the module-by-module form in the output (bit for bit) and in every
+    gradient (the kernel-level test above pins the fused weight gradient bit for bit)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torchseg_amd", "furnace"))
+    from seg_opr.seg_oprs import ConvBnRelu, cbr_chain
+    from torchseg_amd import convwrw
+    from torchseg_amd.convwrw import install_conv_wrw
+    from torchseg_amd.stemconv import install_stem_conv
+    from torchseg_amd.syncbn import SyncBatchNorm
+    torch.manual_seed(5)
+    proto = nn.ModuleList([ConvBnRelu(3, 64, 7, 2, 3, norm_layer=SyncBatchNorm), ConvBnRelu(64, 64, 3, 2, 1, norm_layer=SyncBatchNorm),
+                           ConvBnRelu(64, 64, 3, 2, 1, norm_layer=SyncBatchNorm),
+                           ConvBnRelu(64, 128, 1, 1, 0, norm_layer=SyncBatchNorm)])
+    x = torch.randn(2, 3, 96, 128).to(cuda)
+    out = {}
+    for flag in (True, False):
+        import copy
+        mods = copy.deepcopy(proto).to(cuda).to(memory_format=torch.channels_last)
+        assert install_stem_conv(mods) == 1 and install_conv_wrw(mods) == 2
+        calls = []
+        kp = convwrw.K.provider()
+        orig = kp.stem_conv_wrw_bn
+        kp.stem_conv_wrw_bn = lambda *a, **k: (calls.append("wrw_bn"), orig(*a, **k))[1]
+        old = convwrw._STEM_BN_WRW
+        convwrw._STEM_BN_WRW = flag
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = cbr_chain(list(mods), x)
+            y.float().square().mean().backward()
+        finally:
+            convwrw._STEM_BN_WRW = old
+            del kp.stem_conv_wrw_bn
+        assert calls == (["wrw_bn"] if flag else [])
+        out[flag] = [y.detach().float()] + [p.grad.float() for p in mods.parameters()] + \
+                    [b.clone() for n_, b in mods.named_buffers() if "running" in n_]
+    assert torch.equal(out[True][0], out[False][0])                 # forward: the same kernels on the same values
+    for a, b in zip(out[True][1:], out[False][1:]):                 # backward passes through the library's 1x1 kernels,
+        assert ((a - b).norm() / b.norm().clamp_min(1e-12)).item() <= 1e-3   # which are not run-to-run deterministic

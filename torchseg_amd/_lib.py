@@ -64,6 +64,7 @@ _PROTOS = {
     "tsg_stem_conv_fwd": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_weight_shadow_entry_bytes": (_sz, []),
     "tsg_weight_shadow_refresh": (_i, [_p, _p, _i64, _p]),
+    "tsg_stem_conv_wrw_bn": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_stem_conv_stats_partials": (_i, [_i64, _i64, _i64]),
     "tsg_conv3x3_wrw_tr_norm": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_conv3x3_wrw_gen_norm": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _sz, _p]),

@@ -158,6 +158,92 @@ class _BnReluConvFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, dw.to(wdtype), None, None, None
 
 
+class _StemBnReluConvFn(torch.autograd.Function):
+    """conv_3x3(relu(bn(stem(image)))) — SpatialPath's first two ConvBnRelu (bisenet network.py:116-117) — as ONE node:
+    forward as StemConv2d + _BnReluConvFn; backward additionally folds the BatchNorm backward APPLY into the staging of the
+    stem's weight gradient (tsg_stem_conv_wrw_bn), its only consumer, so neither relu(bn(xc)) nor d(xc) is ever stored."""
+
+    @staticmethod
+    def forward(ctx, img, w_stem, gamma, beta, bn, use_batch_stats, group, weight, wb, stride, wrt):
+        from . import syncbn as S
+        kp = K.provider()
+        if use_batch_stats:
+            xc, hint = kp.stem_conv_fwd_stats(img, w_stem)
+        else:
+            xc, hint = kp.stem_conv_fwd(img, w_stem), None
+        layout, N, C, HW = K.bn_layout(xc)
+        world = S._world(group) if use_batch_stats else 1
+        count_dev = None
+        g32 = gamma.float() if gamma is not None else None
+        b32 = beta.float() if beta is not None else None
+        if use_batch_stats:
+            invstd, fp, count_dev = S._batch_statistics(kp, xc, layout, N, C, HW, bn, g32, b32, group, world, hint)
+        else:
+            invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+            fp = kp.bn_affine(bn.running_mean.float(), invstd, g32, b32)
+        y = kp.conv3x3_c64_fwd(xc, wb, stride=stride, in_ab=fp)
+        ctx.save_for_backward(img, xc, wb, gamma, beta, invstd, fp, count_dev)
+        ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype, w_stem.dtype)
+        ctx.wrt = wrt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import syncbn as S
+        kp = K.provider()
+        img, xc, wb, gamma, beta, invstd, fp, count_dev = ctx.saved_tensors
+        layout, N, C, HW, use_batch_stats, group, world, stride, wdtype, sdtype = ctx.cfg
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dw = kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp)
+        rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
+        da = kp.conv3x3_c64_s2_dgrad(dy, rot, (xc.shape[2], xc.shape[3])) if stride == 2 else kp.conv3x3_c64_fwd(dy, rot)
+        partial, Sn = kp.bn_bwd_reduce(da, xc, None, layout, N, C, HW, fp, True)
+        dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
+                                             world, xc.device)
+        dw_stem = kp.stem_conv_wrw_bn(img, da, xc, bp)           # the BN backward apply happens in its staging
+        if gamma is None:
+            dgamma = dbeta = None
+        else:
+            dgamma = dgamma.to(gamma.dtype)
+            dbeta = dbeta.to(beta.dtype) if beta is not None else None
+        return None, dw_stem.to(sdtype), dgamma, dbeta, None, None, None, dw.to(wdtype), None, None, None
+
+
+# TSG_STEM_BN_WRW=1|0 (default 1): stem -> BN -> ReLU -> 64 -> 64 3x3 as one autograd node (see _StemBnReluConvFn)
+_STEM_BN_WRW = _os.environ.get("TSG_STEM_BN_WRW", "1") != "0"
+
+
+def stem_bn_relu_conv(stem, bn, relu, img, conv):
+    """`conv(relu(bn(stem(img))))`: the fused node when everything is on the HIP path, None otherwise."""
+    from .syncbn import SyncBatchNorm
+    from .stemconv import StemConv2d, _as_bf16_image, _wants_bf16
+    if not (_STEM_BN_WRW and _BN_ON_LOAD and _OWN_C64 and relu is not None and isinstance(stem, StemConv2d)
+            and isinstance(bn, SyncBatchNorm) and isinstance(conv, WrwConv2d) and isinstance(img, torch.Tensor)
+            and img.is_cuda and img.dim() == 4 and not img.requires_grad and stem.bias is None and conv.bias is None
+            and stem.weight.dtype == torch.float32 and conv.weight.dtype == torch.float32 and stem.weight.requires_grad
+            and conv.weight.requires_grad and torch.is_grad_enabled() and stem.padding_mode == "zeros"
+            and _wants_bf16(img) and bn.momentum is not None and bn.num_features == 64
+            and conv.in_channels == 64 and conv.out_channels == 64 and conv.kernel_size == (3, 3)
+            and conv.stride in ((1, 1), (2, 2)) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.weight.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    xb = _as_bf16_image(img)
+    w_stem = stem.weight if stem.weight.is_contiguous() else stem.weight.contiguous()
+    if not K.provider().stem_conv_supported(xb, w_stem, stem.stride[0], stem.padding[0], stem.dilation[0], stem.groups):
+        return None
+    use_batch_stats = bn.training or not bn.track_running_stats
+    with torch.autocast("cuda", enabled=False):
+        if _SHADOW:
+            from .shadow import bank
+            wb, wrt = bank.get(conv.weight, want_rot=True)
+        else:
+            wb, wrt = conv.weight.detach().to(torch.bfloat16), None
+        return _StemBnReluConvFn.apply(xb, w_stem, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, conv.weight,
+                                       wb, conv.stride[0], wrt)
+
+
 # TSG_BN_ON_LOAD=1|0 (default 1): BatchNorm + ReLU in front of a 64 -> 64 3x3 convolution applied while that convolution
 # (and its weight gradient) load their input, instead of as a pass of its own
 _BN_ON_LOAD = _os.environ.get("TSG_BN_ON_LOAD", "1") != "0"

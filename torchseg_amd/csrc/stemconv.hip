@@ -234,10 +234,18 @@ __device__ __forceinline__ int plane_base(int q, int sg) {
   return (q * 2 + sg) * SC_PLANE + sg + 4 * q;
 }
 
+// BNB: dy is not read but MADE — the BatchNorm (+ReLU) backward of the layer behind the stem,
+//   dy = a dv + Bc (xc - mean) + C2,  dv = relu'(a xc + b) * da      (tsg_bn_bwd_apply with the recomputed mask, bf16-rounded),
+// evaluated while the tile is staged from the gradient da w.r.t. the normalised activation and the stem's own output xc.
+// The image needs no gradient, so this weight gradient is the ONLY consumer of dy: the 0.5 GB tensor is never written.
+template <bool BNB>
 __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                  float* __restrict__ part, StemGeom g) {
+                                                  float* __restrict__ part, StemGeom g, const bf16_t* __restrict__ xc,
+                                                  const float* __restrict__ bp) {
   __shared__ __attribute__((aligned(16))) bf16_t dyT[SC_OC * SC_DS];       // 17408 B: [oc][pixel of the tile]
   __shared__ __attribute__((aligned(16))) uint32_t planes[4 * SC_PLANE];   // 17408 B
+  __shared__ __attribute__((aligned(16))) float bps[BNB ? 5 * SC_OC : 4];  // the backward pack {a, b, mean, Bc, C2}
+  if (BNB) for (int i = threadIdx.x; i < 5 * SC_OC; i += 256) bps[i] = bp[i];   // visible after the tile loop's first barrier
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, n = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -270,23 +278,54 @@ __global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, 
     pdst[u] = (ic * SC_RIC + rr) * SC_RS * 2 + dc;
   }
   uint4 rd[SC_TH];
+  uint4 rc[BNB ? SC_TH : 1];                              // BNB: the stem output at the pixels of rd
+  int okm = 0;                                            // BNB: which of the four are inside the image
   uint32_t rp[SC_NPF];
   auto fetch = [&](int tile) {
     const TilePos tp = tile_pos(g, tile);
-    const bf16_t* dt = dy + (((int64_t)tp.b * g.OH + tp.oh0 + strow) * g.OW + tp.ow0 + 2 * spp) * SC_OC + spart * 8;
+    const int64_t off = (((int64_t)tp.b * g.OH + tp.oh0 + strow) * g.OW + tp.ow0 + 2 * spp) * SC_OC + spart * 8;
+    okm = 0;
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
-      for (int px = 0; px < 2; ++px)
-        rd[rs * 2 + px] = (tp.oh0 + strow + 2 * rs < g.OH && tp.ow0 + 2 * spp + px < g.OW)
-                              ? *reinterpret_cast<const uint4*>(dt + ((int64_t)rs * 2 * g.OW + px) * SC_OC)
-                              : make_uint4(0, 0, 0, 0);
+      for (int px = 0; px < 2; ++px) {
+        const bool ok = tp.oh0 + strow + 2 * rs < g.OH && tp.ow0 + 2 * spp + px < g.OW;
+        const int64_t o = off + ((int64_t)rs * 2 * g.OW + px) * SC_OC;
+        rd[rs * 2 + px] = ok ? *reinterpret_cast<const uint4*>(dy + o) : make_uint4(0, 0, 0, 0);
+        if (BNB) {
+          rc[rs * 2 + px] = ok ? *reinterpret_cast<const uint4*>(xc + o) : make_uint4(0, 0, 0, 0);
+          okm |= (ok ? 1 : 0) << (rs * 2 + px);
+        }
+      }
     fetch_patch(x, g, tp, pl, rp);
   };
   int tile = blockIdx.x;
   if (tile < g.ntiles) fetch(tile);
   for (; tile < g.ntiles; tile += gridDim.x) {
     __syncthreads();                                      // previous tile's fragment reads are done
+    if (BNB) {
+#pragma unroll
+      for (int q = 0; q < SC_TH; ++q) {
+        uint32_t wd[4] = {rd[q].x, rd[q].y, rd[q].z, rd[q].w};
+        const uint32_t wx[4] = {rc[q].x, rc[q].y, rc[q].z, rc[q].w};
+        if (okm >> q & 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float o2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int c = spart * 8 + 2 * i + h;
+              const float dav = __uint_as_float(h ? (wd[i] & 0xffff0000u) : (wd[i] << 16));
+              const float xv = __uint_as_float(h ? (wx[i] & 0xffff0000u) : (wx[i] << 16));
+              const float a = bps[c], dv = fmaf(xv, a, bps[SC_OC + c]) > 0.f ? dav : 0.f;
+              o2[h] = fmaf(a, dv, fmaf(bps[3 * SC_OC + c], xv - bps[2 * SC_OC + c], bps[4 * SC_OC + c]));
+            }
+            wd[i] = pack_bf16(o2[0], o2[1]);
+          }
+        }
+        rd[q] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+    }
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) {
       const uint32_t wa[4] = {rd[2 * rs].x, rd[2 * rs].y, rd[2 * rs].z, rd[2 * rs].w};                  // pixel 2 spp
@@ -448,7 +487,26 @@ int tsg_stem_conv_wrw(const void* x, const void* dy, float* dw, int64_t B, int64
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)((char*)ws + sc_align((size_t)SC_OC * SC_KP * sizeof(bf16_t)));
   const int grid = g.ntiles < SC_NPART ? g.ntiles : SC_NPART;
-  hipLaunchKernelGGL(stem_wrw_k, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, part, g);
+  hipLaunchKernelGGL(stem_wrw_k<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, part, g,
+                     (const bf16_t*)nullptr, (const float*)nullptr);
+  TSG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(stem_wrw_fold, dim3(SC_OC * SC_KP / 64), dim3(256), 0, st, (const float*)part, grid, dw);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_stem_conv_wrw_bn(const void* x, const void* da, const void* xc, const float* bp, float* dw, int64_t B, int64_t H,
+                         int64_t W, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !da || !xc || !bp || !dw || !ws) return TSG_E_NULL;
+  StemGeom g;
+  if (!stem_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_stem_conv_ws_bytes()) return TSG_E_WS;
+  if (!aligned16(da) || !aligned16(xc) || !aligned16(ws) || (((uintptr_t)x) & 3u)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)((char*)ws + sc_align((size_t)SC_OC * SC_KP * sizeof(bf16_t)));
+  const int grid = g.ntiles < SC_NPART ? g.ntiles : SC_NPART;
+  hipLaunchKernelGGL(stem_wrw_k<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)da, part, g,
+                     (const bf16_t*)xc, bp);
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(stem_wrw_fold, dim3(SC_OC * SC_KP / 64), dim3(256), 0, st, (const float*)part, grid, dw);
   TSG_CHECK_LAUNCH();

@@ -59,9 +59,14 @@ def cbr_chain(mods, x):
         for m in mods:
             x = m(x)
         return x
-    from torchseg_amd.convwrw import bn_relu_conv
-    x = mods[0].conv(x)
-    for prev, m in zip(mods[:-1], mods[1:]):
+    from torchseg_amd.convwrw import bn_relu_conv, stem_bn_relu_conv
+    first = 1
+    y = stem_bn_relu_conv(mods[0].conv, mods[0].bn, mods[0].relu, x, mods[1].conv) if len(mods) > 1 else None
+    if y is not None:                                 # image stem + its BN + the next convolution as one autograd node
+        x, first = y, 2
+    else:
+        x = mods[0].conv(x)
+    for prev, m in zip(mods[first - 1:-1], mods[first:]):
         x = bn_relu_conv(prev.bn, prev.relu, x, m.conv)
     last = mods[-1]
     relu = last.relu if last.has_relu else None

@@ -325,6 +325,22 @@ class HipKernels:
                                            ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_wrw")
         return dw
 
+    def stem_conv_wrw_bn(self, x, da, xc, bp):
+        """stem_conv_wrw of dy = BN+ReLU backward(da; xc, bp) without writing dy: x the image (as stem_conv_fwd), da / xc
+        [B,64,OH,OW] bf16 channels_last (gradient w.r.t. relu(bn(xc)) / the stem output), bp fp32 [5,64] backward pack"""
+        _require_contiguous(x, bp)
+        for t in (da, xc):
+            if not t.is_contiguous(memory_format=torch.channels_last) or t.dtype != torch.bfloat16 or t.shape != da.shape:
+                raise ValueError("stem_conv_wrw_bn expects bf16 channels_last da / xc of one shape")
+        if bp.dtype != torch.float32 or tuple(bp.shape) != (5, 64):
+            raise ValueError("stem_conv_wrw_bn expects the [5, 64] fp32 backward pack")
+        B, _, H, W = x.shape
+        dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_wrw_bn(x.data_ptr(), da.data_ptr(), xc.data_ptr(), bp.data_ptr(), dw.data_ptr(), B, H,
+                                              W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_wrw_bn")
+        return dw
+
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
@@ -806,6 +822,7 @@ _ALGO_BYTES = {
     "bn_relu_pool_bwd_reduce": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[2]),
     "bn_relu_pool_bwd_apply": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 2 * _nbytes(a[2]),
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
+    "stem_conv_wrw_bn": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[2]),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "conv3x3_c64_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "conv3x3_c64_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
@@ -821,6 +838,7 @@ _ALGO_FLOPS = {
     "conv3x3_c64_s2_dgrad": lambda a, r: 2 * 9 * 64 * a[0].numel(),
     "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
     "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
+    "stem_conv_wrw_bn": lambda a, r: 2 * 147 * a[1].numel(),
 }
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 
