@@ -11,7 +11,7 @@ FAMILIES = [("bn_stats", r"bn_reduce_(nhwc|nchw)<[^,]+, \d+, 0,"), ("bn_bwd_redu
             ("upsample_fwd_nhwc", r"up_fwd_nhwc<"), ("upsample_bwd_nhwc", r"up_bwd_nhwc<"),
             ("chanscale_fwd", r"cs_fwd_"), ("chanscale_bwd", r"cs_bwd_"), ("gap_fwd", r"gap_fwd"), ("gap_bwd", r"gap_bwd"),
             ("maxpool_fwd", r"maxpool_fwd_nhwc<"), ("maxpool_bwd", r"maxpool_bwd_nhwc<"),
-            ("stem_conv_fwd", r"stem_fwd_k<false>"), ("stem_conv_fwd_stats", r"stem_fwd_k<true>"), ("stem_conv_wrw", r"stem_wrw_k"),
+            ("stem_conv_fwd", r"stem_fwd_k<false>"), ("stem_conv_fwd_stats", r"stem_fwd_k<true>"), ("stem_conv_wrw", r"stem_wrw_k<false>"), ("stem_conv_wrw_bn", r"stem_wrw_k<true>"),
             ("sgd_multi_step", r"sgd_multi_k"),
             ("conv3x3_wrw", r"conv3_wrw_(gen_k<|tr_k|k\()"), ("conv3x3_c64_fwd", r"conv64_fwd(_s2)?_k<"),
             ("conv3x3_c64_s2_dgrad", r"conv64_dgrad_s2_k<"), ("ohem_up_fwd", r"ohem_up_fwd_k<"), ("ohem_up_bwd", r"ohem_up_bwd_k<"),
