@@ -577,6 +577,10 @@ int tsg_comm_world(const tsg_comm* c);
 int tsg_comm_allreduce(tsg_comm* c, void* buf, int64_t count, int dtype, void* stream);
 /* recv[world * count_per_rank] <- concatenation of every rank's send[count_per_rank]. */
 int tsg_comm_allgather(tsg_comm* c, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream);
+/* recv[count_per_rank] <- this rank's slice of the sum over ranks of send[world * count_per_rank] (first half of the
+ * reduce-scatter + all-gather form of the gradient-bucket exchange; recv may alias
+ * send + rank * count_per_rank). */
+int tsg_comm_reduce_scatter(tsg_comm* c, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream);
 /* buf[count] <- root's buf (parameter broadcast at wrap time, apex DDP). */
 int tsg_comm_broadcast(tsg_comm* c, void* buf, int64_t count, int dtype, int root, void* stream);
 const char* tsg_comm_error_string(int code);
@@ -587,7 +591,9 @@ const char* tsg_comm_error_string(int code);
  * results on all ranks.  Setup: each rank calls tsg_comm_xgmi_export (allocates its mailbox for messages of up to
  * max_floats and returns an IPC handle of tsg_comm_xgmi_handle_bytes() bytes), the handles are all-gathered in rank
  * order by the host, then tsg_comm_xgmi_attach maps the peers.  tsg_xgmi_small_allreduce uses the mailboxes when they
- * are attached and count fits; otherwise it is ncclAllReduce on the same stream. */
+ * are attached and count fits; otherwise it is ncclAllReduce on the same stream.  The call counter that selects the
+ * mailbox parity and the flag value lives in device memory and is advanced by the kernel, so the launch may be
+ * captured in a hipGraph and replayed. */
 size_t tsg_comm_xgmi_handle_bytes(void);
 int tsg_comm_xgmi_export(tsg_comm* c, int64_t max_floats, void* handle_out);
 int tsg_comm_xgmi_attach(tsg_comm* c, const void* all_handles);

@@ -44,8 +44,9 @@ class Net(nn.Module):
         return nn.functional.cross_entropy(self.head(h), y)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, q, rs="0"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      TSG_DDP_RS=rs)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from _cpu_provider import OracleProvider
     from torchseg_amd import kernels as K
@@ -73,12 +74,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_syncbn_and_ddp_world2_match_single_process():
+@pytest.mark.parametrize("rs", ["0", "1"], ids=["allreduce", "reduce_scatter+all_gather"])
+def test_syncbn_and_ddp_world2_match_single_process(rs):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, rs)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

@@ -82,3 +82,48 @@ def test_whole_eval_and_scale_process_signatures(cuda):
     sc = R.val_func_process(net, inp, False)[:, margin[0]:48 - margin[1], margin[2]:48 - margin[3]]
     ref = R.resize_scores(np.ascontiguousarray(sc.transpose(1, 2, 0)), 60, 88).argmax(2)
     assert (pred != ref).mean() <= 0.01
+
+
+def test_run_with_a_cpu_built_network_and_a_checkpoint(cuda, tmp_path):
+    """The path an unchanged eval.py takes (eval.py:62-69): the network is constructed on the CPU, `run()` loads the
+    checkpoint with map_location='cpu' through load_model, and the sliding evaluation must move it to the GPU itself
+    (reference: evaluator.py:258-259).  Round 2 only did so in val_func_process."""
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    from engine.evaluator import Evaluator
+    torch.manual_seed(9)
+    trained = TinySeg()
+    ckpt = tmp_path / "epoch-3.pth"
+    torch.save({"model": trained.state_dict()}, str(ckpt))
+    rng = np.random.RandomState(4)
+    imgs = [rng.randint(0, 256, size=(40, 56, 3)).astype(np.uint8) for _ in range(2)]
+    labels = [rng.randint(0, C, size=(40, 56)).astype(np.int64) for _ in range(2)]
+
+    class DS(object):
+        def get_length(self):
+            return len(imgs)
+
+        def __getitem__(self, i):
+            return dict(data=imgs[i], label=labels[i], fn=str(i), n=len(imgs))
+
+    class SegEval(Evaluator):
+        def func_per_iteration(self, data, device):
+            pred = self.sliding_eval(data["data"], 32, 2 / 3, device)
+            return dict(pred=pred, label=data["label"])
+
+        def compute_metric(self, results):
+            acc = np.mean([(r["pred"] == r["label"]).mean() for r in results])
+            return "acc %.6f" % acc
+
+    torch.manual_seed(1)
+    cpu_net = TinySeg()                                    # different weights, on the CPU: the checkpoint must win
+    ev = SegEval(DS(), C, MEAN, STD, cpu_net, [1.0], True, [0])
+    log = tmp_path / "val.log"
+    ev.run(str(tmp_path), "3", str(log), str(tmp_path / "val_last.log"))
+    assert next(ev.val_func.parameters()).is_cuda
+    text = log.read_text()
+    assert "epoch-3.pth" in text and "acc " in text
+    want = np.mean([(R.sliding_eval(trained, im, C, [1.0], 32, 2 / 3, MEAN, STD, True) == lb).mean()
+                    for im, lb in zip(imgs, labels)])
+    got = float(text.split("acc ")[1].split()[0])
+    assert abs(got - want) < 0.02

@@ -109,16 +109,45 @@ def test_iadd_followed_by_anything_else_is_an_ordinary_in_place_add(standin):
     a = torch.ones(1, 8, 2, 2, requires_grad=True)
     with FuseMode():
         fm = a * 2.0
-        alias = fm
         fm += torch.ones(1, 8, 2, 2)
         assert isinstance(fm, DeferredSum)
         out = F.relu(fm)                               # not interpolate -> the add happens, in place
     assert standin.calls == []
-    assert torch.equal(out, torch.full((1, 8, 2, 2), 3.0)) and torch.equal(alias, out)
+    assert torch.equal(out, torch.full((1, 8, 2, 2), 3.0))
+    with FuseMode():                                   # an alias can observe the update: the add stays eager
+        fm = a * 2.0
+        alias = fm
+        keep = [fm]
+        fm += torch.ones(1, 8, 2, 2)
+        assert isinstance(fm, torch.Tensor) and fm is alias and keep[0] is fm
+        up = F.interpolate(fm, size=(4, 4), mode='bilinear', align_corners=True)
+    assert torch.equal(alias, torch.full((1, 8, 2, 2), 3.0)) and tuple(up.shape) == (1, 8, 4, 4)
     with FuseMode():                                   # leaves / no-grad tensors are never deferred
         p = torch.zeros(1, 8, 2, 2)
         p += 1
         assert isinstance(p, torch.Tensor)
+
+
+def test_iadd_interpolate_positional_arguments_and_late_modification(standin):
+    """`F.interpolate(fm, (h, w), ...)` with positional size; an in-place change of an addend between the
+    `+=` and its use must not change the result silently."""
+    from torchseg_amd.fusion import FuseMode
+    g = torch.Generator().manual_seed(2)
+    a0, b0 = torch.randn(1, 8, 4, 4, generator=g), torch.randn(1, 8, 4, 4, generator=g)
+    ref = F.interpolate(a0 * 2.0 + b0, (8, 8), None, 'bilinear', True)
+    with FuseMode():
+        fm = a0.clone().requires_grad_(True) * 2.0
+        fm += b0
+        out = F.interpolate(fm, (8, 8), None, 'bilinear', True)
+    assert standin.calls == ["upsample_presum_fwd"]
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    with FuseMode():
+        fm = a0.clone().requires_grad_(True) * 2.0
+        last = b0.clone()
+        fm += last
+        last.mul_(0.0)                                 # the eager program would already have consumed `last`
+        with pytest.raises(RuntimeError, match="modified in place"):
+            F.interpolate(fm, size=(8, 8), mode='bilinear', align_corners=True)
 
 
 def test_bad_labels_are_reported_not_indexed(standin, monkeypatch):
@@ -185,3 +214,14 @@ def test_pending_upsampling_is_a_real_tensor_for_everything_else(standin):
     torch.testing.assert_close(out, ref)
     with FuseMode(head=True), torch.no_grad():         # eval path: nothing is deferred
         assert isinstance(F.interpolate(x, scale_factor=4, mode='bilinear', align_corners=True), torch.Tensor)
+
+
+def test_add_underscore_call_is_never_deferred(standin):
+    """`fm.add_(x)` dispatches to the same torch function as `fm += x` but drops the returned object: deferring it
+    would lose the update."""
+    from torchseg_amd.fusion import FuseMode
+    a = torch.ones(1, 8, 2, 2, requires_grad=True)
+    with FuseMode():
+        fm = a * 2.0
+        fm.add_(torch.ones(1, 8, 2, 2))
+        assert isinstance(fm, torch.Tensor) and torch.equal(fm, torch.full((1, 8, 2, 2), 3.0))

@@ -128,6 +128,7 @@ _PROTOS = {
     "tsg_comm_world": (_i, [_p]),
     "tsg_comm_allreduce": (_i, [_p, _p, _i64, _i, _p]),
     "tsg_comm_allgather": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "tsg_comm_reduce_scatter": (_i, [_p, _p, _p, _i64, _i, _p]),
     "tsg_comm_broadcast": (_i, [_p, _p, _i64, _i, _i, _p]),
     "tsg_comm_error_string": (C.c_char_p, [_i]),
     "tsg_comm_xgmi_handle_bytes": (_sz, []),

@@ -10,7 +10,6 @@ and the IPC handles of the mailboxes between the ranks) and the fallback for CPU
   TSG_XGMI_ONESHOT=1   SyncBN statistics through the one-shot peer-mailbox all-reduce (tsg_xgmi_small_allreduce with
                        mailboxes attached) instead of ncclAllReduce
 """
-import atexit
 import ctypes as C
 import os
 
@@ -92,6 +91,16 @@ class Comm(object):
                                             L.dtype_code(send), L.stream_ptr(send)), "tsg_comm_allgather")
         return recv
 
+    def reduce_scatter(self, send, recv):
+        """recv <- this rank's slice of the sum over ranks of send (recv may be send's own slice: in place)."""
+        self._check(send)
+        self._check(recv)
+        if send.numel() != recv.numel() * self.world or recv.dtype != send.dtype:
+            raise L.TsgError("reduce_scatter: send must hold world x recv")
+        L.check(self.lib.tsg_comm_reduce_scatter(self.handle, send.data_ptr(), recv.data_ptr(), recv.numel(),
+                                                 L.dtype_code(send), L.stream_ptr(send)), "tsg_comm_reduce_scatter")
+        return recv
+
     def broadcast(self, t, root=0):
         self._check(t)
         L.check(self.lib.tsg_comm_broadcast(self.handle, t.data_ptr(), t.numel(), L.dtype_code(t), int(root),
@@ -123,11 +132,21 @@ def get(group=None, like=None):
     return c
 
 
+def get_extra(group=None, tag="extra", like=None):
+    """A SECOND communicator on `group` (ddp.py's TSG_DDP_COMM=separate: gradient buckets that should not serialise
+    with the SyncBN exchanges).  Every rank must ask for it at the same point of its program."""
+    if get(group, like) is None:
+        return None
+    key = (id(group) if group is not None else None, tag)
+    c = _comms.get(key)
+    if c is None:
+        c = _comms[key] = Comm(group, xgmi=False)
+    return c
+
+
 def shutdown():
-    """Destroy every communicator (call before dist.destroy_process_group())."""
+    """Destroy every communicator.  Explicit, not an atexit hook: ncclCommDestroy has to run BEFORE
+    dist.destroy_process_group() and before the HIP runtime is torn down (Engine.__exit__ and bench.py call it)."""
     for c in list(_comms.values()):
         c.destroy()
     _comms.clear()
-
-
-atexit.register(shutdown)

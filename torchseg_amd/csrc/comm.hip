@@ -10,7 +10,9 @@
 // ProcessGroupNCCL runs every collective on its own stream, i.e. two event record/wait handshakes per collective and a
 // Python -> C++ -> Work-object round trip; measured 1.9 ms per step on a 1-rank group where the wire time is zero
 // (DESIGN.md section 6).  Here the collective is one ncclAllReduce call on the compute stream between the kernel that
-// produces the message and the kernel that consumes it: no handshake, no allocation, capturable in a hipGraph.
+// produces the message and the kernel that consumes it: no handshake, no allocation, capturable in a hipGraph (the
+// mailbox path below as well: its call counter lives in device memory and is advanced by the kernel itself, so a
+// replayed launch sees a fresh sequence number — tests/test_comm_gpu.py::test_mailbox_under_graph_replay).
 //
 // librccl is resolved at run time (dlopen) so that libtsg_hip.so has no link-time dependency on it and shares the
 // copy that PyTorch already loaded (two RCCL copies in one process would each grab the xGMI topology).
@@ -42,6 +44,7 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -70,6 +73,7 @@ int load_rccl(const char* path) {
   SYM(AllReduce, "ncclAllReduce");
   SYM(AllGather, "ncclAllGather");
   SYM(Broadcast, "ncclBroadcast");
+  SYM(ReduceScatter, "ncclReduceScatter");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   g_rccl = r;
@@ -100,6 +104,10 @@ inline int rc(ncclResult_t r) { return r == 0 ? 0 : TSG_E_COMM_BASE - r; }
 // calls ahead of a peer after that peer has passed step 2 of the call in between, i.e. finished reading the older
 // parity, so two buffers suffice.  Mailboxes are uncached device memory (hipDeviceMallocUncached) so peer stores and
 // the local spin bypass L2.
+// The sequence number of a call is NOT a kernel argument: a hipGraph would bake one value in and every replay after the
+// first would find its flags already satisfied (stale sums).  It is a counter in this rank's device memory that the
+// kernel reads, advances and writes back; launches of one communicator are stream-ordered, and every rank issues the
+// same sequence of calls, so the counters of all ranks stay in step whether the launches are eager or replayed.
 constexpr int kXgmiMaxWorld = 16;
 
 struct XgmiPeers {
@@ -108,12 +116,17 @@ struct XgmiPeers {
 };
 
 __global__ __launch_bounds__(256) void xgmi_allreduce_k(XgmiPeers peers, float* __restrict__ buf, int n, int cap,
-                                                        int rank, int world, unsigned long long seq) {
-  const int par = (int)(seq & 1ull);
+                                                        int rank, int world, unsigned long long* __restrict__ seq_dev) {
   const int tid = threadIdx.x;
   __shared__ int timed_out;
-  if (tid == 0) timed_out = 0;
+  __shared__ unsigned long long seq_sh;
+  if (tid == 0) {
+    timed_out = 0;
+    seq_sh = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  }
   __syncthreads();
+  const unsigned long long seq = seq_sh;
+  const int par = (int)(seq & 1ull);
   const size_t my_slot = ((size_t)par * world + rank) * cap;
   for (int p = 0; p < world; ++p) {
     float* dst = peers.slots[p] + my_slot;
@@ -133,6 +146,8 @@ __global__ __launch_bounds__(256) void xgmi_allreduce_k(XgmiPeers peers, float* 
     }
   }
   __syncthreads();
+  // the next launch on this stream (eager or a replayed graph node) reads seq + 1
+  if (tid == 0) __hip_atomic_store(seq_dev, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (timed_out) {
     for (int i = tid; i < n; i += 256) buf[i] = __int_as_float(0x7fc00000);
     return;
@@ -154,7 +169,7 @@ struct tsg_comm {
   bool attached;
   void* peer_base[kXgmiMaxWorld];     // opened IPC mappings (own entry = box)
   XgmiPeers peers;
-  unsigned long long seq;             // calls issued so far (host side; every rank issues the same sequence)
+  unsigned long long* seq_dev;        // calls completed so far, in device memory (advanced by the kernel: graph-safe)
 };
 
 namespace {
@@ -208,6 +223,7 @@ int tsg_comm_destroy(tsg_comm* c) {
     for (int p = 0; p < c->world; ++p)
       if (p != c->rank && c->peer_base[p]) (void)hipIpcCloseMemHandle(c->peer_base[p]);
   if (c->box) (void)hipFree(c->box);
+  if (c->seq_dev) (void)hipFree(c->seq_dev);
   if (c->comm) e = rc(g_rccl.CommDestroy(c->comm));
   delete c;
   return e;
@@ -232,9 +248,15 @@ int tsg_comm_xgmi_export(tsg_comm* c, int64_t max_floats, void* handle_out) {
   hipIpcMemHandle_t h;
   hipError_t e = hipIpcGetMemHandle(&h, p);
   if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+  void* sq = nullptr;
+  e = hipMalloc(&sq, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(sq, 0, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(p); if (sq) (void)hipFree(sq); return (int)e; }
   memcpy(handle_out, &h, sizeof h);
   c->box = p;
   c->cap = cap;
+  c->seq_dev = (unsigned long long*)sq;
   return 0;
 }
 
@@ -264,9 +286,8 @@ int tsg_xgmi_small_allreduce(tsg_comm* c, float* buf, int64_t count, void* strea
   if (count < 0) return TSG_E_SHAPE;
   if (count == 0) return 0;
   if (c->attached && count <= c->cap) {
-    c->seq += 1;
     hipLaunchKernelGGL(xgmi_allreduce_k, dim3(1), dim3(256), 0, (hipStream_t)stream, c->peers, buf, (int)count, c->cap,
-                       c->rank, c->world, c->seq);
+                       c->rank, c->world, c->seq_dev);
     TSG_CHECK_LAUNCH();
     return 0;
   }
@@ -293,6 +314,15 @@ int tsg_comm_allgather(tsg_comm* c, const void* send, void* recv, int64_t count_
   if (t < 0) return TSG_E_DTYPE;
   if (count_per_rank == 0) return 0;
   return rc(g_rccl.AllGather(send, recv, (size_t)count_per_rank, t, c->comm, (hipStream_t)stream));
+}
+
+int tsg_comm_reduce_scatter(tsg_comm* c, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream) {
+  if (!c || !send || !recv || !c->comm) return TSG_E_NULL;
+  if (count_per_rank < 0) return TSG_E_SHAPE;
+  const int t = nccl_type(dtype);
+  if (t < 0) return TSG_E_DTYPE;
+  if (count_per_rank == 0) return 0;
+  return rc(g_rccl.ReduceScatter(send, recv, (size_t)count_per_rank, t, kNcclSum, c->comm, (hipStream_t)stream));
 }
 
 int tsg_comm_broadcast(tsg_comm* c, void* buf, int64_t count, int dtype, int root, void* stream) {

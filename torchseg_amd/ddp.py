@@ -15,8 +15,22 @@ MI355X design (instead of apex's flatten -> all_reduce -> unflatten copies):
     backward (reverse-autograd order), which also makes statically unused
     parameters (DFN has 5, SURVEY.md §2) a non-event: they are simply never bucketed;
   * each bucket's all-reduce is issued from the autograd hook of its last
-    gradient; torch.distributed's "nccl" backend is RCCL on ROCm and runs the
-    collective on its own HIP stream, overlapping the rest of backward;
+    gradient.  On HIP tensors it is ONE `tsg_comm_allreduce` (RCCL) on a side
+    stream this reducer owns, fenced by two events (gather -> side stream,
+    side stream -> end of backward): no ProcessGroup Work object and no
+    ProcessGroup stream handshake (round 3; CPU tensors / gloo keep
+    `dist.all_reduce(async_op=True)`).  By default it is the SAME communicator
+    the SyncBN exchanges use on the compute stream: RCCL serialises launches of
+    one communicator in issue order whatever their streams, and every rank issues
+    the same program order (autograd hooks of one model), so there is no
+    cross-communicator ordering to get wrong.  The price is that a SyncBN
+    exchange issued while a bucket is on the wire waits for it (<= 0.25 ms per
+    40 MB bucket at 8 GPUs).  TSG_DDP_COMM=separate gives the buckets their own
+    communicator (full overlap; not validated on a multi-GPU node yet);
+    TSG_DDP_COMM=torch restores torch.distributed;
+  * TSG_DDP_RS=1 splits a bucket's all-reduce into reduce-scatter + all-gather
+    (direct exchange over all 7 xGMI links instead of a
+    ring), in place on the flat buffer (padded to a multiple of the world size);
   * bucket size defaults to 1e7 elements (40 MB): xGMI rings are per-link bound
     (~153 GB/s), so few large messages beat many small ones.
 
@@ -68,13 +82,15 @@ def apply_channels_last(module):
 class _Bucket(object):
     __slots__ = ("params", "offsets", "flat", "pending", "work", "ready", "views", "maps")
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, pad_to=1):
         self.params = params
         self.offsets = []
         n = 0
         for p in params:
             self.offsets.append(n)
             n += (p.numel() + 3) // 4 * 4        # keep every gradient view 16-byte aligned (vector kernels)
+        q = 4 * max(1, int(pad_to))              # reduce-scatter: equal, 16-byte aligned slices per rank
+        n = (n + q - 1) // q * q
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.pending = len(params)
         self.work = None
@@ -110,6 +126,11 @@ class Reducer(object):
         self._seen = set()
         self._callback_queued = False
         self._stragglers = []        # params outside the plan that got a grad later
+        mode = os.environ.get("TSG_DDP_COMM", "shared").strip().lower()
+        self._comm_mode = mode if mode in ("shared", "separate", "torch") else "shared"
+        self._rs = _env_flag("TSG_DDP_RS", False)
+        self._comm = None            # tsg_comm of the buckets (HIP tensors), resolved at the first launch
+        self._side = None            # the HIP stream the bucket collectives run on
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     # -- autograd side -------------------------------------------------------
@@ -179,11 +200,70 @@ class Reducer(object):
             for i in fast:
                 bucket.params[i].grad = bucket.views[i]
 
+    def _bucket_comm(self, flat):
+        """The tsg_comm the buckets use (None: torch.distributed)."""
+        if not flat.is_cuda or self._comm_mode == "torch":
+            return None
+        if self._comm is None:
+            from . import comm
+            if self._comm_mode == "separate":
+                self._comm = comm.get_extra(self.group, "ddp-buckets", like=flat)
+            else:
+                self._comm = comm.get(self.group, like=flat)
+            if self._comm is None:
+                self._comm_mode = "torch"                # gloo group, TSG_COMM=0, ...
+                return None
+            self._side = torch.cuda.Stream(device=flat.device)
+        return self._comm
+
+    def _reduce(self, flat, comm):
+        """SUM over ranks of one flat bucket, in place; returns what _finish_backward has to wait for."""
+        if comm is not None:
+            cur = torch.cuda.current_stream(flat.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)                            # the gather copy (and everything before it) is enqueued
+            self._side.wait_event(ready)
+            with torch.cuda.stream(self._side):
+                if self._rs:
+                    n = flat.numel() // self.world
+                    mine = flat[comm.rank * n:(comm.rank + 1) * n]
+                    comm.reduce_scatter(flat, mine)      # in place: my slice of the sum ...
+                    comm.all_gather(mine, flat)          # ... then everybody's slices
+                else:
+                    comm.all_reduce(flat)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            return done
+        if self._rs and self.world > 1 and not flat.is_cuda:
+            # the same split on torch.distributed primitives (gloo has no reduce_scatter: one reduce per slice)
+            n = flat.numel() // self.world
+            rank = dist.get_rank(self.group)
+            for r in range(self.world):
+                dst = dist.get_global_rank(self.group, r) if self.group is not None else r
+                dist.reduce(flat[r * n:(r + 1) * n], dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+            parts = [torch.empty(n, dtype=flat.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, flat[rank * n:(rank + 1) * n].clone(), group=self.group)
+            for r in range(self.world):
+                flat[r * n:(r + 1) * n].copy_(parts[r])
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def _wait(work, device):
+        if work is None:
+            return
+        if isinstance(work, torch.cuda.Event):
+            torch.cuda.current_stream(device).wait_event(work)      # stream-level fence, the host does not block
+        else:
+            work.wait()                                             # torch.distributed Work: fence on HIP, blocking on gloo
+
     def _launch(self, bucket):
         # averaging = pre-division by the world size inside the gather copy; apex's gradient_predivide_factor only
         # chooses where the same division happens (overflow control for fp16 buckets), irrelevant for fp32 buckets
         self._gather(bucket, 1.0 / self.world if self.average else 1.0)
-        bucket.work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        bucket.work = self._reduce(bucket.flat, self._bucket_comm(bucket.flat))
+        if bucket.work is None:
+            bucket.work = True                           # synchronous path: nothing to wait for
 
     def _build_plan(self):
         device = self._order[0].device if self._order else torch.device("cpu")
@@ -198,7 +278,7 @@ class Reducer(object):
             groups.append(cur)
         self.buckets = []
         for bi, ps in enumerate(groups):
-            bucket = _Bucket(ps, device)
+            bucket = _Bucket(ps, device, self.world if self._rs else 1)
             for i, p in enumerate(ps):
                 self._slot[p] = (bi, i)
                 view = bucket.view(i)
@@ -224,7 +304,8 @@ class Reducer(object):
                 p.grad.div_(self.world)
         self._stragglers = []
         for bucket in self.buckets:
-            bucket.work.wait()       # stream-level fence on HIP, blocking on gloo
+            if bucket.work is not True:
+                self._wait(bucket.work, bucket.flat.device)
             bucket.work = None
             bucket.pending = len(bucket.params)
             bucket.ready = [False] * len(bucket.params)

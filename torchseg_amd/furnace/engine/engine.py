@@ -138,6 +138,11 @@ class Engine(object):
         return self
 
     def __exit__(self, type, value, tb):
+        try:                                    # our RCCL communicators go before the process group and the HIP runtime
+            from torchseg_amd import comm as _tsg_comm
+            _tsg_comm.shutdown()
+        except Exception:                       # noqa: BLE001 - never mask the training error that brought us here
+            pass
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
         if type is not None:

@@ -112,6 +112,9 @@ class Evaluator(object):
 
     def _network_scores(self, x):
         """val_func_process (evaluator.py:255-273) on a batch [n,3,h,w]: log-probabilities, flip TTA, exp."""
+        # the reference moves the network to the input's device on every call (evaluator.py:258-259: an unchanged eval.py
+        # builds it on the CPU and run() loads the checkpoint with map_location='cpu'); a no-op once it is there
+        self.val_func.to(x.device)
         self.val_func.eval()
         with torch.no_grad():
             score = self.val_func(x)
@@ -124,7 +127,6 @@ class Evaluator(object):
         if not isinstance(input_data, torch.Tensor):
             input_data = torch.from_numpy(np.ascontiguousarray(input_data, dtype=np.float32))
         x = input_data.to(self._device(device), dtype=torch.float32)[None]
-        self.val_func.to(x.device)
         return self._network_scores(x)[0]
 
     def process_image(self, img, crop_size=None):

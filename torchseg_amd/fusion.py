@@ -14,8 +14,15 @@ the operator fusions of the hot path have to be recognised at the torch-function
   * a9  `torch.bmm(x, torch.softmax(a, dim=1))` (psanet network.py:125-126,135-136) -> `tsg_psa_*` (psa.py).
 
 Every deferred value materialises itself (with the eager semantics, including the in-place update of `fm`) the
-moment anything other than its fusing consumer touches it, so code outside the recognised patterns is unaffected.
+moment anything other than its fusing consumer touches it.  The `+=` deferral changes WHEN (and, on the fused path,
+whether) `fm` itself is updated, so it is only taken when nothing else can observe `fm`: the tensor must be referenced
+by nothing but the statement's own variable (an alias in a list, an attribute or a second name keeps the eager in-place
+add), and the fused consumer checks the version counters of both addends — an in-place change of either between the
+`+=` and the `F.interpolate` raises instead of producing a silently different sum.
 """
+import dis
+import sys
+
 import torch
 import torch.nn.functional as F
 from torch.overrides import TorchFunctionMode
@@ -87,9 +94,16 @@ class DeferredSum(_Deferred):
 
     def __init__(self, a, b):
         self.a, self.b = a, b
+        self.versions = (a._version, b._version)
+
+    def unchanged(self):
+        return (self.a._version, self.b._version) == self.versions
 
     def materialize(self):
         if self._value is None:
+            if not self.unchanged():
+                raise RuntimeError("torchseg_amd.fusion: a tensor of a pending `a += b` was modified in place before the "
+                                   "sum was used; set TSG_FUSE_ADD_UP=0 for this model")
             self._value = self.a.add_(self.b)
         return self._value
 
@@ -131,9 +145,52 @@ def _is_logits(t):
     return _is_map(t) or (isinstance(t, DeferredUpsample) and _is_map(t.z))
 
 
+_OP_INPLACE_ADD = dis.opmap.get("INPLACE_ADD")            # <= 3.10
+_OP_BINARY = dis.opmap.get("BINARY_OP")                   # >= 3.11: argument 13 = NB_INPLACE_ADD
+
+
+def _caller_runs_augmented_add(depth=2):
+    """True when the Python frame that triggered the current torch function is executing `x += y` — the statement that
+    rebinds `x` to whatever we return.  `x.add_(y)` dispatches to the same torch function but drops the result, so a
+    deferred value would be lost: only the augmented assignment may be deferred."""
+    try:
+        f = sys._getframe(depth)
+        code, i = f.f_code.co_code, f.f_lasti
+        if i < 0 or i >= len(code):
+            return False
+        if _OP_INPLACE_ADD is not None and code[i] == _OP_INPLACE_ADD:
+            return True
+        return _OP_BINARY is not None and code[i] == _OP_BINARY and code[i + 1] == 13
+    except Exception:                                       # noqa: BLE001 - no frame introspection: never defer
+        return False
+
+
+def _calibrate_iadd_refs():
+    """sys.getrefcount of the left operand of `t += u`, seen from a TorchFunctionMode, when `t` is referenced by the
+    statement's own local variable only.  Anything above this count means an alias exists somewhere."""
+    seen = []
+
+    class _Probe(TorchFunctionMode):
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            if func in _IADD_FUNCS:
+                seen.append(sys.getrefcount(args[0]))
+            return func(*args, **(kwargs or {}))
+
+    def stmt():
+        t = torch.zeros(1) * 1.0
+        u = torch.zeros(1)
+        t += u
+        return t
+
+    with _Probe():
+        stmt()
+    return seen[0] if seen else 0
+
+
 _LOG_SOFTMAX_FUNCS = (F.log_softmax, torch.log_softmax, torch.Tensor.log_softmax)
 _IADD_FUNCS = (torch.Tensor.__iadd__, torch.Tensor.add_)
 _ADD_FUNCS = (torch.Tensor.__add__, torch.Tensor.__radd__, torch.Tensor.add, torch.add)
+_IADD_BASE_REFS = _calibrate_iadd_refs()
 
 
 def _ce_args(args, kwargs):
@@ -190,13 +247,20 @@ class FuseMode(TorchFunctionMode):
         if self.add_up:
             if func in _IADD_FUNCS and len(args) == 2 and not kwargs and _is_map(args[0]) and _is_map(args[1]) \
                     and args[0].shape == args[1].shape and args[0].dtype == args[1].dtype \
-                    and args[0].grad_fn is not None and torch.is_grad_enabled():
+                    and args[0].grad_fn is not None and torch.is_grad_enabled() \
+                    and sys.getrefcount(args[0]) <= _IADD_BASE_REFS and _caller_runs_augmented_add():
+                # an augmented assignment whose target is referenced by its own variable only: nobody can observe when
+                # (or whether) the tensor is updated.  Aliased tensors, attributes, `.add_()` calls keep the eager add.
                 return DeferredSum(args[0], args[1])
             if func is F.interpolate and args and isinstance(args[0], DeferredSum):
                 s = args[0]
-                if s._value is None and kwargs.get("mode") == "bilinear" and kwargs.get("align_corners") \
-                        and not kwargs.get("antialias", False):
-                    return upsample_presum(s.a, s.b, size=kwargs.get("size"), scale_factor=kwargs.get("scale_factor"))
+                size = kwargs.get("size", args[1] if len(args) > 1 else None)
+                scale = kwargs.get("scale_factor", args[2] if len(args) > 2 else None)
+                mode = kwargs.get("mode", args[3] if len(args) > 3 else "nearest")
+                ac = kwargs.get("align_corners", args[4] if len(args) > 4 else None)
+                if s._value is None and s.unchanged() and mode == "bilinear" and ac \
+                        and (size is not None or scale is not None) and not kwargs.get("antialias", False):
+                    return upsample_presum(s.a, s.b, size=size, scale_factor=scale)
         if self.head and func is F.interpolate and args and _is_map(args[0]) and torch.is_grad_enabled() \
                 and args[0].requires_grad and kwargs.get("mode") == "bilinear" and kwargs.get("align_corners") \
                 and not kwargs.get("antialias", False):

@@ -460,8 +460,11 @@ class HipKernels:
     def upsample_presum_fwd(self, x, x2, OH, OW):
         """up(x + x2) for two same-shaped tensors, both NCHW-contiguous or both channels_last-dense"""
         N, Cc, IH, IW = x.shape
-        if x2.shape != x.shape or x2.dtype != x.dtype or x2.stride() != x.stride():
-            raise L.TsgError("upsample_presum_fwd: the two addends must share shape, dtype and strides")
+        cl = torch.channels_last
+        same_layout = (x.is_contiguous() and x2.is_contiguous()) or \
+            (x.is_contiguous(memory_format=cl) and x2.is_contiguous(memory_format=cl))     # batch 1 / C 1: strides of
+        if x2.shape != x.shape or x2.dtype != x.dtype or not same_layout:                   # size-1 dims are free
+            raise L.TsgError("upsample_presum_fwd: the two addends must share shape, dtype and a dense layout")
         if x.is_contiguous():
             y = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device)
             L.check(self.lib.tsg_upsample_bilinear_ac_presum_fwd(x.data_ptr(), x2.data_ptr(), y.data_ptr(),
