@@ -3,8 +3,13 @@
 Cityscapes-shaped crops (BASELINE.json `metric`, configs[1]): bf16 activations,
 per-GPU batch 16, SyncBN + OHEM, SGD with the reference's 14 parameter groups.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config bisenet|pspnet|dfn|psanet]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+--config selects the BASELINE.json configuration at its PER-RANK shape (default bisenet = configs[1], the one the
+metric is quoted on): pspnet = configs[2] PSPNet-R50_v1c 2 x 720^2, 150 classes (713 is not a legal crop, SURVEY 8d);
+dfn = configs[3] DFN-R101_v1c 2 x 1024^2, 4 CE + 4 focal heads; psanet = configs[4] PSANet-R101_v1c 2 x 480^2 (473 is
+not legal).  Same JSON schema for every config.
 
 A step = zero_grad -> loss = model(imgs, gts) -> backward (incl. bucketed RCCL
 gradient all-reduce) -> SGD step, i.e. the body of the reference's loop
@@ -30,37 +35,86 @@ NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
 
 
-def build_model(device, batch, size, criterion_cls, norm_layer, seed=12345, fused_sgd=False):
+CONFIGS = {
+    # name: (per-rank batch, crop, classes, BASELINE.json configs index, reference experiment directory)
+    "bisenet": dict(batch=16, size=1024, classes=19, idx=1, model="BiSeNet-R18", ref="model/bisenet/cityscapes.bisenet.R18"),
+    "pspnet": dict(batch=2, size=720, classes=150, idx=2, model="PSPNet-R50_v1c", ref="model/pspnet/ade.pspnet.R50_v1c"),
+    "dfn": dict(batch=2, size=1024, classes=19, idx=3, model="DFN-R101_v1c", ref="model/dfn/cityscapes.dfn.R101_v1c"),
+    "psanet": dict(batch=2, size=480, classes=150, idx=4, model="PSANet-R101_v1c", ref="model/psanet/ade.psanet.R101_v1c"),
+}
+
+
+def _optimizer(groups, lr, wd, fused_sgd):
+    if fused_sgd:
+        from torchseg_amd.optim import FusedSGD                        # same update, one HIP launch for all tensors
+        return FusedSGD(groups, lr=lr, momentum=0.9, weight_decay=wd)
+    return torch.optim.SGD(groups, lr=lr, momentum=0.9, weight_decay=wd)
+
+
+def build_model(device, batch, size, criterion_cls, norm_layer, seed=12345, fused_sgd=False, config="bisenet",
+                focal_cls=None, dropout=True):
+    """Model + optimizer of one BASELINE config exactly as the reference's train.py builds them (bisenet train.py:48-89;
+    pspnet / psanet train.py:48-80; dfn train.py:48-78).  `criterion_cls` is the OHEM criterion class for bisenet (ours
+    on the GPU, the oracle's on the CPU); the other families use nn.CrossEntropyLoss as the reference does, DFN's
+    border heads `focal_cls` (ours / the oracle's SigmoidFocalLoss)."""
     from torchseg_amd.workloads import ensure_furnace_on_path
     ensure_furnace_on_path()
-    from torchseg_amd.workloads.bisenet import BiSeNet
     from utils.init_func import group_weight, init_weight
     torch.manual_seed(seed)
-    min_kept = int(batch * size * size // 16)                          # train.py:48-49
-    criterion = criterion_cls(ignore_label=255, thresh=0.7, min_kept=min_kept, use_weight=False)
-    model = BiSeNet(NUM_CLASSES, is_training=True, criterion=criterion, pretrained_model=None,
-                    norm_layer=norm_layer)
-    init_weight(model.business_layer, nn.init.kaiming_normal_, norm_layer, 1e-5, 0.1,
-                mode='fan_in', nonlinearity='relu')                    # train.py:61-63
-    base_lr = 1e-2
     groups = []
-    groups = group_weight(groups, model.context_path, norm_layer, base_lr)
-    for part in (model.spatial_path, model.global_context, model.arms, model.refines, model.heads, model.ffm):
-        groups = group_weight(groups, part, norm_layer, base_lr * 10)  # train.py:70-84
-    model.to(device)
-    if fused_sgd:
-        from torchseg_amd.optim import FusedSGD                        # same update, one HIP kernel per tensor
-        opt = FusedSGD(groups, lr=base_lr, momentum=0.9, weight_decay=5e-4)
+    if config == "bisenet":
+        from torchseg_amd.workloads.bisenet import BiSeNet
+        min_kept = int(batch * size * size // 16)                      # train.py:48-49
+        criterion = criterion_cls(ignore_label=255, thresh=0.7, min_kept=min_kept, use_weight=False)
+        model = BiSeNet(NUM_CLASSES, is_training=True, criterion=criterion, pretrained_model=None,
+                        norm_layer=norm_layer)
+        init_weight(model.business_layer, nn.init.kaiming_normal_, norm_layer, 1e-5, 0.1,
+                    mode='fan_in', nonlinearity='relu')                # train.py:61-63
+        base_lr, wd = 1e-2, 5e-4
+        groups = group_weight(groups, model.context_path, norm_layer, base_lr)
+        for part in (model.spatial_path, model.global_context, model.arms, model.refines, model.heads, model.ffm):
+            groups = group_weight(groups, part, norm_layer, base_lr * 10)  # train.py:70-84
     else:
-        opt = torch.optim.SGD(groups, lr=base_lr, momentum=0.9, weight_decay=5e-4)   # train.py:86-89
-    return model, opt, base_lr
+        if config == "dfn":
+            from torchseg_amd.workloads.dfn import DFN
+            model = DFN(19, nn.CrossEntropyLoss(reduction='mean', ignore_index=255), focal_cls(255, 2.0, 0.25), 0.1,
+                        None, norm_layer)                              # dfn train.py:48-58, config.py:76
+            base_lr, wd = 7e-4, 1e-4                                   # dfn config.py:79-82
+        else:
+            from torchseg_amd.workloads.pspnet import PSANet, PSPNet
+            cls, depth = (PSPNet, 50) if config == "pspnet" else (PSANet, 101)
+            model = cls(150, nn.CrossEntropyLoss(reduction='mean', ignore_index=-1), None, norm_layer, depth=depth)
+            base_lr, wd = 1e-2, 1e-4                                   # pspnet / psanet config.py:76-79 / 80-83
+        if not dropout:
+            for m in model.modules():
+                if isinstance(m, nn.Dropout2d):
+                    m.p = 0.0                                          # parity runs: CPU and GPU RNG streams differ
+        init_weight(model.business_layer, nn.init.kaiming_normal_, norm_layer, 1e-5, 0.1,
+                    mode='fan_in', nonlinearity='relu')
+        groups = group_weight(groups, model.backbone, norm_layer, base_lr)
+        for part in model.business_layer:
+            groups = group_weight(groups, part, norm_layer, base_lr * 10)
+    model.to(device)
+    return model, _optimizer(groups, base_lr, wd, fused_sgd), base_lr
 
 
-def synthetic_batch(device, batch, size, seed=0):
+def synthetic_batch(device, batch, size, seed=0, config="bisenet", label_dtype=torch.int64):
+    """x ~ N(0,1), labels uniform over the classes with rows 0-7 ignored.  `label_dtype` uint8 is what the
+    GPU loader (torchseg_amd.data) emits for the 19-class / ignore-255 families: the criteria read 1 B instead of
+    8 B per pixel and head (the CPU oracle indexes with int64)."""
     g = torch.Generator(device=device).manual_seed(seed)
+    classes = CONFIGS[config]["classes"]
     imgs = torch.randn(batch, 3, size, size, generator=g, device=device)
-    gts = torch.randint(0, NUM_CLASSES, (batch, size, size), generator=g, device=device)
+    gts = torch.randint(0, classes, (batch, size, size), generator=g, device=device)
+    if config in ("pspnet", "psanet"):
+        gts[:, :8] = -1                                                # ADE: ignore_index -1 (train.py:48-49)
+        return imgs, gts
     gts[:, :8] = 255
+    gts = gts.to(label_dtype)
+    if config == "dfn":                                                # border labels in {0, 1, 255} (dfn dataloader.py:24-29)
+        edge = torch.randint(0, 2, (batch, size, size), generator=g, device=device)
+        edge[:, :, :8] = 255
+        return imgs, gts, edge.to(label_dtype)
     return imgs, gts
 
 
@@ -72,10 +126,10 @@ def set_lr(opt, lr_policy, it):
         opt.refresh_lr()                                               # device-side lr for graph replay
 
 
-def step_body(model, opt, imgs, gts, world, with_optimizer=True):
+def step_body(model, opt, batch, world, with_optimizer=True):
     from utils.pyt_utils import all_reduce_tensor
     opt.zero_grad()
-    loss = model(imgs, gts)
+    loss = model(*batch)
     if world > 1 or dist.is_initialized():
         all_reduce_tensor(loss, world_size=world)                      # train.py:129-131
     loss.backward()
@@ -84,9 +138,9 @@ def step_body(model, opt, imgs, gts, world, with_optimizer=True):
     return loss
 
 
-def train_step(model, opt, imgs, gts, lr_policy, it, world):
+def train_step(model, opt, batch, lr_policy, it, world):
     set_lr(opt, lr_policy, it)
-    return step_body(model, opt, imgs, gts, world)
+    return step_body(model, opt, batch, world)
 
 
 class GraphedStep(object):
@@ -111,13 +165,13 @@ class GraphedStep(object):
             cls.stream = torch.cuda.Stream()
         return cls.stream
 
-    def __init__(self, model, opt, imgs, gts, world, opt_inside=False):
+    def __init__(self, model, opt, batch, world, opt_inside=False):
         self.graph = torch.cuda.CUDAGraph()
         self.opt = opt
         self.opt_inside = bool(opt_inside)
         opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph, stream=self.capture_stream()):
-            self.loss = step_body(model, opt, imgs, gts, world, with_optimizer=self.opt_inside)
+            self.loss = step_body(model, opt, batch, world, with_optimizer=self.opt_inside)
 
     def __call__(self):
         self.graph.replay()
@@ -126,23 +180,103 @@ class GraphedStep(object):
         return self.loss
 
 
-def _cpu_leg(size, batch, cores, budget_s, max_steps):
+def _cpu_leg(size, batch, cores, budget_s, max_steps, config="bisenet", warm=True):
     """img/s of the oracle network (1 untimed warm-up step, then steps until `budget_s` or `max_steps`)."""
+    from oracle.focal_ref import SigmoidFocalLoss as OracleFocal
     from oracle.ohem_ref import ProbOhemCrossEntropy2d as OracleOhem
     from engine.lr_policy import PolyLR
     dev = torch.device("cpu")
-    model, opt, base_lr = build_model(dev, batch, size, OracleOhem, nn.BatchNorm2d)
+    model, opt, base_lr = build_model(dev, batch, size, OracleOhem, nn.BatchNorm2d, config=config, focal_cls=OracleFocal)
     model.train()
-    imgs, gts = synthetic_batch(dev, batch, size)
+    data = synthetic_batch(dev, batch, size, config=config)
     pol = PolyLR(base_lr, 0.9, 80000)
-    train_step(model, opt, imgs, gts, pol, 0, 1)                       # warm-up (thread pool, allocator)
+    if warm:
+        train_step(model, opt, data, pol, 0, 1)                        # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
     done = 0
     while done < max_steps and (done < 1 or time.perf_counter() - t0 < budget_s):
-        train_step(model, opt, imgs, gts, pol, done + 1, 1)
+        train_step(model, opt, data, pol, done + 1, 1)
         done += 1
     dt = time.perf_counter() - t0
     return round(batch * done / dt, 3), done
+
+
+def cpu_baseline_family(config):
+    """cpu_baseline for --config pspnet|dfn|psanet: the same oracle network (nn.BatchNorm2d, nn.CrossEntropyLoss, the
+    loss_opr.py focal restatement) at the bench shape: ONE timed step, no warm-up step (a step of these networks is
+    20-90 s of host time, against which thread-pool start-up is noise)."""
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    cfg = CONFIGS[config]
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 64)
+    torch.set_num_threads(cores)
+    v, n = _cpu_leg(cfg["size"], cfg["batch"], cores, 0.0, 1, config, warm=False)
+    return {"value": v, "unit": "img/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
+            "sample": f"{n} step (no warm-up step at this size) of batch {cfg['batch']} at {cfg['size']}x{cfg['size']}, fp32, "
+                      f"torch CPU, oracle {cfg['model']} (nn.BatchNorm2d + nn.CrossEntropyLoss"
+                      + (" + loss_opr.py focal restatement" if config == "dfn" else "") + " + torch.optim.SGD)"}
+
+
+def ohem_kth_branch_probe(device, batch, size, reps=5):
+    """One BiSeNet head (fused upsample -> OHEM, the path the step takes) on TRAINED-LIKE logits in the spirit of SURVEY
+    8(d): 8 * onehot(label') + N(0,1) at 1/8 resolution, generator seed 1.  For the k-th-value branch of
+    loss_opr.py:84-90 fewer than min_kept = P/16 pixels may have p_target <= 0.7, so the labels are constant over 512 x
+    512 regions (the bilinear up-sampling blurs the logits along region borders: ~3 % of the pixels) and label' re-draws
+    1 % of the low-resolution pixels (SURVEY's 10 % at full resolution would leave > P/16 hard pixels and the threshold
+    branch).  Random-init logits (the timed step) give p_target ~ 1/19 << 0.7, so every step takes the threshold branch and the
+    k-th-value machinery (radix select over 16.8 M probabilities: sel_refine, ohem_pass_c) exits early; the reference
+    would run its full torch.sort there all the same (loss_opr.py:84-90).  This record puts the cost of the k-th branch
+    in front of the driver: forward / forward+backward time per head in both regimes, and what the selection did."""
+    from torchseg_amd.losses import ohem_cross_entropy
+    from torchseg_amd.upsample import DeferredUpsample
+    g = torch.Generator(device=device).manual_seed(1)
+    low = size // 8
+    cells = max(low // 64, 1)
+    lab_low = torch.randint(0, NUM_CLASSES, (batch, cells, cells), generator=g, device=device)
+    lab_low = lab_low.repeat_interleave(low // cells, 1).repeat_interleave(low // cells, 2)
+    target = lab_low.repeat_interleave(8, 1).repeat_interleave(8, 2)
+    redraw = torch.rand(batch, low, low, generator=g, device=device) < 0.01
+    lab2 = torch.where(redraw, torch.randint(0, NUM_CLASSES, (batch, low, low), generator=g, device=device), lab_low)
+    z_tr = (8.0 * torch.nn.functional.one_hot(lab2, NUM_CLASSES).permute(0, 3, 1, 2).float()
+            + torch.randn(batch, NUM_CLASSES, low, low, generator=g, device=device)).to(torch.bfloat16)
+    z_rand = torch.randn(batch, NUM_CLASSES, low, low, generator=g, device=device).to(torch.bfloat16)
+    target[:, :8] = 255
+    target = target.to(torch.uint8)
+    k = batch * size * size // 16
+    out = {"shape": f"{batch}x{NUM_CLASSES}x{low}^2 -> {size}^2 bf16, uint8 labels, min_kept {k}, thresh 0.7"}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return round(a.elapsed_time(b) / reps * 1e3, 1)
+
+    for name, z0 in (("trained_like", z_tr), ("random_init", z_rand)):
+        z = z0.clone().requires_grad_(True)
+
+        def fwd():
+            return ohem_cross_entropy(DeferredUpsample(z, (size, size)), target, 255, 0.7, k, return_selection=True)
+
+        def fb():
+            z.grad = None
+            fwd()[0].backward()
+        with torch.no_grad():
+            t_f = timed(fwd)
+        t_fb = timed(fb)
+        loss, sel = fwd()
+        sel = sel.cpu()
+        thr = float(sel[0:1].view(torch.float32).item())
+        out[name] = {"fwd_us": t_f, "fwd_bwd_us": t_fb, "threshold": round(thr, 6), "kept": int(sel[1]),
+                     "valid": int(sel[2]), "kth_branch_taken": bool(thr > 0.7 + 1e-7), "loss": round(float(loss), 5)}
+    out["selection_tail_us"] = round(out["trained_like"]["fwd_us"] - out["random_init"]["fwd_us"], 1)
+    return out
 
 
 def cpu_baseline(headline=True):
@@ -154,15 +288,16 @@ def cpu_baseline(headline=True):
     /root/reference does not exist on the GPU box, hence kind = "port"."""
     from torchseg_amd.workloads import ensure_furnace_on_path
     ensure_furnace_on_path()
-    cores = min(os.cpu_count() or 1, 64)       # torch's CPU conv stops scaling (and oversubscribes) beyond this
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 64)                      # torch's CPU conv stops scaling (and oversubscribes) beyond this
     torch.set_num_threads(cores)
     v512, n512 = _cpu_leg(512, 2, cores, 6.0, 5)
-    out = {"value": v512, "unit": "img/s", "cores": cores, "kind": "port",
+    out = {"value": v512, "unit": "img/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
            "sample": f"{n512} steps (after 1 warm-up) of batch 2 at 512x512 (BASELINE configs[0] shape), fp32, "
                      f"torch CPU, oracle BiSeNet-R18 (nn.BatchNorm2d + loss_opr restatement)"}
     if headline:
         v1024, n1024 = _cpu_leg(1024, 2, cores, 15.0, 3)
-        out = {"value": v1024, "unit": "img/s", "cores": cores, "kind": "port",
+        out = {"value": v1024, "unit": "img/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
                "sample": f"{n1024} steps (after 1 warm-up) of batch 2 at 1024x1024 (the headline crop of BASELINE "
                          f"configs[1]; batch reduced from 16 to bound the sample), fp32, torch CPU, oracle "
                          f"BiSeNet-R18 (nn.BatchNorm2d + loss_opr restatement + torch.optim.SGD)",
@@ -216,8 +351,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)       # >= 20 warm-up + >= 50 timed steps
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--config", default="bisenet", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration at its per-rank shape (default: configs[1], the headline)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--size", type=int, default=None, help="crop (default: the config's)")
+    ap.add_argument("--labels", default=None, choices=["u8", "i64"],
+                    help="label dtype on the device: u8 (what the GPU loader emits; default for the ignore-255 families) "
+                         "or i64 (what the reference's DataLoader hands over)")
+    ap.add_argument("--no-ohem-probe", action="store_true", help="skip the k-th-branch head record (bisenet only)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-headline", type=int, default=1,
@@ -232,6 +373,13 @@ def main():
     ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "0")),
                     help="torch.backends.cudnn.benchmark (train.py:35); 0 = immediate mode on the shipped MIOpen find-db (same speed, 100 s faster start)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = cfg["batch"]
+    if args.size is None:
+        args.size = cfg["size"]
+    if args.labels is None:
+        args.labels = "u8" if args.config in ("bisenet", "dfn") else "i64"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))             # plain `python bench.py --gpus N`
@@ -265,7 +413,7 @@ def main():
 
     from torchseg_amd import kernels as K
     from torchseg_amd.ddp import DistributedDataParallel
-    from torchseg_amd.losses import ProbOhemCrossEntropy2d
+    from torchseg_amd.losses import ProbOhemCrossEntropy2d, SigmoidFocalLoss
     from torchseg_amd.syncbn import SyncBatchNorm
     from torchseg_amd.workloads import ensure_furnace_on_path
     ensure_furnace_on_path()
@@ -274,10 +422,12 @@ def main():
     use_graph = bool(args.graph)
     model, opt, base_lr = build_model(device, args.batch, args.size, ProbOhemCrossEntropy2d, SyncBatchNorm,
                                       seed=12345 if world == 1 else local_rank,       # train.py:37-40
-                                      fused_sgd=args.optimizer == "fused")
+                                      fused_sgd=args.optimizer == "fused", config=args.config,
+                                      focal_cls=SigmoidFocalLoss)
     model = DistributedDataParallel(model)                             # train.py:98-99
     model.train()
-    imgs, gts = synthetic_batch(device, args.batch, args.size, seed=rank)
+    batch = synthetic_batch(device, args.batch, args.size, seed=rank, config=args.config,
+                            label_dtype=torch.uint8 if args.labels == "u8" else torch.int64)
     pol = PolyLR(base_lr, 0.9, 80 * 1000)
 
     def sync():
@@ -304,7 +454,7 @@ def main():
             probe = None
             if not args.no_kernel_timing and it == n_eager - 1:
                 probe = K.KernelTimer(K.provider())
-            loss = train_step(model, opt, imgs, gts, pol, it, world)
+            loss = train_step(model, opt, batch, pol, it, world)
             if probe is not None:
                 probe.stop()
                 dominant = probe.dominant()
@@ -313,7 +463,7 @@ def main():
         sync()
         graphed = None
         if use_graph:
-            graphed = GraphedStep(model, opt, imgs, gts, world, opt_inside=args.graph == 2)
+            graphed = GraphedStep(model, opt, batch, world, opt_inside=args.graph == 2)
             for it in range(2):                                            # untimed replays
                 set_lr(opt, pol, n_eager + it)
                 loss = graphed()
@@ -326,7 +476,7 @@ def main():
                 set_lr(opt, pol, args.warmup + it)
                 loss = graphed()
             else:
-                loss = train_step(model, opt, imgs, gts, pol, args.warmup + it, world)
+                loss = train_step(model, opt, batch, pol, args.warmup + it, world)
             if args.trace_loss and rank == 0:
                 print("step", it, "loss", float(loss.item()), "lr", opt.param_groups[0]["lr"], file=sys.stderr, flush=True)
         sync()
@@ -350,13 +500,18 @@ def main():
         global_batch = args.batch * world
         value = global_batch * args.steps / dt
         out = {
-            "metric": "training images/sec (1024x1024) BiSeNet-R18",
+            "metric": "training images/sec (1024x1024) BiSeNet-R18" if args.config == "bisenet"
+                      else f"training images/sec ({args.size}x{args.size}) {cfg['model']}",
             "value": round(value, 2), "unit": "img/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BiSeNet-R18 {args.dtype} batch {args.batch}/GPU {args.size}x{args.size} "
-                                   f"synthetic crops, SyncBN + OHEM (BASELINE configs[1])",
+            "config": {"workload": f"{cfg['model']} {args.dtype} batch {args.batch}/GPU {args.size}x{args.size} synthetic crops, "
+                                   + {"bisenet": "SyncBN + OHEM", "pspnet": "SyncBN, 150 classes, 2 CE heads",
+                                      "dfn": "SyncBN, 4 CE + 4 sigmoid-focal heads",
+                                      "psanet": "SyncBN, 150 classes, collect/distribute attention (MFMA)"}[args.config]
+                                   + f" (BASELINE configs[{cfg['idx']}], per-rank shape; {cfg['ref']})",
+                       "labels": args.labels,
                        "global_batch": global_batch, "parallelism": f"dp{world}",
                        "channels_last": model.channels_last, "final_loss": round(final_loss, 4),
                        "hip_graph": bool(use_graph), "optimizer": args.optimizer},
@@ -366,7 +521,7 @@ def main():
             out["roofline"]["measured_over"] = ("instrumented eager warm-up step (hipGraph replay has no host-side "
                                                 "launches to bracket)") if use_graph else "timed region"
             out["kernels_last_warmup_step"] = all_kernels
-        if args.dtype == "bf16" and args.size == 1024:
+        if args.config == "bisenet" and args.dtype == "bf16" and args.size == 1024:
             # whole-step HBM roofline of SURVEY.md 8(d): ~3.4 GB of algorithmic traffic per image in bf16 (our
             # kernels 2.16 GB + the convolutions' operands once each + pools) => 2350 img/s per GPU at 8 TB/s
             gb_per_img = 3.4
@@ -374,8 +529,11 @@ def main():
             out["step_roofline"] = {"bound": "hbm", "algo_GB_per_img": gb_per_img,
                                     "achieved": round(per_gpu * gb_per_img, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(per_gpu * gb_per_img / HBM_PEAK_GBS, 4), "target_frac": 0.70}
+        if args.config == "bisenet" and world == 1 and not args.no_ohem_probe and args.dtype == "bf16":
+            out["ohem_kth_branch"] = ohem_kth_branch_probe(device, args.batch, args.size)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(headline=bool(args.cpu_headline))
+            out["cpu_baseline"] = cpu_baseline(headline=bool(args.cpu_headline)) if args.config == "bisenet" \
+                else cpu_baseline_family(args.config)
     if world > 1 or force_coll:
         from torchseg_amd import comm as tsg_comm
         tsg_comm.shutdown()

@@ -309,6 +309,32 @@ int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B
 int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int I, void* stream);
 
 /* ------------------------------------------------------------------------
+ * General 3x3 / stride 1 / padding 1 convolution forward (csrc/conv3g.hip): C_in a multiple of 16, C_out a multiple
+ * of 64 — ResNet layer2-4's conv3x3 (furnace/base_model/resnet.py:24-29,36-53), BiSeNet's attention-refinement 3x3,
+ * refines and heads (bisenet network.py:43-52,140-156): the cuDNN forward calls of the reference and, fed dy and the
+ * mode-1 filter, its cuDNN backward-data calls (the data gradient of a stride-1 3x3 convolution is the forward
+ * convolution of dy with the rotated, transposed filter).
+ *   tsg_conv3x3_gen_tile: output channels per block (64 or 128) chosen for a problem size; the prepared filter is laid
+ *     out for that width, so pass the same value (BN) to the preparation, the partial count and the forward call.
+ *   tsg_conv3x3_gen_prep_filter: master weight w [O][3][3][I] (fp32 or bf16, the channels_last filter layout) ->
+ *     out: tsg_conv3x3_gen_filter_elems() bf16 in MFMA fragment order (csrc/conv3g.hip).  mode 0: the forward filter
+ *     (the convolution then has C_out = O, C_in = I); mode 1: rot180 + transpose (C_out = I, C_in = O).
+ *   tsg_conv3x3_gen_fwd: x [B,H,W,Cin] -> y [B,H,W,Cout], bf16 channels_last, fp32 accumulation.  partial (may be NULL):
+ *     [S][2][Cout] fp32 sums / square sums of the bf16-rounded outputs, S = tsg_conv3x3_gen_stats_partials(...): the
+ *     layout tsg_bn_finalize / tsg_bn_collapse take.  in_ab (may be NULL; Cin <= 512): [2][Cin] fp32 a, b rows of a
+ *     BatchNorm forward pack: the convolution reads relu(a x + b) of x, bit-equal to tsg_bn_apply_fwd's output,
+ *     zero padding stays zero.
+ * ---------------------------------------------------------------------- */
+int tsg_conv3x3_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
+                              int groups);
+int64_t tsg_conv3x3_gen_filter_elems(int Cin, int Cout);
+int tsg_conv3x3_gen_tile(int64_t B, int64_t H, int64_t W, int Cin, int Cout);
+int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int I, int mode, int BN, void* stream);
+int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN);
+int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, int64_t B,
+                        int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream);
+
+/* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward
  * (furnace/seg_opr/loss_opr.py:68-98) and the nn.CrossEntropyLoss it ends in.
  * logits are [B, C, HW] (NCHW planar), labels [B*HW].
@@ -506,7 +532,7 @@ int tsg_sgd_step_dev(float* param, const float* grad, float* momentum_buf,
  * arrays per group.  blockmap_dev: device copy of the int pairs tsg_sgd_multi_blockmap writes
  * (static for a model); call it with map_host = NULL to get the block count. */
 #define TSG_SGD_MAX_SEGS   128
-#define TSG_SGD_MAX_GROUPS 16
+#define TSG_SGD_MAX_GROUPS 24
 int64_t tsg_sgd_multi_blockmap(const int64_t* numel, int nseg, int* map_host, int64_t cap_blocks);
 int tsg_sgd_multi_step_dev(const uint64_t* params, const uint64_t* grads, const uint64_t* bufs,
                            const int64_t* numel, const int* group, int nseg, const float* lr_dev,

@@ -1,0 +1,147 @@
+"""GPU parity of tsg_conv3x3_gen_fwd (csrc/conv3g.hip, through the C-ABI) with oracle/conv_ref.py on the same bf16-rounded
+operands (fp64 accumulation): y is bf16 -> one bf16 ulp of the fp64 result (2^-8 relative) plus 1e-3 of the output scale
+for cancellation.  Covers both oc-tile widths (C_out = 64 k: 64-wide; 128 k: 128-wide), several oc tiles, C_in from one
+chunk to many, partial pixel tiles (H, W not multiples of 8 / 32), the statistics epilogue, normalise-on-load, the
+mode-1 filter (= the data gradient of the same convolution) and the autograd node the DDP wrapper installs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import conv_ref
+
+pytestmark = pytest.mark.gpu
+
+# (B, Cin, Cout, H, W)
+SHAPES = [(2, 128, 128, 8, 32), (1, 16, 64, 5, 37), (2, 64, 128, 19, 70), (1, 128, 256, 16, 64), (3, 256, 64, 9, 33),
+          (1, 512, 512, 8, 32), (1, 32, 192, 1, 1), (2, 128, 128, 24, 96)]
+
+
+def _operands(cuda, B, Cin, Cout, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    xb = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    wd = w.to(cuda).contiguous(memory_format=torch.channels_last)          # fp32 master, channels_last
+    return x, w, xb, wd
+
+
+def _check(y, y_ref):
+    err = (y.double().cpu() - y_ref).abs()
+    bound = y_ref.abs() * 2.0 ** -8 + 1e-3 * y_ref.abs().max()
+    assert bool((err <= bound).all()), (err.max().item(), y_ref.abs().max().item())
+
+
+@pytest.fixture(params=["64", "128"])
+def tile_width(request, monkeypatch):
+    """Both oc-tile widths at every shape (the library picks 128 only for launches with >= 192 work items; C_out that is
+    not a multiple of 128 takes 64 either way)."""
+    from torchseg_amd import kernels as K
+    monkeypatch.setenv("TSG_CONV3G_BN", request.param)
+    K.provider()._npart.clear()                            # cached geometry answers depend on the override
+    yield request.param
+    K.provider()._npart.clear()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_vs_oracle(cuda, shape, tile_width):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    x, w, xb, wd = _operands(cuda, *shape, seed=sum(shape))
+    assert kp.conv3x3_gen_supported(xb, wd, 1, 1, 1, 1)
+    wf = kp.conv3x3_gen_prep_filter(wd, 0, xb)
+    y = kp.conv3x3_gen_fwd(xb, wf, Cout)
+    assert tuple(y.shape) == (B, Cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    _check(y, conv_ref.conv2d_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(w), stride=1, pad=1))
+    # a bf16 master gives the same prepared filter as the fp32 master rounded by the kernel
+    wf2 = kp.conv3x3_gen_prep_filter(wd.bfloat16().contiguous(memory_format=torch.channels_last), 0, xb)
+    assert torch.equal(wf[0], wf2[0]) and wf[1] == wf2[1]
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 70, 96), (1, 64, 256, 33, 40), (2, 256, 64, 16, 64)])
+def test_statistics_epilogue_and_determinism(cuda, shape, tile_width):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    x, w, xb, wd = _operands(cuda, *shape, seed=5)
+    wf = kp.conv3x3_gen_prep_filter(wd, 0, xb)
+    y, partial = kp.conv3x3_gen_fwd(xb, wf, Cout, with_stats=True)
+    assert torch.equal(y, kp.conv3x3_gen_fwd(xb, wf, Cout))
+    assert partial.shape[1:] == (2, Cout)
+    sums = partial.double().sum(0).cpu()
+    yf = y.double().cpu()
+    ref = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    np.testing.assert_allclose(sums.numpy(), ref.numpy(), rtol=2e-5, atol=2e-3)
+    y2, p2 = kp.conv3x3_gen_fwd(xb, wf, Cout, with_stats=True)
+    assert torch.equal(y, y2) and torch.equal(partial, p2)
+    # ... and they are what tsg_bn_stats computes from y (the pass the epilogue replaces), to fp32 summation order
+    layout, N, C, HW = K.bn_layout(y)
+    p_ref, S = kp.bn_stats(y, layout, N, C, HW)
+    np.testing.assert_allclose(sums.numpy(), p_ref[:S].double().sum(0).cpu().numpy(), rtol=2e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 12, 40), (1, 64, 128, 20, 33), (1, 512, 128, 8, 32)])
+def test_normalise_on_load_equals_bn_apply_then_conv(cuda, shape, tile_width):
+    """in_ab: the convolution reads relu(a x + b); bit-equal to tsg_bn_apply_fwd's output fed to the same kernel."""
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    x, w, xb, wd = _operands(cuda, *shape, seed=8)
+    g = torch.Generator().manual_seed(1)
+    a = (torch.rand(Cin, generator=g) + 0.5).to(cuda)
+    b = (torch.randn(Cin, generator=g) * 0.3).to(cuda)
+    fp = torch.stack([a, b, torch.zeros_like(a)]).contiguous()
+    wf = kp.conv3x3_gen_prep_filter(wd, 0, xb)
+    layout, N, C, HW = K.bn_layout(xb)
+    xn = kp.bn_apply_fwd(xb, None, layout, N, C, HW, fp, True)
+    want = kp.conv3x3_gen_fwd(xn, wf, Cout)
+    got = kp.conv3x3_gen_fwd(xb, wf, Cout, in_ab=fp)
+    assert torch.equal(got, want)
+    ref_in = torch.relu(conv_ref.bf16_round(x) * a.cpu().view(1, -1, 1, 1) + b.cpu().view(1, -1, 1, 1))
+    _check(got, conv_ref.conv2d_ref(conv_ref.bf16_round(ref_in), conv_ref.bf16_round(w), stride=1, pad=1))
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 24, 40), (1, 64, 256, 9, 33), (2, 256, 64, 8, 32)])
+def test_mode1_filter_is_the_data_gradient(cuda, shape, tile_width):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    x, w, xb, wd = _operands(cuda, *shape, seed=11)
+    g = torch.Generator().manual_seed(2)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dx = kp.conv3x3_gen_fwd(dyb, kp.conv3x3_gen_prep_filter(wd, 1, dyb), Cin)
+    xr = conv_ref.bf16_round(x).double().requires_grad_(True)
+    yr = F.conv2d(xr, conv_ref.bf16_round(w).double(), None, 1, 1)
+    yr.backward(conv_ref.bf16_round(dy).double())
+    _check(dx, xr.grad)
+
+
+def test_autograd_node_installed_by_the_wrapper(cuda):
+    """nn.Conv2d(128, 128, 3, padding=1) re-classed by install_conv_wrw: forward, dx, dw against torch in fp64 on the
+    bf16-rounded operands; the output carries the statistics partial for the SyncBatchNorm behind it."""
+    import torch.nn as nn
+    from torchseg_amd.convwrw import WrwConv2d, install_conv_wrw
+    from torchseg_amd.stemconv import take_bn_partial
+    torch.manual_seed(3)
+    conv = nn.Conv2d(128, 256, 3, padding=1, bias=False).to(cuda)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    assert install_conv_wrw(conv) == 1 and isinstance(conv, WrwConv2d)
+    conv.train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 128, 16, 40, generator=g)
+    dy = torch.randn(2, 256, 16, 40, generator=g)
+    xd = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv(xd)
+    part = take_bn_partial(y)
+    assert part is not None and part.shape[1:] == (2, 256)
+    y.backward(dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last))
+    xr = conv_ref.bf16_round(x).double().requires_grad_(True)
+    wr = conv_ref.bf16_round(conv.weight.detach().cpu().float()).double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(conv_ref.bf16_round(dy).double())
+    _check(y.detach(), yr.detach())
+    _check(xd.grad, xr.grad)
+    dw = conv.weight.grad.double().cpu()
+    assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()

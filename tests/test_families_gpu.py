@@ -1,8 +1,11 @@
-"""One training step of each BASELINE.json model family other than BiSeNet (configs 3-5:
-PSPNet-R50, DFN-R101, PSANet-R50 at reduced crop) through the HIP path on the GPU, against the
-same network on the CPU with torch BatchNorm, the oracle focal loss and identical weights.
+"""One training step of each BASELINE.json model family other than BiSeNet AT THE PER-RANK SHAPE bench.py --config
+times (configs 3-5: PSPNet-R50_v1c 2 x 720^2, DFN-R101_v1c 2 x 1024^2, PSANet-R101_v1c 2 x 480^2; round 2 tested 64^2 -
+128^2 crops and PSANet-R50) through the HIP path on the GPU, in fp32, against the same network on the CPU (the oracle:
+torch BatchNorm, nn.CrossEntropyLoss, the loss_opr.py focal restatement) with identical weights and inputs.  The
+models, inputs and optimizer groups come from bench.build_model / bench.synthetic_batch, so what is checked is what
+is timed.  A CPU step of these networks takes 10-60 s on the GPU box's host cores.
 
-Tolerances (fp32).  Loss: 1e-5 relative.  Gradients: a randomly initialised 50/101-layer
+Tolerances (fp32).  Loss: 1e-4 relative (north_star), 1e-5 measured.  Gradients: a randomly initialised 50/101-layer
 network is ill-conditioned in fp32 (the error energy sits in the deep-stem weights; stock torch
 on the same GPU -- MIOpen convs + torch BatchNorm/losses -- is 2.5e-2 .. 8.3e-2 away from the
 CPU over all parameters and 0.7e-2 .. 1.6e-2 over the heads: tools/debug_families.py, DESIGN.md
@@ -10,53 +13,44 @@ section 4a), so the bound is stated against that: over the heads (everything out
 and over all parameters, our path may be at most 2x as far from the CPU in relative L2 as stock
 torch on the same device is.  Measured: ours 0.8e-2 .. 1.3e-2 (heads), 2.1e-2 .. 6.5e-2 (all),
 i.e. closer to the CPU than stock torch in 5 of the 6 numbers."""
+import os
+import sys
+
 import pytest
 import torch
 import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 pytestmark = pytest.mark.gpu
 
 
 def _build(kind, norm, gpu):
-    torch.manual_seed(77)
-    if kind == "dfn":
-        from torchseg_amd.workloads.dfn import DFN
-        if gpu:
-            from torchseg_amd.losses import SigmoidFocalLoss
-        else:
-            from oracle.focal_ref import SigmoidFocalLoss
-        return DFN(19, nn.CrossEntropyLoss(reduction='mean', ignore_index=255),
-                   SigmoidFocalLoss(255, 2.0, 0.25), 0.1, None, norm)
-    from torchseg_amd.workloads.pspnet import PSANet, PSPNet
-    cls = PSPNet if kind == "pspnet" else PSANet
-    net = cls(150, nn.CrossEntropyLoss(reduction='mean', ignore_index=-1), None, norm, depth=50)
-    for m in net.modules():
-        if isinstance(m, nn.Dropout2d):
-            m.p = 0.0               # CPU and GPU RNG streams differ
+    import bench
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    if gpu:
+        from torchseg_amd.losses import SigmoidFocalLoss
+    else:
+        from oracle.focal_ref import SigmoidFocalLoss
+    cfg = bench.CONFIGS[kind]
+    # dropout off: CPU and GPU RNG streams differ
+    net, _, _ = bench.build_model(torch.device("cpu"), cfg["batch"], cfg["size"], None, norm, seed=77, config=kind,
+                                  focal_cls=SigmoidFocalLoss, dropout=False)
     return net
 
 
 def _batch(kind):
-    g = torch.Generator().manual_seed(5)
-    if kind == "dfn":
-        B, S = 8, 128
-        x = torch.randn(B, 3, S, S, generator=g)
-        y = torch.randint(0, 19, (B, S, S), generator=g)
-        y[:, :4] = 255
-        e = torch.randint(0, 2, (B, S, S), generator=g)
-        e[:, :, :4] = 255
-        return (x, y, e)
-    B, S = (8, 64) if kind == "pspnet" else (1, 480)
-    x = torch.randn(B, 3, S, S, generator=g)
-    y = torch.randint(0, 150, (B, S, S), generator=g)
-    y[:, :4] = -1
-    return (x, y)
+    import bench
+    cfg = bench.CONFIGS[kind]
+    return bench.synthetic_batch(torch.device("cpu"), cfg["batch"], cfg["size"], seed=5, config=kind)
 
 
 @pytest.mark.parametrize("kind", ["pspnet", "dfn", "psanet"])
 def test_family_step_matches_cpu(cuda, kind):
     from torchseg_amd.ddp import DistributedDataParallel
     from torchseg_amd.syncbn import SyncBatchNorm
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))      # torch's CPU convolutions stop scaling beyond this
     ref = _build(kind, nn.BatchNorm2d, False)
     net = _build(kind, SyncBatchNorm, True)
     net.load_state_dict(ref.state_dict())
@@ -92,7 +86,7 @@ def test_family_step_matches_cpu(cuda, kind):
     assert calls["psa_fwd"] == (2 if kind == "psanet" else 0), calls
     stock(*dbatch).backward()
     torch.cuda.synchronize()
-    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
 
     def rel(model, keep):
         num = den = 0.0

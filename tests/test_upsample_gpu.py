@@ -100,7 +100,10 @@ def test_aten_override_used_by_interpolate(cuda):
 
 
 @pytest.mark.parametrize("c,ih,iw,oh,ow", [(128, 1, 1, 32, 32), (128, 32, 32, 64, 64), (128, 64, 64, 128, 128),
-                                           (8, 7, 5, 13, 9), (16, 9, 9, 4, 3), (256, 6, 6, 60, 60)])
+                                           (8, 7, 5, 13, 9), (16, 9, 9, 4, 3), (256, 6, 6, 60, 60),
+                                           # PSPNet's pyramid pooling at 720^2 (pspnet network.py:101-106): small sources,
+                                           # footprints of up to 90 rows -> the row-split backward (up_bwd_nhwc_split)
+                                           (512, 2, 2, 90, 90), (512, 3, 3, 90, 90), (512, 6, 6, 90, 90), (24, 2, 3, 40, 17)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bilinear_channels_last(cuda, c, ih, iw, oh, ow, dtype):
     from torchseg_amd.upsample import upsample_bilinear_ac
@@ -120,6 +123,22 @@ def test_bilinear_channels_last(cuda, c, ih, iw, oh, ow, dtype):
     else:
         np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref, rtol=8e-3, atol=8e-3)
         np.testing.assert_allclose(xd.grad.float().cpu().numpy(), dx_ref, rtol=1e-2, atol=1e-2 * np.abs(dx_ref).max())
+
+
+def test_backward_of_a_channel_slice_stays_channels_last(cuda):
+    """torch.cat's backward hands the pyramid-pooling branches channel SLICES of a channels_last gradient (pixel stride
+    = all channels): they must take the NHWC gather (with its small-source path), not a copy to NCHW."""
+    from torchseg_amd.upsample import upsample_bilinear_ac
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 3, 3, generator=g)
+    big = torch.randn(2, 160, 45, 45, generator=g)
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = upsample_bilinear_ac(xd, size=(45, 45))
+    dyd = big.to(cuda).contiguous(memory_format=torch.channels_last)[:, 32:96]
+    assert dyd.stride(1) == 1 and not dyd.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dyd)
+    dx_ref = R.upsample_bilinear_ac_backward(big[:, 32:96].numpy(), 3, 3)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), dx_ref, rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -85,6 +85,53 @@ class _ConvWrwFn(torch.autograd.Function):
         return dx, dw.to(ctx.wdtype), None, None, None
 
 
+# TSG_CONV_GEN=1|0 (default 1): forward and data gradient of every other stride-1 3x3 layer (C_in % 16 == 0, C_out % 64
+# == 0) on tsg_conv3x3_gen_fwd (csrc/conv3g.hip) instead of the vendor library; TSG_CONV_GEN_STATS=1|0 (default 1): the
+# BatchNorm statistics of the output in its epilogue (every one of these convolutions feeds a SyncBatchNorm)
+_OWN_GEN = _os.environ.get("TSG_CONV_GEN", "1") != "0"
+_GEN_STATS = _os.environ.get("TSG_CONV_GEN_STATS", "1") != "0"
+
+
+class _ConvGenFn(torch.autograd.Function):
+    """conv3x3 / stride 1 / padding 1 on the general MFMA kernel: forward from the fp32 master weight (the bf16 cast
+    happens inside the filter preparation), data gradient as the forward convolution of dy with the rotated / transposed
+    filter, weight gradient on tsg_conv3x3_wrw_gen.  Second output: the statistics partial of y (or an empty tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, with_stats):
+        kp = K.provider()
+        wf = kp.conv3x3_gen_prep_filter(weight, 0, x)
+        out = kp.conv3x3_gen_fwd(x, wf, weight.shape[0], with_stats=with_stats)
+        y, partial = out if with_stats else (out, x.new_empty(0, dtype=torch.float32))
+        ctx.save_for_backward(x, weight)
+        ctx.need_dx = x.requires_grad
+        ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, dy, _dpartial):
+        kp = K.provider()
+        x, weight = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = None
+        if ctx.need_dx:
+            O, I = weight.shape[0], weight.shape[1]
+            if O % 16 == 0 and I % 64 == 0:
+                dx = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(weight, 1, dy), I)
+            else:
+                dx = F.conv2d(dy, kp.conv3x3_weight_rot180_t(weight.detach().to(torch.bfloat16)), None, 1, 1)
+        dw = kp.conv3x3_wrw(x, dy, stride=1)
+        return dx, dw.to(weight.dtype), None
+
+
+def _gen_eligible(xb, conv):
+    return (_OWN_GEN and conv.stride == (1, 1) and not (_OWN_C64 and conv.in_channels == 64 and conv.out_channels == 64)
+            and conv.weight.is_contiguous(memory_format=torch.channels_last)
+            and K.provider().conv3x3_gen_supported(xb, conv.weight, 1, conv.padding[0], conv.dilation[0], conv.groups))
+
+
 class WrwConv2d(nn.Conv2d):
     def forward(self, x):
         if (x.is_cuda and self.bias is None and self.weight.dtype == torch.float32 and x.dim() == 4
@@ -95,6 +142,13 @@ class WrwConv2d(nn.Conv2d):
             xb = xb.contiguous(memory_format=torch.channels_last)
             if K.provider().conv3x3_wrw_supported(xb, self.weight, self.stride[0], self.padding[0], self.dilation[0],
                                                   self.groups):
+                if _gen_eligible(xb, self):
+                    with torch.autocast("cuda", enabled=False):
+                        y, partial = _ConvGenFn.apply(xb, self.weight, _GEN_STATS and self.training)
+                    if partial.numel():
+                        from .stemconv import attach_bn_partial
+                        attach_bn_partial(y, partial)      # the SyncBatchNorm behind it skips its statistics pass
+                    return y
                 with torch.autocast("cuda", enabled=False):
                     if _SHADOW and self.weight.is_contiguous(memory_format=torch.channels_last):
                         from .shadow import bank           # bf16 (and rotated) filters kept fresh once per step

@@ -1,0 +1,399 @@
+// General 3x3 / stride 1 / padding 1 convolution, forward, on the bf16 MFMA, channels_last — every 3x3 layer of the
+// networks with C_in a multiple of 16 and C_out a multiple of 64 that csrc/conv64.hip (64 -> 64) does not cover:
+// ResNet-18 layer2-4 (furnace/base_model/resnet.py:24-29,36-53: 128 / 256 / 512 channels on 128^2 / 64^2 / 32^2 maps at
+// BASELINE config 2), BiSeNet's attention-refinement 3x3, refines and heads (bisenet network.py:43-52,140-156).  The
+// same kernel computes their DATA gradient: a stride-1 3x3 data gradient is the forward convolution of dy with the
+// 180-degree-rotated, transposed filter, which tsg_conv3x3_gen_prep_filter(mode 1) writes.
+//
+// Round 2 left these layers on the vendor library (0.62-0.91 PF forward, 25-35 % slower backward, no way to attach the
+// BatchNorm statistics of the output or the BatchNorm + ReLU of the input).  Shape of this kernel:
+//   * implicit GEMM, D[oc][pixel] += W[oc][tap, ci] * X[tap, ci][pixel]: A operand = filter, B operand = pixels, 32x32x16
+//     MFMAs, one K step = 16 input channels of one tap;
+//   * a block (8 waves, 2 per SIMD) owns 128 (or 64) output channels x an 8 x 32 pixel tile and walks the input channels
+//     in chunks of 16: per chunk the (8+2) x (32+2) x 16 input patch is staged ONCE and serves all nine taps from LDS
+//     (48-byte pixel stride: the 32 lanes of a ds_read_b128 fragment fall on distinct bank groups), and the 9 x BN x 16
+//     filter slab is a LINEAR copy: tsg_conv3x3_gen_prep_filter lays the filter out in MFMA fragment order
+//     [oc tile][chunk][tap][32-channel block][lane][8], so an A fragment is 1 KB of consecutive LDS (conflict-free by
+//     construction) — 166 staged bytes per MFMA against 512 for a 128 x 128 x 64 GEMM tile;
+//   * both LDS images are double-buffered: the global loads of chunk c+1 are issued before the 36 MFMAs per wave of
+//     chunk c and written behind them, one barrier per chunk;
+//   * a wave computes 64 oc x 2 rows x 32 pixels (4 accumulators); the 12 pixel fragments of a chunk (4 patch rows x 3
+//     column shifts) are read once and reused by the taps that share them: 30 LDS reads per 36 MFMAs;
+//   * blocks are persistent over the pixel tiles of one oc tile, mapped XCD-aware (blocks that read the same pixels for
+//     different oc tiles run on the same XCD at the same time, so the second read of x is an L2 hit);
+//   * epilogue through LDS (the filter buffers) so that every lane stores 16 B of NHWC; STATS: per-channel sum / square
+//     sum of the bf16-rounded outputs (the statistics pass of the SyncBatchNorm that follows these convolutions,
+//     legacy/sync_bn/syncbn.py:86-98) accumulated over the block's tiles, partial[slot][2][C_out];
+//   * AFF: the input is relu(a x + b) of the tensor that is read (BatchNorm + ReLU in front of the convolution,
+//     resnet.py:36-46), applied while the patch is written to LDS with the values tsg_bn_apply_fwd would have stored.
+// x, y: NHWC bf16.  wf: the prepared filter.  fp32 accumulation, one rounding to bf16 at the store.
+#include "tsg_common.h"
+#include <stdlib.h>
+
+namespace tsg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float g3_f32x16;
+
+constexpr int G3_TH = 8, G3_TW = 32;                     // output tile: 256 pixels
+constexpr int G3_PH = G3_TH + 2, G3_PW = G3_TW + 2;      // input patch
+constexpr int G3_KC = 16;                                // input channels per chunk
+constexpr int G3_PS = 24;                                // LDS pixel stride in bf16: 32 B of data + 16 B of padding
+constexpr int G3_NPX = G3_PH * G3_PW;                    // 340 patch pixels
+constexpr int G3_PATCH = G3_NPX * G3_PS;                 // bf16 elements of one patch buffer (16,320 B)
+constexpr int G3_NPV = G3_NPX * 2;                       // 16-byte vectors of a patch chunk: 680
+constexpr int G3_THREADS = 512;
+constexpr int G3_MAX_AFF_C = 512;                        // normalise-on-load: a / b rows staged in LDS
+
+struct G3Geom {
+  int B, H, W, Cin, Cout;
+  int tiles_h, tiles_w, ntiles;                          // pixel tiles (per oc tile)
+  int nchunks, noct, nslots;                             // Cin / 16, Cout / BN, persistent blocks per oc tile
+};
+
+template <int BN> struct G3Cfg {
+  static constexpr int NOB = BN / 64;                    // 32-channel blocks per wave
+  static constexpr int FELEMS = 9 * BN * G3_KC;          // bf16 elements of one filter slab
+  static constexpr int NFV = FELEMS / 8;                 // 16-byte vectors of a filter slab: 2304 / 1152
+  static constexpr int NFU = (NFV + G3_THREADS - 1) / G3_THREADS;   // per thread: 5 / 3 (the last one partly)
+  static constexpr int OS = BN + 8;                      // epilogue staging: bf16 per pixel row
+  static constexpr size_t LDS = (size_t)(2 * FELEMS + 2 * G3_PATCH) * 2 + 2 * G3_MAX_AFF_C * 4;
+  static_assert(256 * OS <= 2 * FELEMS, "the output tile is staged in the two filter buffers");
+};
+
+__device__ __forceinline__ uint4 g3_affine_relu(uint4 v, const float* __restrict__ a, const float* __restrict__ b) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+    const float y0 = fmaf(x0, a[2 * i], b[2 * i]), y1 = fmaf(x1, a[2 * i + 1], b[2 * i + 1]);
+    w[i] = pack2_bf16(y0 > 0.f ? y0 : 0.f, y1 > 0.f ? y1 : 0.f);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int BN, bool AFF, bool STATS>
+__global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                             bf16_t* __restrict__ y, G3Geom g,
+                                                             const float* __restrict__ in_ab,
+                                                             float* __restrict__ partial) {
+  using Cfg = G3Cfg<BN>;
+  constexpr int NOB = Cfg::NOB, NFU = Cfg::NFU, OS = Cfg::OS, OCB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
+  bf16_t* fbuf = reinterpret_cast<bf16_t*>(g3_smem);                       // [2][FELEMS]
+  bf16_t* pbuf = fbuf + 2 * Cfg::FELEMS;                                   // [2][G3_PATCH]
+  float* abs_ = reinterpret_cast<float*>(pbuf + 2 * G3_PATCH);             // [2][Cin] (AFF)
+  bf16_t* outs = fbuf;                                                     // epilogue: [256 pixels][OS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int wo = wave & 1, wp = wave >> 1;               // oc half of the tile, row pair of the tile
+  // XCD-aware persistent mapping: the blocks of one slot (same pixel tiles, all oc tiles) sit on one XCD
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int oct = jb % g.noct, slot = (jb / g.noct) * 8 + xcd;
+
+  if (AFF) {
+    for (int i = tid; i < 2 * g.Cin; i += G3_THREADS) abs_[i] = in_ab[i];
+  }
+
+  // staging descriptors
+  int prc[2];                                            // patch vector u: pr | pc << 8 | part << 16, or -1
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = tid + G3_THREADS * u, pp = v >> 1;
+    prc[u] = v < G3_NPV ? ((pp / G3_PW) | ((pp % G3_PW) << 8) | ((v & 1) << 16)) : -1;
+  }
+  uint4 rf[NFU], rp[2];
+  const bf16_t* wslab = wf + (int64_t)oct * g.nchunks * Cfg::FELEMS;
+
+  // STATS: the thread's 8 channels (16-byte part tid % (BN / 8)) over the pixels it stores: tid / (BN / 8) + k * 4096 / BN
+  float st1[8], st2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
+
+  for (int tile = slot; tile < g.ntiles; tile += g.nslots) {
+    const int ow0 = (tile % g.tiles_w) * G3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * G3_TH;
+    const int bimg = tile / (g.tiles_w * g.tiles_h);
+    const bf16_t* ximg = x + (int64_t)bimg * g.H * g.W * g.Cin;
+
+    auto fetch = [&](int chunk) {
+      const bf16_t* ws = wslab + (int64_t)chunk * Cfg::FELEMS;
+#pragma unroll
+      for (int u = 0; u < NFU; ++u) {
+        const int v = tid + G3_THREADS * u;
+        rf[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (u < NFU - 1 || v < Cfg::NFV) rf[u] = *reinterpret_cast<const uint4*>(ws + (int64_t)v * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ih = oh0 - 1 + (prc[u] & 0xff), iw = ow0 - 1 + ((prc[u] >> 8) & 0xff);
+        rp[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (prc[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+          rp[u] = *reinterpret_cast<const uint4*>(ximg + ((int64_t)ih * g.W + iw) * g.Cin + chunk * G3_KC +
+                                                  ((prc[u] >> 16) & 1) * 8);
+      }
+    };
+    auto stage = [&](int chunk, int buf) {
+      bf16_t* fb = fbuf + buf * Cfg::FELEMS;
+#pragma unroll
+      for (int u = 0; u < NFU; ++u) {
+        const int v = tid + G3_THREADS * u;
+        if (u < NFU - 1 || v < Cfg::NFV) *reinterpret_cast<uint4*>(fb + v * 8) = rf[u];
+      }
+      bf16_t* pbw = pbuf + buf * G3_PATCH;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (prc[u] >= 0) {
+          uint4 v = rp[u];
+          const int part = (prc[u] >> 16) & 1;
+          if (AFF) {
+            const int ih = oh0 - 1 + (prc[u] & 0xff), iw = ow0 - 1 + ((prc[u] >> 8) & 0xff);
+            if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {     // padding pixels stay exactly zero
+              const int c0 = chunk * G3_KC + part * 8;
+              v = g3_affine_relu(v, abs_ + c0, abs_ + g.Cin + c0);
+            }
+          }
+          const int pp = (prc[u] & 0xff) * G3_PW + ((prc[u] >> 8) & 0xff);
+          *reinterpret_cast<uint4*>(pbw + pp * G3_PS + part * 8) = v;
+        }
+    };
+
+    g3_f32x16 acc[NOB][2];
+#pragma unroll
+    for (int j = 0; j < NOB; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    fetch(0);
+    __syncthreads();                                     // the previous tile's epilogue is done with the buffers; abs_ visible
+    stage(0, 0);
+    __syncthreads();
+
+    for (int c = 0; c < g.nchunks; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < g.nchunks) fetch(c + 1);               // in flight during the MFMAs of this chunk
+      const bf16_t* pb = pbuf + buf * G3_PATCH + ((2 * wp) * G3_PW + p) * G3_PS + half * 8;
+      const bf16_t* fa = fbuf + buf * Cfg::FELEMS + ((wo * NOB) * 64 + lane) * 8;
+      g3_bf16x8 bq[4][3];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          bq[pr][kw] = *reinterpret_cast<const g3_bf16x8*>(pb + (pr * G3_PW + kw) * G3_PS);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int t = kh * 3 + kw;
+#pragma unroll
+          for (int j = 0; j < NOB; ++j) {
+            const g3_bf16x8 af = *reinterpret_cast<const g3_bf16x8*>(fa + ((t * OCB + j) * 64) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[i + kh][kw], acc[j][i], 0, 0, 0);
+          }
+        }
+      if (c + 1 < g.nchunks) stage(c + 1, buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- epilogue: acc[j][i][r] is oc = (wo NOB + j) 32 + (r & 3) + 8 (r >> 2) + 4 half, pixel (row 2 wp + i, column p)
+#pragma unroll
+    for (int j = 0; j < NOB; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2 v;
+          v.x = pack2_bf16(acc[j][i][4 * gq + 0], acc[j][i][4 * gq + 1]);
+          v.y = pack2_bf16(acc[j][i][4 * gq + 2], acc[j][i][4 * gq + 3]);
+          *reinterpret_cast<uint2*>(outs + ((2 * wp + i) * G3_TW + p) * OS + (wo * NOB + j) * 32 + 8 * gq + 4 * half) = v;
+        }
+    __syncthreads();
+    constexpr int VPP = BN / 8;                          // 16-byte vectors per pixel
+    bf16_t* yimg = y + (int64_t)bimg * g.H * g.W * g.Cout + oct * BN;
+#pragma unroll
+    for (int k = 0; k < 256 * VPP / G3_THREADS; ++k) {
+      const int v = tid + G3_THREADS * k, px = v / VPP, part = v % VPP;
+      const int oh = oh0 + (px >> 5), ow = ow0 + (px & 31);
+      if (oh < g.H && ow < g.W) {
+        const uint4 o = *reinterpret_cast<const uint4*>(outs + px * OS + part * 8);
+        *reinterpret_cast<uint4*>(yimg + ((int64_t)oh * g.W + ow) * g.Cout + part * 8) = o;
+        if (STATS) {                                     // the values just stored: no second pass over the tile
+          const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+            st1[2 * e] += lo; st2[2 * e] = fmaf(lo, lo, st2[2 * e]);
+            st1[2 * e + 1] += hi; st2[2 * e + 1] = fmaf(hi, hi, st2[2 * e + 1]);
+          }
+        }
+      }
+    }
+    // the next tile's first __syncthreads() (after its fetch) orders these reads before the buffers are rewritten
+  }
+
+  if (STATS) {                                           // fold the pixel groups in a fixed order
+    constexpr int VPP = BN / 8, NG = G3_THREADS / VPP;    // 32 / 64 pixel groups
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(fbuf);         // [NG][2][BN] floats: 32 KB, the filter buffers are free now
+    const int part = tid % VPP, q = tid / VPP;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(q * 2 + 0) * BN + part * 8 + e] = st1[e];
+      red[(q * 2 + 1) * BN + part * 8 + e] = st2[e];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int c = tid % BN, which = tid / BN;
+      float sacc = 0.f;
+      for (int qq = 0; qq < NG; ++qq) sacc += red[(qq * 2 + which) * BN + c];
+      partial[((int64_t)slot * 2 + which) * g.Cout + oct * BN + c] = sacc;
+    }
+  }
+}
+
+// ---- filter preparation: fp32 / bf16 master weight [O][3][3][I] (channels_last filter) -> bf16 in fragment order
+//   out[oc tile][chunk][tap][ocb][lane][e] = W'[oc = tile BN + ocb 32 + (lane & 31)][tap][ci = chunk 16 + (lane >> 5) 8 + e]
+// mode 0: W' = w (forward: C_out' = O, C_in' = I).
+// mode 1: W'[oc'][tap][ci'] = w[ci'][8 - tap][oc'] (data gradient: C_out' = I, C_in' = O).
+template <typename TI>
+__global__ __launch_bounds__(256) void g3_prep_filter_k(const TI* __restrict__ w, bf16_t* __restrict__ out, int O, int I,
+                                                        int BN, int mode, int64_t nvec) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvec) return;
+  const int Co = mode ? I : O, Ci = mode ? O : I;        // of the convolution that will run
+  const int nch = Ci / G3_KC, ocb_n = BN / 32;
+  int64_t r = v;
+  const int ln = (int)(r % 64); r /= 64;
+  const int ocb = (int)(r % ocb_n); r /= ocb_n;
+  const int tap = (int)(r % 9); r /= 9;
+  const int chunk = (int)(r % nch); r /= nch;
+  const int tile = (int)r;
+  const int oc = tile * BN + ocb * 32 + (ln & 31), ci0 = chunk * G3_KC + (ln >> 5) * 8;
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ci0 + e;
+    float val = 0.f;
+    if (oc < Co) val = mode ? ld1<TI>(w + ((int64_t)ci * 9 + (8 - tap)) * I + oc) : ld1<TI>(w + ((int64_t)oc * 9 + tap) * I + ci);
+    f[e] = val;
+  }
+  uint4 o;
+  o.x = pack2_bf16(f[0], f[1]); o.y = pack2_bf16(f[2], f[3]); o.z = pack2_bf16(f[4], f[5]); o.w = pack2_bf16(f[6], f[7]);
+  *reinterpret_cast<uint4*>(out + v * 8) = o;
+}
+
+// Output channels per block: 128 when C_out allows it and the launch still has >= 192 (pixel tile, oc tile) work items
+// for the 256 CUs; 64 otherwise (BiSeNet's 512 -> 128 attention-refinement 3x3 on the 32 x 32 map has 64 pixel tiles:
+// 64-wide tiles give 128 blocks instead of 64).  The prepared filter is laid out for the width it was made for.
+static int g3_bn(int64_t B, int64_t H, int64_t W, int Cout) {
+  if (Cout % 128) return 64;
+  if (const char* e = getenv("TSG_CONV3G_BN")) {         // tests / tuning: force a width
+    const int v = atoi(e);
+    if (v == 64 || v == 128) return v;
+  }
+  const int64_t tiles = B * ((H + G3_TH - 1) / G3_TH) * ((W + G3_TW - 1) / G3_TW);
+  return tiles * (Cout / 128) >= 192 ? 128 : 64;
+}
+
+static int g3_geom(G3Geom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % G3_KC || Cout % 64) return TSG_E_SHAPE;
+  if ((BN != 64 && BN != 128) || Cout % BN) return TSG_E_SHAPE;
+  const int64_t th = (H + G3_TH - 1) / G3_TH, tw = (W + G3_TW - 1) / G3_TW;
+  if (B * th * tw > 0x7fffffffLL || H * W * (int64_t)(Cin > Cout ? Cin : Cout) > 0x7fffffffLL) return TSG_E_SHAPE;
+  g->B = (int)B; g->H = (int)H; g->W = (int)W; g->Cin = Cin; g->Cout = Cout;
+  g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
+  g->nchunks = Cin / G3_KC; g->noct = Cout / BN;
+  // one block per CU (8 waves, ~110 KB of LDS): ~256 blocks in all, a multiple of 8 slots per oc tile (XCD mapping)
+  static int target = 0;
+  if (!target) { const char* e = getenv("TSG_CONV3G_BLOCKS"); target = e ? atoi(e) : 256; if (target < 8) target = 256; }
+  int64_t ns = target / g->noct;
+  if (ns > g->ntiles) ns = g->ntiles;
+  ns = (ns + 7) / 8 * 8;
+  if (ns < 8) ns = 8;
+  g->nslots = (int)ns;
+  return 0;
+}
+
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" {
+
+int tsg_conv3x3_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation, int groups) {
+  return dtype == TSG_BF16 && Cin > 0 && Cout > 0 && Cin % G3_KC == 0 && Cout % 64 == 0 && kh == 3 && kw == 3 &&
+         stride == 1 && pad == 1 && dilation == 1 && groups == 1;
+}
+
+/* bf16 elements of the prepared filter of a convolution with C_out output and C_in input channels */
+int64_t tsg_conv3x3_gen_filter_elems(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cin % G3_KC || Cout % 64) return TSG_E_SHAPE;
+  return (int64_t)9 * Cin * Cout;
+}
+
+/* output channels per block (64 or 128) tsg_conv3x3_gen_fwd should use for this problem: pass it to the filter
+ * preparation and to the forward call */
+int tsg_conv3x3_gen_tile(int64_t B, int64_t H, int64_t W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % G3_KC || Cout % 64) return TSG_E_SHAPE;
+  return g3_bn(B, H, W, Cout);
+}
+
+int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int I, int mode, int BN, void* stream) {
+  if (!w || !out) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (mode != 0 && mode != 1) return TSG_E_SHAPE;
+  const int Co = mode ? I : O, Ci = mode ? O : I;
+  if (O <= 0 || I <= 0 || Ci % G3_KC || Co % 64 || (BN != 64 && BN != 128) || Co % BN) return TSG_E_SHAPE;
+  if (!aligned16(out)) return TSG_E_ALIGN;
+  const int64_t nvec = (int64_t)9 * Ci * Co / 8;
+  const unsigned grid = (unsigned)((nvec + 255) / 256);
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((g3_prep_filter_k<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)w,
+                       (bf16_t*)out, O, I, BN, mode, nvec);
+  else
+    hipLaunchKernelGGL((g3_prep_filter_k<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w,
+                       (bf16_t*)out, O, I, BN, mode, nvec);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+/* rows of the statistics partial the forward writes when `partial` is given: partial[rows][2][Cout] */
+int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN) {
+  G3Geom g;
+  int e = g3_geom(&g, B, H, W, Cin, Cout, BN);
+  return e ? e : g.nslots;
+}
+
+int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, int64_t B, int64_t H,
+                        int64_t W, int Cin, int Cout, int BN, void* stream) {
+  if (!x || !wf || !y) return TSG_E_NULL;
+  G3Geom g;
+  int e = g3_geom(&g, B, H, W, Cin, Cout, BN);
+  if (e) return e;
+  if (in_ab && Cin > G3_MAX_AFF_C) return TSG_E_SHAPE;
+  if (!aligned16(x) || !aligned16(wf) || !aligned16(y) || (in_ab && !aligned16(in_ab))) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = g.nslots * g.noct;
+#define G3_GO(BNN, AF, STT)                                                                                         \
+  do {                                                                                                              \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3g_fwd_k<BNN, AF, STT>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3Cfg<BNN>::LDS));                 \
+    hipLaunchKernelGGL((conv3g_fwd_k<BNN, AF, STT>), dim3(grid), dim3(G3_THREADS), G3Cfg<BNN>::LDS, st,             \
+                       (const bf16_t*)x, (const bf16_t*)wf, (bf16_t*)y, g, in_ab, partial);                         \
+  } while (0)
+  if (BN == 128) {
+    if (in_ab) { if (partial) G3_GO(128, true, true); else G3_GO(128, true, false); }
+    else { if (partial) G3_GO(128, false, true); else G3_GO(128, false, false); }
+  } else {
+    if (in_ab) { if (partial) G3_GO(64, true, true); else G3_GO(64, true, false); }
+    else { if (partial) G3_GO(64, false, true); else G3_GO(64, false, false); }
+  }
+#undef G3_GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -405,23 +405,31 @@ static int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t st) {
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef v4i16 __attribute__((address_space(3))) lds_v4i16;
 
-constexpr int MM_BN = 64, MM_BK = 64, MM_T = 256;
+constexpr int MM_BK = 64, MM_T = 256;
 constexpr int MM_NT_ROW = 72;                       // elements per NT row (64 + 8 pad)
-constexpr int MM_B_TR_ROW = MM_BN + 32;             // 96 elements  = 192 B
-constexpr int MM_B_ELEMS = MM_BK * MM_B_TR_ROW;     // 6144  (>= 64 * 72 = 4608 for the NT image)
-constexpr int MM_EPI_ROW = 68;                      // fp32 words per epilogue row (64 + 4 pad)
 
 // BM = rows of C per block (256: 64 per wave, 1 block/CU; 128: 32 per wave, 2 blocks/CU), PF = K tiles whose global
 // loads are in flight in registers beyond the one being written to LDS (HBM/L2 latency is ~2 us: with one wave per
 // SIMD a single tile of lead time leaves every iteration waiting for its loads)
-template <int BM> struct MmGeom {
+// BN = columns of C per block: 64 (the four waves stacked along M, each BM / 4 rows x 64 columns) or 128 (round 3: the
+// waves form a 2 x 2 grid, each BM / 2 rows x 64 columns).  With M = Cx = 512 rows only, the forward / dX products have
+// 2 x 512 x 3600 outputs for 256 CUs: 128 x 128 tiles are one per CU (225 blocks), every staged (and, for B,
+// exponentiated) K tile feeds 16 MFMAs per wave instead of 8, and X / dOut are re-read by 29 instead of 57 column tiles.
+template <int BM, int BN> struct MmGeom {
+  static constexpr int WN = BN / 64, WM = 4 / WN;                              // wave grid
+  static constexpr int WROWS = BM / WM;                                        // C rows per wave
   static constexpr int A_TR_ROW = BM + 32;                                     // (2 BM + 64) B: odd multiple of 64 B
   static constexpr int A_ELEMS = (BM * MM_NT_ROW > MM_BK * A_TR_ROW) ? BM * MM_NT_ROW : MM_BK * A_TR_ROW;
-  static constexpr int STAGE = A_ELEMS + MM_B_ELEMS;
-  static constexpr size_t LDS = (size_t)2 * STAGE * sizeof(bf16_t);            // 98,304 B (BM 256) / 65,536 B (BM 128)
+  static constexpr int B_TR_ROW = BN + 32;                                     // 96 / 160 elements: odd multiples of 64 B
+  static constexpr int B_ELEMS = (BN * MM_NT_ROW > MM_BK * B_TR_ROW) ? BN * MM_NT_ROW : MM_BK * B_TR_ROW;
+  static constexpr int STAGE = A_ELEMS + B_ELEMS;
+  static constexpr size_t LDS = (size_t)2 * STAGE * sizeof(bf16_t);            // 98,304 B (256 x 64) / 65,536 B (128 x 64) / 81,920 B (128 x 128)
   static constexpr int ACH = BM / 32;                                          // 16-byte A chunks per thread and tile
-  static constexpr int MI = BM / 128;                                          // 32-row MFMA tiles per wave along M
-  static_assert((size_t)BM * MM_EPI_ROW * 4 <= LDS, "epilogue image must fit the tile buffers");
+  static constexpr int BCH = BN / 32;                                          // 16-byte B chunks per thread and tile
+  static constexpr int MI = WROWS / 32;                                        // 32-row MFMA tiles per wave along M
+  static constexpr int EPI_ROW = BN + 4;                                       // fp32 words per epilogue row
+  static constexpr int CPR = BN / 8;                                           // 8-column chunks per epilogue row
+  static_assert((size_t)BM * EPI_ROW * 4 <= LDS, "epilogue image must fit the tile buffers");
 };
 
 struct MmArgs {
@@ -439,14 +447,15 @@ struct MmArgs {
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int BM, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
-__global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
-  typedef MmGeom<BM> G;
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
+__global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(MmArgs g) {
+  typedef MmGeom<BM, BN> G;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
   constexpr float kLog2e = 1.4426950408889634f;
-  constexpr int WROWS = BM / 4;                          // C rows per wave
+  constexpr int WROWS = G::WROWS;                        // C rows per wave
+  const int wm = wave / G::WN, wn = wave % G::WN;        // wave grid: WM x WN
 
   // block -> (batch, tile): consecutive block ids go round-robin over the 8 XCDs; give every XCD a contiguous run of tiles
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
@@ -458,12 +467,12 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   if (g.m_fastest) { tm = (int)(t % g.tiles_m); tn = (int)((t / g.tiles_m) % g.tiles_n); }
   else             { tn = (int)(t % g.tiles_n); tm = (int)((t / g.tiles_n) % g.tiles_m); }
   const int64_t b = t / ((int64_t)g.tiles_m * g.tiles_n);
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * MM_BN;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const bf16_t* Ag = g.A + b * g.sA;
   const bf16_t* Bg = g.B + b * g.sB;
   const float* lse = (EXPB || EPI == 1) ? g.lse + b * g.sL : nullptr;
 
-  // ---- staging maps: 16-byte chunks.  A tile = BM * 8 chunks (ACH per thread), B tile = 512 chunks (2 per thread)
+  // ---- staging maps: 16-byte chunks.  A tile = BM * 8 chunks (ACH per thread), B tile = BN * 8 chunks (BCH per thread)
   //   NT image [rows][8 chunks]: chunk id c -> row c >> 3, k-chunk c & 7
   //   TR image [64 k][cols / 8 chunks]: chunk id c -> k row c / (cols / 8), column chunk c % (cols / 8)
   // Everything that does not depend on the K tile is computed once per thread here (the K loop is issue-bound:
@@ -471,9 +480,9 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   // Loads are UNCONDITIONAL (per-lane predicates compile to divergent branches, ~40 of them per K tile): rows / columns /
   // k positions outside the problem are clamped to the last valid chunk, i.e. they read real tensor data; the K tail is
   // made exact by zeroing the B chunk (finite x 0), rows / columns beyond M / N are never stored.
-  uint4 ra[PF][G::ACH], rb[PF][2];
+  uint4 ra[PF][G::ACH], rb[PF][G::BCH];
   const bf16_t* pa[G::ACH]; int ka[G::ACH], oa[G::ACH];                  // base pointer (k = 0), k inside the tile, LDS offset
-  const bf16_t* pb[2];      int kb[2],      ob[2];      bool vb[2];      // vb: column / row of B inside the problem
+  const bf16_t* pb[G::BCH]; int kb[G::BCH], ob[G::BCH]; bool vb[G::BCH]; // vb: column / row of B inside the problem
   const int64_t sa_k = A_TR ? g.M : 1, sb_k = B_TR ? g.N : 1;            // elements per unit of k
   const int Kd = (int)g.K;
   const int ka_max = A_TR ? Kd - 1 : Kd - 8, kb_max = B_TR ? Kd - 1 : Kd - 8;
@@ -491,23 +500,23 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
     }
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < G::BCH; ++q) {
     const int c = tid + MM_T * q;
     if (B_TR) {
-      const int kr = c >> 3, nc = (c & 7) * 8;
+      const int kr = c / G::CPR, nc = (c % G::CPR) * 8;
       vb[q] = n0 + nc < g.N;
-      kb[q] = kr; pb[q] = Bg + (vb[q] ? n0 + nc : g.N - 8); ob[q] = kr * MM_B_TR_ROW + nc;
+      kb[q] = kr; pb[q] = Bg + (vb[q] ? n0 + nc : g.N - 8); ob[q] = kr * G::B_TR_ROW + nc;
     } else {
       const int nr = c >> 3, kc = (c & 7) * 8;
       vb[q] = n0 + nr < g.N;
       kb[q] = kc; pb[q] = Bg + (vb[q] ? n0 + nr : g.N - 1) * g.K; ob[q] = nr * MM_NT_ROW + kc;
     }
   }
-  float bl[2][8];                                       // EXPB 1: lse * log2e of the thread's B columns (fixed per block)
+  float bl[EXPB == 1 ? G::BCH : 1][8];                  // EXPB 1: lse * log2e of the thread's B columns (fixed per block)
   if (EXPB == 1) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int64_t n = n0 + ((tid + MM_T * q) & 7) * 8;
+    for (int q = 0; q < G::BCH; ++q) {
+      const int64_t n = n0 + ((tid + MM_T * q) % G::CPR) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) bl[q][e] = (n + e < g.N) ? lse[n + e] * kLog2e : 0.f;
     }
@@ -518,13 +527,13 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
 #pragma unroll
   for (int q = 0; q < G::ACH; ++q) pa[q] += (int64_t)ka[q] * sa_k;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) pb[q] += (int64_t)kb[q] * sb_k;
+  for (int q = 0; q < G::BCH; ++q) pb[q] += (int64_t)kb[q] * sb_k;
   auto fetch = [&](uint4* qa, uint4* qb, int k0) {
     if (k0 + MM_BK <= Kd) {
 #pragma unroll
       for (int q = 0; q < G::ACH; ++q) { qa[q] = ld16(pa[q]); pa[q] += step_a; }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) { qb[q] = ld16(pb[q]); pb[q] += step_b; }
+      for (int q = 0; q < G::BCH; ++q) { qb[q] = ld16(pb[q]); pb[q] += step_b; }
     } else {
 #pragma unroll
       for (int q = 0; q < G::ACH; ++q) {
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
         qa[q] = ld16(pa[q] - (over > 0 ? (int64_t)over * sa_k : 0));
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < G::BCH; ++q) {
         const int over = k0 + kb[q] - kb_max;
         qb[q] = ld16(pb[q] - (over > 0 ? (int64_t)over * sb_k : 0));
       }
@@ -555,11 +564,11 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
 #pragma unroll
     for (int q = 0; q < G::ACH; ++q) *reinterpret_cast<uint4*>(sa + oa[q]) = qa[q];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < G::BCH; ++q) {
       uint4 v = qb[q];
       const bool in = vb[q] && k0 + kb[q] < Kd;            // the K tail (and the padding) must be exact zeros, not exp(-lse)
       if (EXPB == 1) {
-        v = expchunk(v, bl[q]);
+        v = expchunk(v, bl[EXPB == 1 ? q : 0]);
       } else if (EXPB == 2) {
         const int k = k0 + kb[q] < kb_max ? k0 + kb[q] : kb_max;
         const float4 l0 = *reinterpret_cast<const float4*>(lse + k), l1 = *reinterpret_cast<const float4*>(lse + k + 4);
@@ -582,10 +591,10 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
 
   // fragment bases (elements).  NT: row = 32 i + (lane & 31), k = 16 ks + 8 half .. +7 (one ds_read_b128).
   // TR: source row k = 16 ks + 8 half + (i16 >> 2) (+4 for the second read), column = 32 i + 16 sub + 4 (i16 & 3).
-  const int a_nt = (wave * WROWS + (lane & 31)) * MM_NT_ROW + half * 8;
-  const int a_tr = (8 * half + (i16 >> 2)) * G::A_TR_ROW + wave * WROWS + 16 * sub + 4 * (i16 & 3);
-  const int b_nt = (lane & 31) * MM_NT_ROW + half * 8;
-  const int b_tr = (8 * half + (i16 >> 2)) * MM_B_TR_ROW + 16 * sub + 4 * (i16 & 3);
+  const int a_nt = (wm * WROWS + (lane & 31)) * MM_NT_ROW + half * 8;
+  const int a_tr = (8 * half + (i16 >> 2)) * G::A_TR_ROW + wm * WROWS + 16 * sub + 4 * (i16 & 3);
+  const int b_nt = (wn * 64 + (lane & 31)) * MM_NT_ROW + half * 8;
+  const int b_tr = (8 * half + (i16 >> 2)) * G::B_TR_ROW + wn * 64 + 16 * sub + 4 * (i16 & 3);
 
   // tile t travels in register set t % PF: fetched PF iterations before it is written to LDS
   const int nk = (int)((g.K + MM_BK - 1) / MM_BK);
@@ -621,9 +630,9 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (B_TR) {
-            const lds_v4i16* p = (const lds_v4i16*)(sb + b_tr + ks * 16 * MM_B_TR_ROW + j * 32);
+            const lds_v4i16* p = (const lds_v4i16*)(sb + b_tr + ks * 16 * G::B_TR_ROW + j * 32);
             fb[j].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
-            fb[j].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (MM_B_TR_ROW / 4)));
+            fb[j].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (G::B_TR_ROW / 4)));
           } else {
             fb[j].v = *reinterpret_cast<const bf16x8*>(sb + b_nt + j * 32 * MM_NT_ROW + ks * 16);
           }
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   }
 
   // ---- epilogue through LDS: acc (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half) -> fp32 image
-  // [BM][68], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
+  // [BM][BN + 4], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
   __syncthreads();
   float* ep = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -647,12 +656,13 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wave * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        ep[row * MM_EPI_ROW + j * 32 + (lane & 31)] = acc[i][j][r];
+        const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        ep[row * G::EPI_ROW + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
       }
   __syncthreads();
   bf16_t* Cg = g.C + b * g.sC;
-  const int cchunk = tid & 7;
+  constexpr int RPP = MM_T / G::CPR;                     // rows per pass of the block: 32 / 16
+  const int cchunk = tid % G::CPR;
   const int64_t n = n0 + cchunk * 8;
   float dl[8], l2[8];
   if (EPI == 1 && n < g.N) {
@@ -660,12 +670,12 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
     for (int e = 0; e < 8; ++e) { dl[e] = g.delta[b * g.sD + n + e]; l2[e] = lse[n + e] * kLog2e; }
   }
 #pragma unroll 4
-  for (int q = 0; q < BM / 32; ++q) {
-    const int row = (tid >> 3) + 32 * q;
+  for (int q = 0; q < BM / RPP; ++q) {
+    const int row = tid / G::CPR + RPP * q;
     const int64_t m = m0 + row;
     if (m >= g.M || n >= g.N) continue;
-    const float4 v0 = *reinterpret_cast<const float4*>(ep + row * MM_EPI_ROW + cchunk * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(ep + row * MM_EPI_ROW + cchunk * 8 + 4);
+    const float4 v0 = *reinterpret_cast<const float4*>(ep + row * G::EPI_ROW + cchunk * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(ep + row * G::EPI_ROW + cchunk * 8 + 4);
     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     if (EPI == 1) {
       const uint4 a = ld16(g.Araw + b * g.sR + m * g.N + n);
@@ -686,30 +696,33 @@ __global__ __launch_bounds__(MM_T, (BM == 128 ? 2 : 1)) void psa_mm(MmArgs g) {
   }
 }
 
-template <int BM, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
 static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   g.tiles_m = (int)((g.M + BM - 1) / BM);
-  g.tiles_n = (int)((g.N + MM_BN - 1) / MM_BN);
+  g.tiles_n = (int)((g.N + BN - 1) / BN);
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
   g.per_xcd = (int)((tiles + 7) / 8);
   { const char* o = getenv("TSG_PSA_ORDER"); g.m_fastest = (o && o[0] == 'm') ? 1 : 0; }
-  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, PF, A_TR, B_TR, EXPB, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MmGeom<BM>::LDS));
-  hipLaunchKernelGGL((psa_mm<BM, PF, A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T),
-                     MmGeom<BM>::LDS, st, g);
+  constexpr size_t lds_bytes = MmGeom<BM, BN>::LDS;
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T),
+                     lds_bytes, st, g);
   TSG_CHECK_LAUNCH();
   return 0;
 }
 
-// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (bring-up / tuning knob, read once); default chosen by measurement
+// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (64-column tiles, round 2) or "128x128x<PF>" (round 3: 2 x 2 wave
+// grid); bring-up / tuning knob, read once; default chosen by measurement
 static int mm_cfg() {
   static int cfg = -1;
   if (cfg < 0) {
     const char* e = getenv("TSG_PSA_CFG");
-    cfg = 1281;
+    cfg = 1281281;
     if (e) {
       if (!strcmp(e, "256x1")) cfg = 2561; else if (!strcmp(e, "256x2")) cfg = 2562;
       else if (!strcmp(e, "128x1")) cfg = 1281; else if (!strcmp(e, "128x2")) cfg = 1282;
+      else if (!strcmp(e, "128x128x1")) cfg = 1281281; else if (!strcmp(e, "128x128x2")) cfg = 1281282;
     }
   }
   return cfg;
@@ -720,10 +733,12 @@ static int launch_mm(MmArgs g, hipStream_t st) {
   if (g.M % 8 || g.N % 8 || g.K % 8) return TSG_E_SHAPE;
   if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return TSG_E_ALIGN;
   switch (mm_cfg()) {
-    case 2561: return launch_mm_cfg<256, 1, A_TR, B_TR, EXPB, EPI>(g, st);
-    case 2562: return launch_mm_cfg<256, 2, A_TR, B_TR, EXPB, EPI>(g, st);
-    case 1282: return launch_mm_cfg<128, 2, A_TR, B_TR, EXPB, EPI>(g, st);
-    default:   return launch_mm_cfg<128, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 2561: return launch_mm_cfg<256, 64, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 2562: return launch_mm_cfg<256, 64, 2, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 1282: return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 1281: return launch_mm_cfg<128, 64, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 1281282: return launch_mm_cfg<128, 128, 2, A_TR, B_TR, EXPB, EPI>(g, st);
+    default:   return launch_mm_cfg<128, 128, 1, A_TR, B_TR, EXPB, EPI>(g, st);
   }
 }
 

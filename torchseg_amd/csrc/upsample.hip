@@ -349,6 +349,59 @@ __global__ __launch_bounds__(kT) void up_bwd_nhwc(const T* __restrict__ dy, T* _
   }
 }
 
+// The same gather for SMALL sources with large footprints — the pyramid-pooling branches of PSPNet (pspnet
+// network.py:101-106: 1x1 / 2x2 / 3x3 / 6x6 pooled maps interpolated to 90 x 90): one thread per source pixel and channel
+// group would leave a few hundred threads walking thousands of output pixels each (1 ms per launch at 2 x 512 x 6 x 6 ->
+// 90 x 90).  Here a block owns one source pixel (and up to 256 channel groups of V); its threads split the footprint's
+// ROWS, and the row partials are folded through LDS in a fixed order: deterministic, no atomics.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void up_bwd_nhwc_split(const T* __restrict__ dy, T* __restrict__ dx, int64_t N, int C,
+                                                         int IH, int IW, int OH, int OW, float sy, float sx, int gpb) {
+  __shared__ float red[256 * V];
+  const int G = C / V, RS = 256 / gpb;                   // channel groups per block, row splitters
+  const int tid = threadIdx.x, gl = tid % gpb, rs = tid / gpb;
+  const int g = blockIdx.y * gpb + gl;
+  int64_t t = blockIdx.x;
+  const int ix = (int)(t % IW); t /= IW;
+  const int iy = (int)(t % IH);
+  const int64_t n = t / IH;
+  int xlo, xhi, ylo, yhi;
+  footprint(sx, ix, OW, xlo, xhi);
+  footprint(sy, iy, OH, ylo, yhi);
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  if (rs < RS && g < G) {
+    const T* b = dy + n * OH * (int64_t)OW * C + g * V;
+    for (int oy = ylo + rs; oy <= yhi; oy += RS) {
+      const float wy = tap_weight(sy, oy, IH, iy);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float w = wy * tap_weight(sx, ox, IW, ix);
+        if (w != 0.f) {
+          OutVec<T, V> p;
+          p.load(b + ((int64_t)oy * OW + ox) * C);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += w * p.v[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[tid * V + j] = acc[j];
+  __syncthreads();
+  if (rs == 0 && g < G) {
+    OutVec<T, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float s = 0.f;
+      for (int q = 0; q < RS; ++q) s += red[(q * gpb + gl) * V + j];
+      o.v[j] = s;
+    }
+    o.store(dx + (blockIdx.x * (int64_t)G + g) * V);
+  }
+}
+
 template <int EB>
 __global__ __launch_bounds__(kT) void nearest_fwd(const void* __restrict__ x, void* __restrict__ y,
                                                   int64_t NC, int IH, int IW, int OH, int OW,
@@ -536,6 +589,20 @@ int tsg_upsample_bilinear_ac_nhwc_bwd(const void* dy, void* dx, int dtype, int64
   if (!aligned16(dy) || !aligned16(dx)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
+  // few source pixels, each with a footprint of many rows: split the rows over the threads of a block
+  const int G = C / V;
+  if (N * IH * (int64_t)IW * G < 65536 && OH >= 8 * IH && N * IH * (int64_t)IW <= 0x7fffffffLL) {
+    const int gpb = G < 256 ? G : 256;
+    const dim3 grid2((unsigned)(N * IH * IW), (unsigned)((G + gpb - 1) / gpb));
+    if (dtype == TSG_F32)
+      hipLaunchKernelGGL((up_bwd_nhwc_split<float, 4>), grid2, dim3(256), 0, st, (const float*)dy, (float*)dx, N, C, IH, IW,
+                         OH, OW, sy, sx, gpb);
+    else
+      hipLaunchKernelGGL((up_bwd_nhwc_split<bf16_t, 8>), grid2, dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, C, IH,
+                         IW, OH, OW, sy, sx, gpb);
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
   const int grid = grid_for(N * IH * (int64_t)IW * (C / V));
   if (dtype == TSG_F32)
     hipLaunchKernelGGL((up_bwd_nhwc<float, 4>), dim3(grid), dim3(kT), 0, st, (const float*)dy, (float*)dx, N, C,

@@ -587,6 +587,57 @@ class HipKernels:
         L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), B, H, W, L.stream_ptr(x)), what)
         return (y, partial) if with_stats else y
 
+    def conv3x3_gen_supported(self, x, weight, stride, padding, dilation, groups):
+        """the general stride-1 3x3 forward kernel (csrc/conv3g.hip): bf16 channels_last, Cin % 16 == 0, Cout % 64 == 0"""
+        if x.dim() != 4 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+            return False
+        return bool(self.lib.tsg_conv3x3_gen_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
+                                                       weight.shape[3], stride, padding, dilation, groups))
+
+    def conv3x3_gen_tile(self, B, H, W, Cin, Cout):
+        """output channels per block (64 / 128) for this problem: the prepared filter is laid out for it"""
+        return self._count(("g3_tile", B, H, W, Cin, Cout), lambda: self.lib.tsg_conv3x3_gen_tile(B, H, W, Cin, Cout),
+                           "tsg_conv3x3_gen_tile")
+
+    def conv3x3_gen_prep_filter(self, weight, mode, like):
+        """weight [O,I,3,3] channels_last (fp32 master or bf16) -> (wf, BN): the bf16 filter in MFMA fragment order for
+        the convolution that will read `like` ([B,C,H,W]): mode 0 for conv(x, w), mode 1 for the data gradient
+        conv(dy, rot180(w)^T)"""
+        if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or not weight.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("conv3x3_gen_prep_filter expects a channels_last [O, I, 3, 3] weight")
+        O, I = weight.shape[0], weight.shape[1]
+        Cin, Cout = (O, I) if mode else (I, O)
+        B, C, H, W = like.shape
+        if C != Cin:
+            raise ValueError("conv3x3_gen_prep_filter: the input does not have the filter's channel count")
+        bn = self.conv3x3_gen_tile(B, H, W, Cin, Cout)
+        out = torch.empty(9 * O * I, dtype=torch.bfloat16, device=weight.device)
+        L.check(self.lib.tsg_conv3x3_gen_prep_filter(weight.data_ptr(), L.dtype_code(weight), out.data_ptr(), O, I, int(mode),
+                                                     bn, L.stream_ptr(weight)), "tsg_conv3x3_gen_prep_filter")
+        return out, bn
+
+    def conv3x3_gen_fwd(self, x, wf, Cout, with_stats=False, in_ab=None):
+        """x [B,Cin,H,W] bf16 channels_last, wf = conv3x3_gen_prep_filter(..., like=x) -> y [B,Cout,H,W] channels_last, or
+        (y, partial [S,2,Cout]).  in_ab: fp32 [>=2, Cin] BN forward pack: the convolution reads relu(a x + b)."""
+        if not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.bfloat16:
+            raise ValueError("conv3x3_gen_fwd expects a bf16 channels_last input")
+        B, Cin, H, W = x.shape
+        wf, bn = wf
+        if wf.numel() != 9 * Cin * Cout or wf.dtype != torch.bfloat16 or bn != self.conv3x3_gen_tile(B, H, W, Cin, Cout):
+            raise ValueError("conv3x3_gen_fwd: the prepared filter does not belong to this convolution")
+        if in_ab is not None and (in_ab.dtype != torch.float32 or not in_ab.is_contiguous() or in_ab.shape[-1] != Cin):
+            raise ValueError("conv3x3_gen_fwd: in_ab must be a contiguous fp32 [>=2, Cin] pack")
+        y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        partial = None
+        if with_stats:
+            S = self._count(("g3_stats", B, H, W, Cin, Cout, bn),
+                            lambda: self.lib.tsg_conv3x3_gen_stats_partials(B, H, W, Cin, Cout, bn),
+                            "tsg_conv3x3_gen_stats_partials")
+            partial = torch.empty((S, 2, Cout), dtype=torch.float32, device=x.device)
+        L.check(self.lib.tsg_conv3x3_gen_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), B, H, W,
+                                             Cin, Cout, bn, L.stream_ptr(x)), "tsg_conv3x3_gen_fwd")
+        return (y, partial) if with_stats else y
+
     def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw):
         """dy [B,64,OH,OW] bf16 channels_last, wt = conv3x3_weight_rot180_t(w) -> dx [B,64,H,W] of the stride-2 convolution"""
         if not dy.is_contiguous(memory_format=torch.channels_last) or not wt.is_contiguous(memory_format=torch.channels_last):
@@ -736,6 +787,7 @@ class HipKernels:
         return out
 
     SGD_MAX_SEGS = 128
+    SGD_MAX_GROUPS = 24          # TSG_SGD_MAX_GROUPS (include/tsg_hip.h)
 
     def sgd_multi_blockmap(self, numel, device):
         """Static block -> (tensor, chunk) table for sgd_multi_step_dev, as a device int32 tensor."""
@@ -828,6 +880,7 @@ _ALGO_BYTES = {
     "stem_conv_wrw_bn": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[2]),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "conv3x3_c64_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "conv3x3_gen_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1][0]) + _nbytes(r[0] if isinstance(r, tuple) else r),
     "conv3x3_c64_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
@@ -838,6 +891,7 @@ _ALGO_FLOPS = {
     "conv3x3_wrw": lambda a, r: 2 * 9 * a[1].numel() * a[0].shape[1],          # dy elements x C_in x 9 taps
     "stem_conv_fwd": lambda a, r: 2 * 147 * r.numel(),
     "conv3x3_c64_fwd": lambda a, r: 2 * 9 * 64 * r.numel(),
+    "conv3x3_gen_fwd": lambda a, r: 2 * 9 * a[0].shape[1] * (r[0] if isinstance(r, tuple) else r).numel(),
     "conv3x3_c64_s2_dgrad": lambda a, r: 2 * 9 * 64 * a[0].numel(),
     "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
     "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
@@ -908,15 +962,20 @@ class KernelTimer:
     def roofline(self, peak_gbs, profiles_dir=None):
         name = self.dominant()
         st = self.stats[name]
-        traffic = None
+        traffic = source = busy = None
         if profiles_dir:
             import json
             import os
             f = os.path.join(profiles_dir, "traffic.json")
             if os.path.exists(f):
-                traffic = json.load(open(f)).get(name)   # PMC bytes per launch, profiles/r01_pmc_summary.txt
+                tj = json.load(open(f))
+                traffic = tj.get(name)                   # PMC bytes per launch (separate rocprofv3 --pmc passes)
+                # NOT a counter of this run: rocprofv3 cannot be attached from inside the process it profiles
+                source = "profiles/traffic.json@" + str(tj.get("_round", "r02")) + \
+                    " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench command, tools/pmc_traffic.sh)"
+                busy = (tj.get("_mfma_busy_frac") or {}).get(name)
         out = {"bound": "hbm", "kernel": name, "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
-               "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic,
+               "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic, "traffic_source": source,
                "algo_bytes_per_launch": int(st["algo_MB_per_launch"] * 1e6), "avg_launch_us": st["avg_us"]}
         if "TFLOPs" in st and st["TFLOPs"] / MFMA_PEAK_TFLOPS > out["frac"]:
             # a matrix kernel: the roof it is closer to is the MFMA one (the HBM figure stays alongside)
@@ -924,4 +983,6 @@ class KernelTimer:
                         "frac": round(st["TFLOPs"] / MFMA_PEAK_TFLOPS, 4),
                         "algo_flops_per_launch": int(st["algo_GFLOP_per_launch"] * 1e9),
                         "hbm_GBps": st["GBps"], "hbm_frac": round(st["GBps"] / peak_gbs, 4)})
+            if busy is not None:
+                out["mfma_busy_frac"] = busy             # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES), same source
         return out

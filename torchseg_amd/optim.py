@@ -67,8 +67,8 @@ class FusedSGD(torch.optim.Optimizer):
             return None
         if not capturing:
             self._sync_lr(first.device)
-        if len(self.param_groups) > 16:
-            raise K.L.TsgError("FusedSGD supports at most 16 parameter groups")
+        if len(self.param_groups) > kp.SGD_MAX_GROUPS:      # DFN's train.py builds 18 (dfn train.py:66-73)
+            raise K.L.TsgError(f"FusedSGD supports at most {kp.SGD_MAX_GROUPS} parameter groups")
         segs = []                                   # (param view, grad view, buffer, group index)
         for gi, group in enumerate(self.param_groups):
             if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):

@@ -50,6 +50,10 @@ def _backward_any_layout(dy, IH, IW):
         return (kp.gap_fwd(dy, layout, N, C, HW).float() * float(HW)).to(dy.dtype).view(N, C, 1, 1)
     if _is_cl_dense(dy) and _vec_ok(dy):
         return kp.upsample_bwd_nhwc(dy, IH, IW)
+    if dy.dim() == 4 and dy.stride(1) == 1 and dy.shape[1] > 1 and _vec_ok(dy):
+        # a channel slice of a channels_last tensor (the gradient of torch.cat in PSPNet's pyramid pooling, pspnet
+        # network.py:101-106): keep it channels_last, the NHWC gather is the one with a path for small sources
+        return kp.upsample_bwd_nhwc(dy.contiguous(memory_format=torch.channels_last), IH, IW)
     return kp.upsample_bwd(dy.contiguous(), IH, IW)
 
 
