@@ -36,8 +36,9 @@ def test_kernels_with_affine_on_load_equal_the_materialised_path(cuda, shape, st
         assert torch.equal(kp.conv3x3_wrw(x, dy, variant="gen", stride=1, in_ab=fp), kp.conv3x3_wrw(a, dy, variant="gen", stride=1))
 
 
-@pytest.mark.parametrize("stride", [1, 2])
-def test_fused_node_equals_module_sequence_and_fp64(cuda, stride):
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 64, 2),                  # conv64 kernels
+                                             (128, 128, 1), (128, 256, 1), (256, 64, 1)])  # the general kernel (round 3)
+def test_fused_node_equals_module_sequence_and_fp64(cuda, cin, cout, stride):
     from torchseg_amd import convwrw
     from torchseg_amd.convwrw import bn_relu_conv, install_conv_wrw
     from torchseg_amd.syncbn import SyncBatchNorm
@@ -46,17 +47,17 @@ def test_fused_node_equals_module_sequence_and_fp64(cuda, stride):
     class Pair(nn.Module):
         def __init__(self, bn_cls):
             super().__init__()
-            self.bn = bn_cls(64)
+            self.bn = bn_cls(cin)
             self.relu = nn.ReLU()
-            self.conv = nn.Conv2d(64, 64, 3, stride, 1, bias=False)
+            self.conv = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
 
     ref = Pair(nn.BatchNorm2d).double()
     with torch.no_grad():
-        ref.bn.weight.copy_(torch.randn(64) * 0.4 + 1.0)
-        ref.bn.bias.copy_(torch.randn(64) * 0.2)
+        ref.bn.weight.copy_(torch.randn(cin) * 0.4 + 1.0)
+        ref.bn.bias.copy_(torch.randn(cin) * 0.2)
         ref.conv.weight.copy_(ref.conv.weight.float().bfloat16().double())
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(2, 64, 40, 48, generator=g).bfloat16().float()
+    x = torch.randn(2, cin, 40, 48, generator=g).bfloat16().float()
     xr = x.double().requires_grad_(True)
     out_ref = ref.conv(ref.relu(ref.bn(xr)))
     dout = torch.randn(out_ref.shape, generator=g).bfloat16().float()
@@ -69,8 +70,9 @@ def test_fused_node_equals_module_sequence_and_fp64(cuda, stride):
         net.bn.running_mean.zero_(); net.bn.running_var.fill_(1.0); net.bn.num_batches_tracked.zero_()
         assert install_conv_wrw(net) == 1
         xg = x.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-        old = convwrw._BN_ON_LOAD
+        old, old_gen = convwrw._BN_ON_LOAD, convwrw._GEN_BN_ON_LOAD
         convwrw._BN_ON_LOAD = fused
+        convwrw._GEN_BN_ON_LOAD = True                     # opt-in for the general kernel (TSG_CONV_GEN_BN_ON_LOAD=1)
         calls = []
         kp = convwrw.K.provider()
         orig = kp.bn_apply_fwd
@@ -80,7 +82,7 @@ def test_fused_node_equals_module_sequence_and_fp64(cuda, stride):
                 out = bn_relu_conv(net.bn, net.relu, xg, net.conv)
             out.backward(dout.to(cuda).to(out.dtype))
         finally:
-            convwrw._BN_ON_LOAD = old
+            convwrw._BN_ON_LOAD, convwrw._GEN_BN_ON_LOAD = old, old_gen
             del kp.bn_apply_fwd
         assert calls == ([] if fused else ["bn_apply_fwd"])          # the normalised activation was never written
         res[fused] = [t.float().cpu() for t in (out, xg.grad, net.conv.weight.grad, net.bn.weight.grad, net.bn.bias.grad,

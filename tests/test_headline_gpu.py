@@ -11,7 +11,11 @@ with stock PyTorch-ROCm modules (nn.BatchNorm2d, ATen upsample; tools/diag_fp32_
 any layout, Winograd / FFT / GEMM solvers on or off, and varying run to run with MIOpen's solver choice).  So the test
 measures that stock floor on the same device and asserts (a) our path is no further from the CPU than 2x it and within
 4e-3 of the logit scale, (b) loss within 1e-4, (c) the OHEM kept mask equal to the reference's except pixels whose
-probability lies within the logit noise of the threshold, (d) gradients 1e-2 in relative L2 over all parameters."""
+probability lies within the band the MEASURED logit error of the run implies (2 x that error, relative), (d) gradients
+1e-2 in relative L2 over all parameters.  Selection exactness at the real batch (16 images, min_kept 1 048 576) is checked
+without any convolution in between by test_batch16_selection_against_the_oracle_at_the_real_min_kept."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -106,12 +110,16 @@ def test_fp32_logits_loss_and_kept_mask_at_1024(cuda, oracle_run):
         _, info = ohem_select(want, y, 255, 0.7, min_kept)
         assert int(sel[3]) == info["branch"] and int(sel[2]) == info["num_valid"]
         mp = info["mask_prob"].view(B, S, S)
-        # the logits carry the convolutions' ~1e-3 noise, hence p_t differs by up to ~4e-3 relative across devices:
-        # pixels that close to the threshold may fall on either side; everything else must agree exactly
-        near = (mp - info["threshold"]).abs() <= 8e-3 * max(info["threshold"], 1e-30)
+        # The band is the one the MEASURED logit error of this head implies (round 2 used a fixed 8e-3): logits within
+        # `err` of the oracle's move log p_t by at most 2 err (target logit and log-sum-exp by err each), i.e. p_t by a
+        # relative exp(2 err) - 1; on the k-th-value branch the threshold moves by as much again.  Pixels that close to
+        # the threshold may fall on either side; everything else must agree exactly.
+        band = (2.0 if info["branch"] == 0 else 4.0) * 1.05 * err + 4e-7
+        near = (mp - info["threshold"]).abs() <= band * max(info["threshold"], 1e-30)
+        print("head %d: kept-mask exemption band %.2e relative (%d pixels of %d)" % (h, band, int(near.sum()), B * S * S))
         assert torch.equal(kept[~near], info["kept"][~near]), h
         assert abs(int(sel[1]) - info["n_kept"]) <= int(near.sum())
-        assert int(near.sum()) <= 0.01 * B * S * S
+        assert int(near.sum()) <= 0.004 * B * S * S
     loss = net(xd, yd)
     loss.backward()
     assert abs(loss.item() - o["loss"]) <= 1e-4 * max(1.0, abs(o["loss"])), (loss.item(), o["loss"])
@@ -280,3 +288,56 @@ def test_ten_step_trajectory_matches_stock_torch(cuda):
     d_stock = np.abs(np.array(stock_bf16) - np.array(stock)).max()
     assert d_ours <= 2.0 * d_stock + 2e-2, (d_ours, d_stock)
     assert ours_bf16[-1] < ours_bf16[0] and stock[-1] < stock[0]                  # and it trains
+
+
+def test_batch16_selection_against_the_oracle_at_the_real_min_kept(cuda):
+    """VERDICT r2 item 5c: the headline fp32 test runs batch 2, so its k-th order statistic is taken over 2 M candidates;
+    BASELINE config 2 selects among 16.8 M with min_kept = 1 048 576 (train.py:48-49).  Here the ORACLE's selection
+    (loss_opr.py:68-98 restated, run on the host) and the HIP kernels see the same 16 x 19 x 1024 x 1024 fp32 logits — no
+    convolution in between, so what is compared is the selection alone, in the k-th-value branch:
+      * the device threshold is bit-equal to torch.sort(p_device)[k-1] (the reference's own statement on the device's
+        probabilities) and within 2 ulp of the oracle's threshold (two devices' expf);
+      * the kept INDICES equal the oracle's everywhere except pixels whose probability lies within 2 ulp of the threshold
+        (counted and bounded);
+      * the loss is within 1e-4."""
+    from oracle import ohem_ref
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    B, C, S = 16, 19, 1024
+    k = B * S * S // 16
+    g = torch.Generator().manual_seed(1)
+    t = torch.randint(0, C, (B, S, S), generator=g)
+    t[:, :8] = 255
+    t2 = t.clone()
+    t2[t2 == 255] = 0
+    flip = torch.rand(t.shape, generator=g) < 0.03          # 3 % wrong labels: fewer than P / 16 pixels have p <= 0.7
+    t2[flip] = torch.randint(0, C, (int(flip.sum()),), generator=g)
+    pred = torch.randn(B, C, S, S, generator=g)
+    pred.scatter_add_(1, t2[:, None], torch.full((B, 1, S, S), 8.0))
+    del t2, flip
+    with torch.no_grad():
+        loss_ref, info = ohem_ref.ohem_cross_entropy(pred, t, 255, 0.7, k, None, return_info=True)
+    assert info["branch"] == 1 and info["threshold"] > 0.7
+    td = t.to(cuda)
+    loss, nll, lse, sel = kp.ohem_fwd(pred.to(cuda), td, 255, 0.7, k, None)
+    sel = sel.cpu()
+    assert int(sel[3]) == 1 and int(sel[2]) == info["num_valid"]
+    p_dev = kp.ohem_target_prob(nll, td, C, 255).cpu()
+    thr_dev = sel[0:1].view(torch.float32).item()
+    # the reference's statement on the device's own probabilities: bit-exact
+    assert int(sel[0]) == torch.sort(p_dev)[0][k - 1].view(torch.int32).item()
+    thr = info["threshold"]
+    assert abs(thr_dev - thr) <= 4e-7 * thr, (thr_dev, thr)
+    valid = t.view(-1) != 255
+    kept_dev = valid & (p_dev <= thr_dev)
+    assert int(sel[1]) == int(kept_dev.sum())
+    mp = info["mask_prob"]
+    near = (mp - thr).abs() <= 4e-7 * thr
+    kept_ref = info["kept"].view(-1)
+    assert torch.equal(kept_dev[~near], kept_ref[~near])
+    n_near = int(near.sum())
+    print("batch 16: threshold %.9g (oracle %.9g), kept %d (oracle %d), %d pixels within 2 ulp of the threshold"
+          % (thr_dev, thr, int(sel[1]), info["n_kept"], n_near))
+    assert n_near <= 64 and abs(int(sel[1]) - info["n_kept"]) <= n_near
+    assert abs(loss.item() - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref)))

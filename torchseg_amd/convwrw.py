@@ -90,6 +90,12 @@ class _ConvWrwFn(torch.autograd.Function):
 # BatchNorm statistics of the output in its epilogue (every one of these convolutions feeds a SyncBatchNorm)
 _OWN_GEN = _os.environ.get("TSG_CONV_GEN", "1") != "0"
 _GEN_STATS = _os.environ.get("TSG_CONV_GEN_STATS", "1") != "0"
+# TSG_CONV_GEN_BN_ON_LOAD=0|1 (default 0): BatchNorm + ReLU in front of such a layer applied while it loads its input.
+# Bit-equal to the separate pass (tests/test_bnconv_gpu.py) and it never writes the normalised activation, but measured
+# slower in the step (same box: 1103 img/s with it, 1116 without, gpurun_out/r3d): the 6 BatchNorm passes it removes
+# (layer2-4's bn1: ~0.1 ms) cost less than the transform adds to the staging code of 12 convolution / weight-gradient
+# launches.  Opt-in, like the round-2 finding for the 64-channel layers (time-neutral there, kept for the memory).
+_GEN_BN_ON_LOAD = _os.environ.get("TSG_CONV_GEN_BN_ON_LOAD", "0") == "1"
 
 
 class _ConvGenFn(torch.autograd.Function):
@@ -160,12 +166,14 @@ class WrwConv2d(nn.Conv2d):
 
 
 class _BnReluConvFn(torch.autograd.Function):
-    """conv(relu(bn(x))) for the 64 -> 64 3x3 layers with the normalised activation never stored: the convolution
-    (tsg_conv3x3_c64_*_fwd) and its weight gradient (tsg_conv3x3_wrw_*_norm) apply a x + b, ReLU while they stage x; the
-    data gradient of the convolution feeds the ordinary SyncBN backward, which needs dy and x only."""
+    """conv(relu(bn(x))) for the 3x3 layers our kernels cover, with the normalised activation never stored: the
+    convolution (tsg_conv3x3_c64_*_fwd for 64 -> 64, tsg_conv3x3_gen_fwd for every other stride-1 layer) and its weight
+    gradient (tsg_conv3x3_wrw_*_norm) apply a x + b, ReLU while they stage x; the data gradient of the convolution feeds
+    the ordinary SyncBN backward, which needs dy and x only.  Second output: the statistics partial of y (general
+    kernel) or an empty tensor."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, use_batch_stats, group, hint, weight, wb, stride, wrt):
+    def forward(ctx, x, gamma, beta, bn, use_batch_stats, group, hint, weight, wb, stride, wrt, gen=False, out_stats=False):
         from . import syncbn as S
         kp = K.provider()
         layout, N, C, HW = K.bn_layout(x)
@@ -179,27 +187,39 @@ class _BnReluConvFn(torch.autograd.Function):
             mean = bn.running_mean.float()
             invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
             fp = kp.bn_affine(mean, invstd, g32, b32)
-        y = kp.conv3x3_c64_fwd(x, wb, stride=stride, in_ab=fp)
-        ctx.save_for_backward(x, wb, gamma, beta, invstd, fp, count_dev)
-        ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype)
+        partial = None
+        if gen:
+            out = kp.conv3x3_gen_fwd(x, kp.conv3x3_gen_prep_filter(weight, 0, x), weight.shape[0], with_stats=out_stats,
+                                     in_ab=fp)
+            y, partial = out if out_stats else (out, None)
+        else:
+            y = kp.conv3x3_c64_fwd(x, wb, stride=stride, in_ab=fp)
+        if partial is None:
+            partial = x.new_empty(0, dtype=torch.float32)
+        ctx.save_for_backward(x, weight if gen else wb, gamma, beta, invstd, fp, count_dev)
+        ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype, gen)
         ctx.wrt = wrt
-        return y
+        ctx.mark_non_differentiable(partial)
+        return y, partial
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial):
         from . import syncbn as S
         kp = K.provider()
         x, wb, gamma, beta, invstd, fp, count_dev = ctx.saved_tensors
-        layout, N, C, HW, use_batch_stats, group, world, stride, wdtype = ctx.cfg
+        layout, N, C, HW, use_batch_stats, group, world, stride, wdtype, gen = ctx.cfg
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         dw = kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp)
-        rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
-        if stride == 2:
-            da = kp.conv3x3_c64_s2_dgrad(dy, rot, (x.shape[2], x.shape[3]))
+        if gen:                                                  # wb is the fp32 master weight here
+            da = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(wb, 1, dy), wb.shape[1])
         else:
-            da = kp.conv3x3_c64_fwd(dy, rot)
+            rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
+            if stride == 2:
+                da = kp.conv3x3_c64_s2_dgrad(dy, rot, (x.shape[2], x.shape[3]))
+            else:
+                da = kp.conv3x3_c64_fwd(dy, rot)
         partial, Sn = kp.bn_bwd_reduce(da, x, None, layout, N, C, HW, fp, True)
         dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
                                              world, x.device)
@@ -209,7 +229,7 @@ class _BnReluConvFn(torch.autograd.Function):
         else:
             dgamma = dgamma.to(gamma.dtype)
             dbeta = dbeta.to(beta.dtype) if beta is not None else None
-        return dx, dgamma, dbeta, None, None, None, None, dw.to(wdtype), None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, dw.to(wdtype), None, None, None, None, None
 
 
 class _StemBnReluConvFn(torch.autograd.Function):
@@ -306,31 +326,42 @@ _BN_ON_LOAD = _os.environ.get("TSG_BN_ON_LOAD", "1") != "0"
 def bn_relu_conv(bn, relu, x, conv):
     """`conv(relu(bn(x)))` — seg_oprs.py:39-46 followed by the next ConvBnRelu's convolution (bisenet network.py:117-118),
     BasicBlock's bn1 -> relu -> conv2 (resnet.py:36-46).  One fused autograd node on HIP tensors when `bn` is our
-    SyncBatchNorm and `conv` one of the 64 -> 64 3x3 layers the conv64 kernels cover; the three modules otherwise."""
+    SyncBatchNorm and `conv` one of the 3x3 layers our convolution kernels cover (64 -> 64 stride 1 / 2: conv64; any other
+    stride-1 layer with C_in <= 512: the general kernel); the three modules otherwise."""
     from .syncbn import SyncBatchNorm
     from .furnace_glue import norm_act
-    if (_BN_ON_LOAD and _OWN_C64 and relu is not None and isinstance(bn, SyncBatchNorm) and isinstance(conv, WrwConv2d)
+    if (_BN_ON_LOAD and relu is not None and isinstance(bn, SyncBatchNorm) and isinstance(conv, WrwConv2d)
             and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16
-            and x.shape[1] == 64 and conv.in_channels == 64 and conv.out_channels == 64 and conv.bias is None
+            and x.shape[1] == conv.in_channels and conv.bias is None
             and conv.weight.dtype == torch.float32 and conv.weight.requires_grad and torch.is_grad_enabled()
             and bn.momentum is not None and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
-            and conv.weight.is_contiguous(memory_format=torch.channels_last)
-            and K.provider().conv3x3_c64_supported(x, conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
-                                                   conv.groups)):
-        bn._check_input_dim(x)
-        use_batch_stats = bn.training or not bn.track_running_stats
-        hint = None
-        if use_batch_stats and hasattr(x, "_tsg_bn_partial"):
-            from .stemconv import take_bn_partial
-            hint = take_bn_partial(x)
-        with torch.autocast("cuda", enabled=False):
-            if _SHADOW:
-                from .shadow import bank
-                wb, wrt = bank.get(conv.weight, want_rot=True)
-            else:
-                wb, wrt = conv.weight.detach().to(torch.bfloat16), None
-            return _BnReluConvFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, hint, conv.weight,
-                                       wb, conv.stride[0], wrt)
+            and conv.weight.is_contiguous(memory_format=torch.channels_last)):
+        c64 = (_OWN_C64 and conv.in_channels == 64 and conv.out_channels == 64
+               and K.provider().conv3x3_c64_supported(x, conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
+                                                      conv.groups))
+        gen = (not c64) and _GEN_BN_ON_LOAD and conv.in_channels <= 512 and _gen_eligible(x, conv) \
+            and K.provider().conv3x3_wrw_supported(x, conv.weight, 1, conv.padding[0], conv.dilation[0], conv.groups)
+        if c64 or gen:
+            bn._check_input_dim(x)
+            use_batch_stats = bn.training or not bn.track_running_stats
+            hint = None
+            if use_batch_stats and hasattr(x, "_tsg_bn_partial"):
+                from .stemconv import take_bn_partial
+                hint = take_bn_partial(x)
+            with torch.autocast("cuda", enabled=False):
+                if gen:
+                    wb, wrt = None, None
+                elif _SHADOW:
+                    from .shadow import bank
+                    wb, wrt = bank.get(conv.weight, want_rot=True)
+                else:
+                    wb, wrt = conv.weight.detach().to(torch.bfloat16), None
+                y, partial = _BnReluConvFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, hint,
+                                                 conv.weight, wb, conv.stride[0], wrt, gen, gen and _GEN_STATS and conv.training)
+            if partial.numel():
+                from .stemconv import attach_bn_partial
+                attach_bn_partial(y, partial)
+            return y
     return conv(norm_act(bn, relu, x))
 
 

@@ -42,7 +42,6 @@ constexpr int G3_PS = 24;                                // LDS pixel stride in 
 constexpr int G3_NPX = G3_PH * G3_PW;                    // 340 patch pixels
 constexpr int G3_PATCH = G3_NPX * G3_PS;                 // bf16 elements of one patch buffer (16,320 B)
 constexpr int G3_NPV = G3_NPX * 2;                       // 16-byte vectors of a patch chunk: 680
-constexpr int G3_THREADS = 512;
 constexpr int G3_MAX_AFF_C = 512;                        // normalise-on-load: a / b rows staged in LDS
 
 struct G3Geom {
@@ -51,11 +50,16 @@ struct G3Geom {
   int nchunks, noct, nslots;                             // Cin / 16, Cout / BN, persistent blocks per oc tile
 };
 
-template <int BN> struct G3Cfg {
-  static constexpr int NOB = BN / 64;                    // 32-channel blocks per wave
+// BN output channels per block, NW waves: 8 waves = 2 (oc halves) x 4 (row pairs), one block per CU; 4 waves = 1 x 4 with
+// BN = 64, two blocks per CU that run out of phase and cover each other's staging / barriers (the conv64 finding)
+template <int BN, int NW> struct G3Cfg {
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int WO = NW / 4;                      // waves along the output channels
+  static constexpr int NOB = BN / 32 / WO;               // 32-channel blocks per wave
   static constexpr int FELEMS = 9 * BN * G3_KC;          // bf16 elements of one filter slab
   static constexpr int NFV = FELEMS / 8;                 // 16-byte vectors of a filter slab: 2304 / 1152
-  static constexpr int NFU = (NFV + G3_THREADS - 1) / G3_THREADS;   // per thread: 5 / 3 (the last one partly)
+  static constexpr int NFU = (NFV + THREADS - 1) / THREADS;          // per thread: 5 / 3 / 5 (the last one partly)
+  static constexpr int NPU = (G3_NPV + THREADS - 1) / THREADS;       // patch vectors per thread: 2 / 3
   static constexpr int OS = BN + 8;                      // epilogue staging: bf16 per pixel row
   static constexpr size_t LDS = (size_t)(2 * FELEMS + 2 * G3_PATCH) * 2 + 2 * G3_MAX_AFF_C * 4;
   static_assert(256 * OS <= 2 * FELEMS, "the output tile is staged in the two filter buffers");
@@ -72,13 +76,13 @@ __device__ __forceinline__ uint4 g3_affine_relu(uint4 v, const float* __restrict
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int BN, bool AFF, bool STATS>
-__global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+template <int BN, int NW, bool AFF, bool STATS>
+__global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
                                                              bf16_t* __restrict__ y, G3Geom g,
                                                              const float* __restrict__ in_ab,
                                                              float* __restrict__ partial) {
-  using Cfg = G3Cfg<BN>;
-  constexpr int NOB = Cfg::NOB, NFU = Cfg::NFU, OS = Cfg::OS, OCB = BN / 32;
+  using Cfg = G3Cfg<BN, NW>;
+  constexpr int NOB = Cfg::NOB, NFU = Cfg::NFU, NPU = Cfg::NPU, OS = Cfg::OS, OCB = BN / 32, G3_THREADS = Cfg::THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
   bf16_t* fbuf = reinterpret_cast<bf16_t*>(g3_smem);                       // [2][FELEMS]
   bf16_t* pbuf = fbuf + 2 * Cfg::FELEMS;                                   // [2][G3_PATCH]
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __re
   bf16_t* outs = fbuf;                                                     // epilogue: [256 pixels][OS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
-  const int wo = wave & 1, wp = wave >> 1;               // oc half of the tile, row pair of the tile
+  const int wo = wave % Cfg::WO, wp = wave / Cfg::WO;    // oc part of the tile, row pair of the tile
   // XCD-aware persistent mapping: the blocks of one slot (same pixel tiles, all oc tiles) sit on one XCD
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int oct = jb % g.noct, slot = (jb / g.noct) * 8 + xcd;
@@ -96,13 +100,13 @@ __global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __re
   }
 
   // staging descriptors
-  int prc[2];                                            // patch vector u: pr | pc << 8 | part << 16, or -1
+  int prc[NPU];                                          // patch vector u: pr | pc << 8 | part << 16, or -1
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NPU; ++u) {
     const int v = tid + G3_THREADS * u, pp = v >> 1;
     prc[u] = v < G3_NPV ? ((pp / G3_PW) | ((pp % G3_PW) << 8) | ((v & 1) << 16)) : -1;
   }
-  uint4 rf[NFU], rp[2];
+  uint4 rf[NFU], rp[NPU];
   const bf16_t* wslab = wf + (int64_t)oct * g.nchunks * Cfg::FELEMS;
 
   // STATS: the thread's 8 channels (16-byte part tid % (BN / 8)) over the pixels it stores: tid / (BN / 8) + k * 4096 / BN
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __re
         if (u < NFU - 1 || v < Cfg::NFV) rf[u] = *reinterpret_cast<const uint4*>(ws + (int64_t)v * 8);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NPU; ++u) {
         const int ih = oh0 - 1 + (prc[u] & 0xff), iw = ow0 - 1 + ((prc[u] >> 8) & 0xff);
         rp[u] = make_uint4(0u, 0u, 0u, 0u);
         if (prc[u] >= 0 && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __re
       }
       bf16_t* pbw = pbuf + buf * G3_PATCH;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NPU; ++u)
         if (prc[u] >= 0) {
           uint4 v = rp[u];
           const int part = (prc[u] >> 16) & 1;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void conv3g_fwd_k(const bf16_t* __re
   if (STATS) {                                           // fold the pixel groups in a fixed order
     constexpr int VPP = BN / 8, NG = G3_THREADS / VPP;    // 32 / 64 pixel groups
     __syncthreads();
-    float* red = reinterpret_cast<float*>(fbuf);         // [NG][2][BN] floats: 32 KB, the filter buffers are free now
+    float* red = reinterpret_cast<float*>(fbuf);         // [NG][2][BN] floats: <= 32 KB, the filter buffers are free now
     const int part = tid % VPP, q = tid / VPP;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -285,17 +289,27 @@ __global__ __launch_bounds__(256) void g3_prep_filter_k(const TI* __restrict__ w
   *reinterpret_cast<uint4*>(out + v * 8) = o;
 }
 
-// Output channels per block: 128 when C_out allows it and the launch still has >= 192 (pixel tile, oc tile) work items
-// for the 256 CUs; 64 otherwise (BiSeNet's 512 -> 128 attention-refinement 3x3 on the 32 x 32 map has 64 pixel tiles:
-// 64-wide tiles give 128 blocks instead of 64).  The prepared filter is laid out for the width it was made for.
+// Output channels per block.  Default 64 with 4-wave blocks, two per CU: measured over BiSeNet's ten layer shapes
+// (tools/bench_conv3g.py, profiles/r03_conv3g_configs.log) 1266 us per step of forwards against 1278 us for one 8-wave
+// 128-channel block per CU and 1418 us for 8-wave 64-channel blocks — two independent blocks per CU run out of phase and
+// cover each other's staging and barriers, which is worth more than reading x once instead of twice (the second read is
+// an L2 hit: XCD-aware mapping).  TSG_CONV3G_BN=128 selects the wide tile where C_out allows it (tests cover both).
+// The prepared filter is laid out for the width it was made for.
 static int g3_bn(int64_t B, int64_t H, int64_t W, int Cout) {
+  (void)B; (void)H; (void)W;
   if (Cout % 128) return 64;
-  if (const char* e = getenv("TSG_CONV3G_BN")) {         // tests / tuning: force a width
+  if (const char* e = getenv("TSG_CONV3G_BN")) {
     const int v = atoi(e);
     if (v == 64 || v == 128) return v;
   }
-  const int64_t tiles = B * ((H + G3_TH - 1) / G3_TH) * ((W + G3_TW - 1) / G3_TW);
-  return tiles * (Cout / 128) >= 192 ? 128 : 64;
+  return 64;
+}
+
+// waves per block: 4 (two blocks per CU) for 64-wide tiles unless TSG_CONV3G_NW=8
+static int g3_nw(int BN) {
+  static const int forced = [] { const char* e = getenv("TSG_CONV3G_NW"); return e ? atoi(e) : 0; }();
+  if (BN == 128) return 8;
+  return forced == 8 ? 8 : 4;
 }
 
 static int g3_geom(G3Geom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN) {
@@ -306,10 +320,11 @@ static int g3_geom(G3Geom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout
   g->B = (int)B; g->H = (int)H; g->W = (int)W; g->Cin = Cin; g->Cout = Cout;
   g->tiles_h = (int)th; g->tiles_w = (int)tw; g->ntiles = (int)(B * th * tw);
   g->nchunks = Cin / G3_KC; g->noct = Cout / BN;
-  // one block per CU (8 waves, ~110 KB of LDS): ~256 blocks in all, a multiple of 8 slots per oc tile (XCD mapping)
+  // one 8-wave block (~110 KB of LDS) or two 4-wave blocks (~74 KB each) per CU: ~256 / ~512 blocks in all, a multiple
+  // of 8 slots per oc tile (XCD mapping)
   static int target = 0;
   if (!target) { const char* e = getenv("TSG_CONV3G_BLOCKS"); target = e ? atoi(e) : 256; if (target < 8) target = 256; }
-  int64_t ns = target / g->noct;
+  int64_t ns = (g3_nw(BN) == 4 ? 2 * target : target) / g->noct;
   if (ns > g->ntiles) ns = g->ntiles;
   ns = (ns + 7) / 8 * 8;
   if (ns < 8) ns = 8;
@@ -377,20 +392,23 @@ int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, 
   if (!aligned16(x) || !aligned16(wf) || !aligned16(y) || (in_ab && !aligned16(in_ab))) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int grid = g.nslots * g.noct;
-#define G3_GO(BNN, AF, STT)                                                                                         \
+#define G3_GO(BNN, NWW, AF, STT)                                                                                    \
   do {                                                                                                              \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3g_fwd_k<BNN, AF, STT>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3Cfg<BNN>::LDS));                 \
-    hipLaunchKernelGGL((conv3g_fwd_k<BNN, AF, STT>), dim3(grid), dim3(G3_THREADS), G3Cfg<BNN>::LDS, st,             \
+    constexpr size_t lds_bytes = G3Cfg<BNN, NWW>::LDS;                                                              \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3g_fwd_k<BNN, NWW, AF, STT>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                       \
+    hipLaunchKernelGGL((conv3g_fwd_k<BNN, NWW, AF, STT>), dim3(grid), dim3(64 * NWW), lds_bytes, st,                \
                        (const bf16_t*)x, (const bf16_t*)wf, (bf16_t*)y, g, in_ab, partial);                         \
   } while (0)
-  if (BN == 128) {
-    if (in_ab) { if (partial) G3_GO(128, true, true); else G3_GO(128, true, false); }
-    else { if (partial) G3_GO(128, false, true); else G3_GO(128, false, false); }
-  } else {
-    if (in_ab) { if (partial) G3_GO(64, true, true); else G3_GO(64, true, false); }
-    else { if (partial) G3_GO(64, false, true); else G3_GO(64, false, false); }
-  }
+#define G3_PICK(BNN, NWW)                                                                                           \
+  do {                                                                                                              \
+    if (in_ab) { if (partial) G3_GO(BNN, NWW, true, true); else G3_GO(BNN, NWW, true, false); }                     \
+    else { if (partial) G3_GO(BNN, NWW, false, true); else G3_GO(BNN, NWW, false, false); }                         \
+  } while (0)
+  if (BN == 128) G3_PICK(128, 8);
+  else if (g3_nw(64) == 8) G3_PICK(64, 8);
+  else G3_PICK(64, 4);
+#undef G3_PICK
 #undef G3_GO
   TSG_CHECK_LAUNCH();
   return 0;

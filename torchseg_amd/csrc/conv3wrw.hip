@@ -330,7 +330,14 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wh = wave & 1;            // oc half, ci half of the 64 x 64 pair
   const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
-  const int pair = blockIdx.x % g.npairs, slot = blockIdx.x / g.npairs;
+  // XCD-aware mapping (round 3).  Consecutive block ids go round-robin over the 8 XCDs (own L2 each).  With
+  // pair = id % npairs the npairs blocks that stream the SAME pixel tiles (one per (oc tile, ci tile) pair: each x tile is
+  // wanted by C_out / 64 of them, each dy tile by C_in / 64) landed on different XCDs, so every one of them fetched its
+  // operands from HBM: 2.01x the algorithmic traffic over the step's 25 launches (profiles/traffic.json, round 2).  Now the
+  // pairs of a slot are consecutive ids on ONE XCD: they run at the same time on the same tiles and the re-reads are
+  // L2 hits.  bpp is a multiple of 8 (w3gen_geom).
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int pair = jb % g.npairs, slot = (jb / g.npairs) * 8 + xcd;
   const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
   if (AFF && tid < 2 * W3_C) abs_[tid] = in_ab[(tid >> 6) * g.Cin + ci0 + (tid & 63)];   // a / b rows of this ci tile
 
@@ -575,7 +582,7 @@ static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t Hin, int64_t Win, int Cin
   int bpp = ((stride == 1 && w3_occ2(g->ntiles) ? 2 * target : target) + g->npairs - 1) / g->npairs;
   if (bpp > g->ntiles) bpp = g->ntiles;
   if (bpp < 1) bpp = 1;
-  g->bpp = bpp;
+  g->bpp = (bpp + 7) / 8 * 8;                                // slots per pair: a multiple of 8 (XCD mapping of the kernel)
   return 0;
 }
 

@@ -266,18 +266,52 @@ __global__ __launch_bounds__(kT) void ohem_pass_a(
 // decide: single block.  Reduces the block partials (fp64, fixed order), picks
 // the branch (loss_opr.py:78-90) and, on the k-th-value branch, walks hist0.
 // =============================================================================
+// Find the bin that holds rank krem.  Called by ALL 64 lanes of one wave (round 3: the serial walk of one thread over
+// up to 4096 bins — a dependent global load per bin — cost 57 + 2 x 159 us per head on trained-like logits, i.e. the whole
+// "selection tail" of the k-th-value branch; bench.py's ohem_kth_branch record).  Every lane sums 8 consecutive bins, a
+// wave scan locates the lane whose run crosses the rank, that lane walks its 8 bins.  Integers only: the result is the
+// one the serial walk gives.
 __device__ void scan_hist(const uint32_t* hist, int bins, int shift, SelState* st) {
-  // thread 0 only: find the bin holding rank krem
-  int64_t r = st->krem, cum = 0;
-  int b = 0;
-  for (; b < bins; ++b) {
-    const int64_t h = hist[b];
-    if (cum + h >= r) break;
-    cum += h;
+  constexpr int CH = 8;
+  const int lane = threadIdx.x & 63;
+  int64_t r = lane == 0 ? st->krem : 0;                  // lane 0 may have written it a moment ago (ohem_decide0)
+  r = __shfl(r, 0, 64);
+  int64_t cum = 0;
+  bool done = false;
+  for (int base = 0; base < bins && !done; base += 64 * CH) {
+    uint32_t h[CH];
+    int64_t sum = 0;
+    const int b0 = base + lane * CH;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { h[j] = b0 + j < bins ? hist[b0 + j] : 0u; sum += h[j]; }
+    int64_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    const int64_t total = __shfl(incl, 63, 64);
+    if (cum + total >= r) {
+      const int64_t excl = incl - sum;
+      if (cum + excl < r && cum + incl >= r) {          // exactly one lane: the first whose run reaches the rank
+        int64_t c = cum + excl;
+        int j = 0;
+        for (; j < CH - 1; ++j) {
+          if (c + h[j] >= r) break;
+          c += h[j];
+        }
+        st->krem = r - c;
+        st->lo_d += (int64_t)(b0 + j) << shift;
+      }
+      done = true;
+    } else {
+      cum += total;
+    }
   }
-  if (b >= bins) b = bins - 1;  // cannot happen when counts are consistent
-  st->krem = r - cum;
-  st->lo_d += (int64_t)b << shift;
+  if (!done && lane == 0) {                              // cannot happen when counts are consistent
+    st->krem = r - cum;
+    st->lo_d += (int64_t)(bins - 1) << shift;
+  }
 }
 
 __global__ __launch_bounds__(kT) void ohem_decide0(
@@ -307,37 +341,43 @@ __global__ __launch_bounds__(kT) void ohem_decide0(
     lsm[0][wv] = c0; lsm[1][wv] = c1; lsm[2][wv] = c2;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  a0 = a1 = a2 = a3 = 0; c0 = c1 = c2 = 0;
-  for (int i = 0; i < kT / 64; ++i) {
-    a0 += dsm[0][i]; a1 += dsm[1][i]; a2 += dsm[2][i]; a3 += dsm[3][i];
-    c0 += lsm[0][i]; c1 += lsm[1][i]; c2 += lsm[2][i];
+  if (threadIdx.x >= 64) return;                         // wave 0 stays: lane 0 decides, all 64 lanes walk the histogram
+  int branch = 0;
+  if (threadIdx.x == 0) {
+    a0 = a1 = a2 = a3 = 0; c0 = c1 = c2 = 0;
+    for (int i = 0; i < kT / 64; ++i) {
+      a0 += dsm[0][i]; a1 += dsm[1][i]; a2 += dsm[2][i]; a3 += dsm[3][i];
+      c0 += lsm[0][i]; c1 += lsm[1][i]; c2 += lsm[2][i];
+    }
+    const int64_t num_valid = c2, cnt_le_all = c0, cnt_le_valid = c1;
+    st->num_valid = num_valid;
+    st->lo_d = 0;
+    const int64_t k = P < min_kept ? P : min_kept;  // loss_opr.py:87
+    if (min_kept > num_valid || num_valid == 0 || min_kept <= 0) {
+      // loss_opr.py:78-80 (only logs) / :80 num_valid == 0 / :85 min_kept == 0: plain CE
+      branch = 2;
+      st->n_kept = num_valid;
+      st->sum = a1;
+      st->wsum = weighted ? a3 : (double)num_valid;
+      st->thr_bits = 0x7f800000u;  // +inf: everything valid is kept
+    } else if (k <= cnt_le_all || levels == 0) {
+      branch = 0;  // k-th smallest <= thresh  =>  threshold stays thresh (loss_opr.py:84,88)
+      st->n_kept = cnt_le_valid;
+      st->sum = a0;
+      st->wsum = weighted ? a2 : (double)cnt_le_valid;
+      st->thr_bits = __float_as_uint(thresh);
+    } else {
+      branch = 1;
+      st->krem = k - cnt_le_all;
+    }
+    st->branch = branch;
+    __threadfence();                                     // krem / lo_d visible to the other lanes' loads below
   }
-  const int64_t num_valid = c2, cnt_le_all = c0, cnt_le_valid = c1;
-  st->num_valid = num_valid;
-  st->lo_d = 0;
-  if (min_kept > num_valid || num_valid == 0 || min_kept <= 0) {
-    // loss_opr.py:78-80 (only logs) / :80 num_valid == 0 / :85 min_kept == 0: plain CE
-    st->branch = 2;
-    st->n_kept = num_valid;
-    st->sum = a1;
-    st->wsum = weighted ? a3 : (double)num_valid;
-    st->thr_bits = 0x7f800000u;  // +inf: everything valid is kept
-    return;
-  }
-  const int64_t k = P < min_kept ? P : min_kept;  // loss_opr.py:87
-  if (k <= cnt_le_all || levels == 0) {
-    st->branch = 0;  // k-th smallest <= thresh  =>  threshold stays thresh (loss_opr.py:84,88)
-    st->n_kept = cnt_le_valid;
-    st->sum = a0;
-    st->wsum = weighted ? a2 : (double)cnt_le_valid;
-    st->thr_bits = __float_as_uint(thresh);
-    return;
-  }
-  st->branch = 1;
-  st->krem = k - cnt_le_all;
+  branch = __shfl(branch, 0, 64);
+  if (branch != 1) return;
   scan_hist(hist0, bins0, shift0, st);
-  if (levels == 1) st->thr_bits = (uint32_t)(st->lo_d + tb + 1);
+  __threadfence();
+  if (threadIdx.x == 0 && levels == 1) st->thr_bits = (uint32_t)(st->lo_d + tb + 1);
 }
 
 // refinement level l >= 1: histogram of the sub-bin index of every element
@@ -370,9 +410,10 @@ __global__ __launch_bounds__(kT) void sel_refine(
 
 __global__ void sel_decide(const uint32_t* __restrict__ hist, int bins, int shift, int last,
                            int64_t tb, SelState* __restrict__ st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0 || st->branch != 1) return;
+  if (threadIdx.x >= 64 || blockIdx.x != 0 || st->branch != 1) return;     // one wave walks the histogram
   scan_hist(hist, bins, shift, st);
-  if (last) st->thr_bits = (uint32_t)(st->lo_d + tb + 1);
+  __threadfence();
+  if (threadIdx.x == 0 && last) st->thr_bits = (uint32_t)(st->lo_d + tb + 1);
 }
 
 // pass C: re-sum nll over valid & p <= thr (k-th value branch only)

@@ -447,11 +447,19 @@ struct MmArgs {
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
-__global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(MmArgs g) {
+// SPLIT (round 3): 8 waves, two per SIMD with different jobs.  Waves 0-3 only read fragments and issue MFMAs; waves 4-7
+// only fetch, transform (the fused softmax: 32 v_exp_f32 + ~130 other VALU instructions per thread and K tile) and
+// write the LDS images of the next K tile.  The round-2 kernel did both in every wave, one wave per SIMD, in order:
+// its counters (profiles/r03_psa_sq_counters.txt) show SQ_ACTIVE_INST_ANY at 48 % of the wave cycles with the MFMA pipe
+// busy 17 % of the time — issue-bound on the staging code.  The matrix pipe and the VALU are separate pipes, so a
+// staging wave and an MFMA wave on one SIMD run concurrently (MI355X_MICROARCH.md, wave scheduling).
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN == 64) ? 2 : 1)) void psa_mm(MmArgs g) {
   typedef MmGeom<BM, BN> G;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = SPLIT && threadIdx.x >= MM_T;    // wave-uniform
+  const bool stages = !SPLIT || producer, computes = !SPLIT || !producer;
+  const int tid = threadIdx.x & (MM_T - 1), lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, sub = (lane >> 4) & 1, i16 = lane & 15;
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr int WROWS = G::WROWS;                        // C rows per wave
@@ -598,11 +606,13 @@ __global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(
 
   // tile t travels in register set t % PF: fetched PF iterations before it is written to LDS
   const int nk = (int)((g.K + MM_BK - 1) / MM_BK);
-  fetch(ra[0], rb[0], 0);
-  stash(ra[0], rb[0], 0, 0);
+  if (stages) {
+    fetch(ra[0], rb[0], 0);
+    stash(ra[0], rb[0], 0, 0);
 #pragma unroll
-  for (int u = 1; u <= PF; ++u)
-    if (u < nk) fetch(ra[u % PF], rb[u % PF], u * MM_BK);
+    for (int u = 1; u <= PF; ++u)
+      if (u < nk) fetch(ra[u % PF], rb[u % PF], u * MM_BK);
+  }
   for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -610,8 +620,11 @@ __global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(
       if (kt >= nk) break;
       const int s = (u + 1) % PF;                        // == (kt + 1) % PF: kt0 is a multiple of PF
       __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
-      if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (kt + 1) * MM_BK);
-      if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (kt + 1 + PF) * MM_BK);
+      if (stages) {
+        if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (kt + 1) * MM_BK);
+        if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (kt + 1 + PF) * MM_BK);
+      }
+      if (!computes) continue;
       const bf16_t* sa = lds + (size_t)(kt & 1) * G::STAGE;
       const bf16_t* sb = sa + G::A_ELEMS;
 #pragma unroll
@@ -650,16 +663,19 @@ __global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(
   // [BM][BN + 4], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
   __syncthreads();
   float* ep = reinterpret_cast<float*>(lds);
+  if (computes) {
 #pragma unroll
-  for (int i = 0; i < G::MI; ++i)
+    for (int i = 0; i < G::MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        ep[row * G::EPI_ROW + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          ep[row * G::EPI_ROW + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+  }
   __syncthreads();
+  // SPLIT: both halves of the block store, the staging waves take the odd passes
   bf16_t* Cg = g.C + b * g.sC;
   constexpr int RPP = MM_T / G::CPR;                     // rows per pass of the block: 32 / 16
   const int cchunk = tid % G::CPR;
@@ -671,6 +687,7 @@ __global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(
   }
 #pragma unroll 4
   for (int q = 0; q < BM / RPP; ++q) {
+    if (SPLIT && (q & 1) != (producer ? 1 : 0)) continue;
     const int row = tid / G::CPR + RPP * q;
     const int64_t m = m0 + row;
     if (m >= g.M || n >= g.N) continue;
@@ -696,7 +713,7 @@ __global__ __launch_bounds__(MM_T, (BM == 128 && BN == 64 ? 2 : 1)) void psa_mm(
   }
 }
 
-template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI>
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT = false>
 static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   g.tiles_m = (int)((g.M + BM - 1) / BM);
   g.tiles_n = (int)((g.N + BN - 1) / BN);
@@ -704,25 +721,28 @@ static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   g.per_xcd = (int)((tiles + 7) / 8);
   { const char* o = getenv("TSG_PSA_ORDER"); g.m_fastest = (o && o[0] == 'm') ? 1 : 0; }
   constexpr size_t lds_bytes = MmGeom<BM, BN>::LDS;
-  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI>),
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI>), dim3((unsigned)(8 * g.per_xcd)), dim3(MM_T),
-                     lds_bytes, st, g);
+  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT>), dim3((unsigned)(8 * g.per_xcd)),
+                     dim3(SPLIT ? 2 * MM_T : MM_T), lds_bytes, st, g);
   TSG_CHECK_LAUNCH();
   return 0;
 }
 
-// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (64-column tiles, round 2) or "128x128x<PF>" (round 3: 2 x 2 wave
-// grid); bring-up / tuning knob, read once; default chosen by measurement
+// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (64-column tiles, round 2), "128x128x<PF>" (round 3: 2 x 2 wave grid)
+// or "split<BM>x<BN>x<PF>" (round 3: 4 MFMA waves + 4 staging waves); bring-up / tuning knob, read once; default chosen
+// by measurement
 static int mm_cfg() {
   static int cfg = -1;
   if (cfg < 0) {
     const char* e = getenv("TSG_PSA_CFG");
-    cfg = 1281281;
+    cfg = 9128641;       // split128x64x1: fwd 92 / bwd 163 us at B = 2, 512 x 3600^2 (128x1 of round 2: 94 / 178), r03 profiles
     if (e) {
       if (!strcmp(e, "256x1")) cfg = 2561; else if (!strcmp(e, "256x2")) cfg = 2562;
       else if (!strcmp(e, "128x1")) cfg = 1281; else if (!strcmp(e, "128x2")) cfg = 1282;
       else if (!strcmp(e, "128x128x1")) cfg = 1281281; else if (!strcmp(e, "128x128x2")) cfg = 1281282;
+      else if (!strcmp(e, "split128x128x1")) cfg = 91281281; else if (!strcmp(e, "split128x128x2")) cfg = 91281282;
+      else if (!strcmp(e, "split128x64x1")) cfg = 9128641; else if (!strcmp(e, "split256x64x1")) cfg = 9256641;
     }
   }
   return cfg;
@@ -738,7 +758,11 @@ static int launch_mm(MmArgs g, hipStream_t st) {
     case 1282: return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI>(g, st);
     case 1281: return launch_mm_cfg<128, 64, 1, A_TR, B_TR, EXPB, EPI>(g, st);
     case 1281282: return launch_mm_cfg<128, 128, 2, A_TR, B_TR, EXPB, EPI>(g, st);
-    default:   return launch_mm_cfg<128, 128, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 1281281: return launch_mm_cfg<128, 128, 1, A_TR, B_TR, EXPB, EPI>(g, st);
+    case 91281282: return launch_mm_cfg<128, 128, 2, A_TR, B_TR, EXPB, EPI, true>(g, st);
+    case 91281281: return launch_mm_cfg<128, 128, 1, A_TR, B_TR, EXPB, EPI, true>(g, st);
+    case 9256641: return launch_mm_cfg<256, 64, 1, A_TR, B_TR, EXPB, EPI, true>(g, st);
+    default:   return launch_mm_cfg<128, 64, 1, A_TR, B_TR, EXPB, EPI, true>(g, st);
   }
 }
 
