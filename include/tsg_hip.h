@@ -290,12 +290,14 @@ int tsg_conv3x3_wrw_gen_norm(const void* x, const float* in_ab, const void* dy, 
  * follows does not re-read y for its statistics.  in_ab (may be NULL): [2][64] fp32 = the a, b rows of a BatchNorm
  * forward pack (tsg_bn_finalize): the convolution then reads relu(a x + b) of x — the BatchNorm + ReLU in front of it
  * (seg_oprs.py:39-46, resnet.py:36-46) applied while the input patch is staged, bit-equal to what tsg_bn_apply_fwd
- * would have written, without writing it; zero padding stays zero. */
+ * would have written, without writing it; zero padding stays zero.  addend (may be NULL; stride 1, not together
+ * with partial): [B,H,W,64] bf16, y = bf16(bf16(conv) + addend): the gradient of a residual block's skip connection
+ * (resnet.py:48-52) added in the epilogue of the first convolution's data gradient. */
 int tsg_conv3x3_c64_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
                               int groups);
 int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W);
-int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, int64_t B,
-                        int64_t H, int64_t W, void* stream);
+int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, const void* addend,
+                        int64_t B, int64_t H, int64_t W, void* stream);
 /* The same for stride 2 (BiSeNet SpatialPath.conv_3x3_1 / conv_3x3_2, network.py:117-118): x [B,H,W,64] ->
  * y [B,OH,OW,64], OH = (H - 1) / 2 + 1; and its data gradient dx [B,H,W,64] from dy [B,OH,OW,64] and the transposed
  * filter wt = tsg_conv3x3_weight_rot180_t(w), evaluated per output parity (9 tap products per 2 x 2 block of dx, every
@@ -323,7 +325,9 @@ int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int 
  *     [S][2][Cout] fp32 sums / square sums of the bf16-rounded outputs, S = tsg_conv3x3_gen_stats_partials(...): the
  *     layout tsg_bn_finalize / tsg_bn_collapse take.  in_ab (may be NULL; Cin <= 512): [2][Cin] fp32 a, b rows of a
  *     BatchNorm forward pack: the convolution reads relu(a x + b) of x, bit-equal to tsg_bn_apply_fwd's output,
- *     zero padding stays zero.
+ *     zero padding stays zero.  addend (may be NULL; not together with partial): [B,H,W,Cout] bf16,
+ *     y = bf16(bf16(conv) + addend) — used for the data gradient of a residual block's first convolution, where the
+ *     gradient of the skip connection (resnet.py:48-52) is added in the epilogue instead of by a separate pass.
  * ---------------------------------------------------------------------- */
 int tsg_conv3x3_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
                               int groups);
@@ -331,8 +335,8 @@ int64_t tsg_conv3x3_gen_filter_elems(int Cin, int Cout);
 int tsg_conv3x3_gen_tile(int64_t B, int64_t H, int64_t W, int Cin, int Cout);
 int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int I, int mode, int BN, void* stream);
 int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN);
-int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, int64_t B,
-                        int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream);
+int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, const void* addend,
+                        int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream);
 
 /* ------------------------------------------------------------------------
  * OHEM 2-D cross entropy — replaces ProbOhemCrossEntropy2d.forward

@@ -41,9 +41,19 @@ _OWN_C64 = _os.environ.get("TSG_CONV_C64", "1") != "0"
 _SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "0") == "1"
 
 
+def _skip_addend(dskip, like_shape):
+    """The gradient of a skip connection as an epilogue addend of the data-gradient kernel (bf16, channels_last,
+    the shape of dx), or None when it cannot be one."""
+    if dskip is None or tuple(dskip.shape) != tuple(like_shape):
+        return None
+    if dskip.dtype != torch.bfloat16:
+        dskip = dskip.to(torch.bfloat16)
+    return dskip.contiguous(memory_format=torch.channels_last)
+
+
 class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, wb, stride, wrt=None):
+    def forward(ctx, x, weight, wb, stride, wrt=None, skip=False):
         # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
         ctx.own = _OWN_C64 and K.provider().conv3x3_c64_supported(x, wb, stride, 1, 1, 1) \
             and wb.is_contiguous(memory_format=torch.channels_last)
@@ -58,21 +68,29 @@ class _ConvWrwFn(torch.autograd.Function):
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
         ctx.dgrad_fwd = _DGRAD_FWD and stride == 1 and (_DGRAD_ANY or weight.shape[0] == weight.shape[1])
-        return y
+        ctx.set_materialize_grads(False)
+        # skip: x is returned as a second output for the block's skip connection, so that the gradient of that path
+        # arrives HERE (dskip) and is added in the epilogue of the data-gradient kernel instead of by autograd's own pass
+        return (y, x) if skip else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, wb = ctx.saved_tensors
+        if dy is None:                                     # only the skip path was used
+            return dskip, None, None, None, None, None
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
         rot = (lambda: ctx.wrt) if ctx.wrt is not None else (lambda: K.provider().conv3x3_weight_rot180_t(wb))
         if ctx.need_dx:
+            add = _skip_addend(dskip, x.shape) if (ctx.own and ctx.stride == 1) else None
             if ctx.own and ctx.stride == 2:
                 dx = K.provider().conv3x3_c64_s2_dgrad(dy, rot(), ctx.in_hw)
             elif ctx.own:
-                dx = K.provider().conv3x3_c64_fwd(dy, rot())
+                dx = K.provider().conv3x3_c64_fwd(dy, rot(), addend=add)
+                if add is not None:
+                    dskip = None
             elif ctx.dgrad_fwd:
                 # dx = conv(dy, rot180(w)^T): the library's forward kernels beat its backward-data kernels on the
                 # symmetric layers (tools/probe_conv2.py); same bf16 operands, fp32 accumulation
@@ -81,8 +99,10 @@ class _ConvWrwFn(torch.autograd.Function):
                 st = ctx.stride
                 dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [st, st], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
+            if dskip is not None:
+                dx = dx + dskip.to(dx.dtype)
         dw = K.provider().conv3x3_wrw(x, dy, stride=ctx.stride)
-        return dx, dw.to(ctx.wdtype), None, None, None
+        return dx, dw.to(ctx.wdtype), None, None, None, None
 
 
 # TSG_CONV_GEN=1|0 (default 1): forward and data gradient of every other stride-1 3x3 layer (C_in % 16 == 0, C_out % 64
@@ -104,7 +124,7 @@ class _ConvGenFn(torch.autograd.Function):
     filter, weight gradient on tsg_conv3x3_wrw_gen.  Second output: the statistics partial of y (or an empty tensor)."""
 
     @staticmethod
-    def forward(ctx, x, weight, with_stats):
+    def forward(ctx, x, weight, with_stats, skip=False):
         kp = K.provider()
         wf = kp.conv3x3_gen_prep_filter(weight, 0, x)
         out = kp.conv3x3_gen_fwd(x, wf, weight.shape[0], with_stats=with_stats)
@@ -112,12 +132,15 @@ class _ConvGenFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.need_dx = x.requires_grad
         ctx.mark_non_differentiable(partial)
-        return y, partial
+        ctx.set_materialize_grads(False)
+        return (y, partial, x) if skip else (y, partial)      # skip: see _ConvWrwFn.forward
 
     @staticmethod
-    def backward(ctx, dy, _dpartial):
+    def backward(ctx, dy, _dpartial, dskip=None):
         kp = K.provider()
         x, weight = ctx.saved_tensors
+        if dy is None:                                     # only the skip path was used
+            return dskip, None, None, None
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -125,11 +148,16 @@ class _ConvGenFn(torch.autograd.Function):
         if ctx.need_dx:
             O, I = weight.shape[0], weight.shape[1]
             if O % 16 == 0 and I % 64 == 0:
-                dx = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(weight, 1, dy), I)
+                add = _skip_addend(dskip, x.shape)
+                dx = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(weight, 1, dy), I, addend=add)
+                if add is not None:
+                    dskip = None
             else:
                 dx = F.conv2d(dy, kp.conv3x3_weight_rot180_t(weight.detach().to(torch.bfloat16)), None, 1, 1)
+            if dskip is not None:
+                dx = dx + dskip.to(dx.dtype)
         dw = kp.conv3x3_wrw(x, dy, stride=1)
-        return dx, dw.to(weight.dtype), None
+        return dx, dw.to(weight.dtype), None, None
 
 
 def _gen_eligible(xb, conv):
@@ -138,8 +166,20 @@ def _gen_eligible(xb, conv):
             and K.provider().conv3x3_gen_supported(xb, conv.weight, 1, conv.padding[0], conv.dilation[0], conv.groups))
 
 
+# TSG_FUSE_SKIP_GRAD=1|0 (default 1): in a residual block whose skip connection is the block input itself (resnet.py:
+# 48-52), the gradient of the skip path is added in the epilogue of conv1's data-gradient kernel (conv_with_skip)
+_FUSE_SKIP = _os.environ.get("TSG_FUSE_SKIP_GRAD", "1") != "0"
+
+
 class WrwConv2d(nn.Conv2d):
     def forward(self, x):
+        return self._forward(x, False)
+
+    def _forward(self, x, want_skip):
+        """want_skip=True: returns (y, x_skip): x_skip is x as a second output of the convolution's autograd node when the
+        fused path is taken, else None.  want_skip=False: returns y."""
+        def ret(y, x_skip=None):
+            return (y, x_skip) if want_skip else y
         if (x.is_cuda and self.bias is None and self.weight.dtype == torch.float32 and x.dim() == 4
                 and self.padding_mode == "zeros" and torch.is_grad_enabled() and self.weight.requires_grad
                 and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and x.dtype == torch.float32
@@ -148,21 +188,37 @@ class WrwConv2d(nn.Conv2d):
             xb = xb.contiguous(memory_format=torch.channels_last)
             if K.provider().conv3x3_wrw_supported(xb, self.weight, self.stride[0], self.padding[0], self.dilation[0],
                                                   self.groups):
+                fuse = want_skip and xb is x and x.requires_grad      # the alias must BE the block input
                 if _gen_eligible(xb, self):
                     with torch.autocast("cuda", enabled=False):
-                        y, partial = _ConvGenFn.apply(xb, self.weight, _GEN_STATS and self.training)
+                        out = _ConvGenFn.apply(xb, self.weight, _GEN_STATS and self.training, fuse)
+                    y, partial = out[0], out[1]
                     if partial.numel():
                         from .stemconv import attach_bn_partial
                         attach_bn_partial(y, partial)      # the SyncBatchNorm behind it skips its statistics pass
-                    return y
+                    return ret(y, out[2] if fuse else None)
                 with torch.autocast("cuda", enabled=False):
                     if _SHADOW and self.weight.is_contiguous(memory_format=torch.channels_last):
                         from .shadow import bank           # bf16 (and rotated) filters kept fresh once per step
                         wb, wrt = bank.get(self.weight, want_rot=True)
                     else:
                         wb, wrt = self.weight.detach().to(torch.bfloat16), None
-                    return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt)
-        return super().forward(x)
+                    own64 = _OWN_C64 and self.stride == (1, 1) and self.in_channels == 64 and self.out_channels == 64
+                    if fuse and own64:
+                        return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, True)
+                    return ret(_ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt))
+        return ret(super().forward(x))
+
+
+def conv_with_skip(conv, x):
+    """`conv(x)` for the first convolution of a residual block whose skip connection is x itself.  Returns (y, x_skip):
+    x_skip is x routed through the convolution's autograd node when our kernels compute its data gradient (then the
+    block must use x_skip for `out += residual`: the skip path's gradient is added in that kernel's epilogue), else None
+    (use x)."""
+    if _FUSE_SKIP and isinstance(conv, WrwConv2d) and conv.stride == (1, 1) and isinstance(x, torch.Tensor) and x.is_cuda \
+            and torch.is_grad_enabled():
+        return conv._forward(x, True)
+    return conv(x), None
 
 
 class _BnReluConvFn(torch.autograd.Function):

@@ -65,6 +65,17 @@ template <int BN, int NW> struct G3Cfg {
   static_assert(256 * OS <= 2 * FELEMS, "the output tile is staged in the two filter buffers");
 };
 
+// bf16(bf16 a + bf16 b) per element, fp32 add: what the eager `a + b` of two bf16 tensors computes
+__device__ __forceinline__ uint4 g3_add_bf16x8(uint4 a, uint4 b) {
+  const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = pack2_bf16(__uint_as_float(x[i] << 16) + __uint_as_float(y[i] << 16),
+                      __uint_as_float(x[i] & 0xffff0000u) + __uint_as_float(y[i] & 0xffff0000u));
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 __device__ __forceinline__ uint4 g3_affine_relu(uint4 v, const float* __restrict__ a, const float* __restrict__ b) {
   uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -80,7 +91,8 @@ template <int BN, int NW, bool AFF, bool STATS>
 __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
                                                              bf16_t* __restrict__ y, G3Geom g,
                                                              const float* __restrict__ in_ab,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial,
+                                                             const bf16_t* __restrict__ addend) {
   using Cfg = G3Cfg<BN, NW>;
   constexpr int NOB = Cfg::NOB, NFU = Cfg::NFU, NPU = Cfg::NPU, OS = Cfg::OS, OCB = BN / 32, G3_THREADS = Cfg::THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
@@ -216,14 +228,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
         }
     __syncthreads();
     constexpr int VPP = BN / 8;                          // 16-byte vectors per pixel
-    bf16_t* yimg = y + (int64_t)bimg * g.H * g.W * g.Cout + oct * BN;
+    const int64_t img_off = (int64_t)bimg * g.H * g.W * g.Cout + oct * BN;
+    bf16_t* yimg = y + img_off;
 #pragma unroll
     for (int k = 0; k < 256 * VPP / G3_THREADS; ++k) {
       const int v = tid + G3_THREADS * k, px = v / VPP, part = v % VPP;
       const int oh = oh0 + (px >> 5), ow = ow0 + (px & 31);
       if (oh < g.H && ow < g.W) {
-        const uint4 o = *reinterpret_cast<const uint4*>(outs + px * OS + part * 8);
-        *reinterpret_cast<uint4*>(yimg + ((int64_t)oh * g.W + ow) * g.Cout + part * 8) = o;
+        uint4 o = *reinterpret_cast<const uint4*>(outs + px * OS + part * 8);
+        const int64_t off = ((int64_t)oh * g.W + ow) * g.Cout + part * 8;
+        // addend: y = bf16(bf16(conv) + addend) — the gradient that reaches the same tensor through a skip connection
+        // (resnet.py:48-52: out += residual), summed here instead of by a separate pass over three tensors
+        if (addend) o = g3_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + img_off + off));
+        *reinterpret_cast<uint4*>(yimg + off) = o;
         if (STATS) {                                     // the values just stored: no second pass over the tile
           const uint32_t w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
@@ -382,9 +399,10 @@ int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int
   return e ? e : g.nslots;
 }
 
-int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, int64_t B, int64_t H,
-                        int64_t W, int Cin, int Cout, int BN, void* stream) {
+int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, const void* addend,
+                        int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream) {
   if (!x || !wf || !y) return TSG_E_NULL;
+  if (addend && (partial || !aligned16(addend))) return partial ? TSG_E_SHAPE : TSG_E_ALIGN;   // statistics are of the convolution
   G3Geom g;
   int e = g3_geom(&g, B, H, W, Cin, Cout, BN);
   if (e) return e;
@@ -398,7 +416,7 @@ int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, 
     TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3g_fwd_k<BNN, NWW, AF, STT>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                       \
     hipLaunchKernelGGL((conv3g_fwd_k<BNN, NWW, AF, STT>), dim3(grid), dim3(64 * NWW), lds_bytes, st,                \
-                       (const bf16_t*)x, (const bf16_t*)wf, (bf16_t*)y, g, in_ab, partial);                         \
+                       (const bf16_t*)x, (const bf16_t*)wf, (bf16_t*)y, g, in_ab, partial, (const bf16_t*)addend);  \
   } while (0)
 #define G3_PICK(BNN, NWW)                                                                                           \
   do {                                                                                                              \

@@ -87,11 +87,23 @@ __device__ __forceinline__ uint4 c6_affine_relu(uint4 v, const float* __restrict
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// bf16(bf16 a + bf16 b) per element, fp32 add: what the eager `a + b` of two bf16 tensors computes
+__device__ __forceinline__ uint4 c6_add_bf16x8(uint4 a, uint4 b) {
+  const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = pack2_bf16(__uint_as_float(x[i] << 16) + __uint_as_float(y[i] << 16),
+                      __uint_as_float(x[i] & 0xffff0000u) + __uint_as_float(y[i] & 0xffff0000u));
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // 4 waves: wave = (row pair wr) * 2 + (oc half wm)
 template <bool STATS, int OCC, bool AFF>
 __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                     bf16_t* __restrict__ y, C6Geom g, float* __restrict__ partial,
-                                                    const float* __restrict__ in_ab) {
+                                                    const float* __restrict__ in_ab,
+                                                    const bf16_t* __restrict__ addend) {
   __shared__ __attribute__((aligned(16))) bf16_t patch[C6_PH * C6_PW * C6_PS];     // 29376 B
   __shared__ __attribute__((aligned(16))) bf16_t outs[C6_TH * C6_TW * C6_PS];      // 18432 B: [pixel][64 oc + 8 pad]
   __shared__ __attribute__((aligned(16))) float abs_[AFF ? 2 * C6_C : 4];
@@ -176,13 +188,18 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
         *reinterpret_cast<uint2*>(outs + ((2 * wr + i) * C6_TW + p) * C6_PS + oc0) = v;
       }
     __syncthreads();
-    bf16_t* yt = y + (((int64_t)tp.b * g.H + tp.oh0) * g.W + tp.ow0) * C6_C;
+    const int64_t tile_off = (((int64_t)tp.b * g.H + tp.oh0) * g.W + tp.ow0) * C6_C;
+    bf16_t* yt = y + tile_off;
     const bool colok = tp.ow0 + spl < g.W;
 #pragma unroll
     for (int qd = 0; qd < C6_TH; ++qd)
-      if (tp.oh0 + qd < g.H && colok)
-        *reinterpret_cast<uint4*>(yt + ((int64_t)qd * g.W + spl) * C6_C + spart * 8) =
-            *reinterpret_cast<const uint4*>(outs + (qd * C6_TW + spl) * C6_PS + spart * 8);
+      if (tp.oh0 + qd < g.H && colok) {
+        uint4 o = *reinterpret_cast<const uint4*>(outs + (qd * C6_TW + spl) * C6_PS + spart * 8);
+        const int64_t off = ((int64_t)qd * g.W + spl) * C6_C + spart * 8;
+        // addend: y = bf16(bf16(conv) + addend): the skip connection's gradient joins the data gradient here
+        if (addend) o = c6_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + tile_off + off));
+        *reinterpret_cast<uint4*>(yt + off) = o;
+      }
     if (STATS) {
       const int c = tid & 63, qd = tid >> 6;
       if (tp.oh0 + qd < g.H) {
@@ -532,10 +549,11 @@ int tsg_conv3x3_c64_stats_partials(int64_t B, int64_t H, int64_t W) {
   return g.ntiles < 256 * c6_occ() ? g.ntiles : 256 * c6_occ();
 }
 
-int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, int64_t B, int64_t H,
-                        int64_t W, void* stream) {
+int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, const float* in_ab, const void* addend,
+                        int64_t B, int64_t H, int64_t W, void* stream) {
   if (!x || !w || !y) return TSG_E_NULL;
   if (in_ab && !aligned16(in_ab)) return TSG_E_ALIGN;
+  if (addend && (partial || !aligned16(addend))) return partial ? TSG_E_SHAPE : TSG_E_ALIGN;
   C6Geom g;
   if (!c6_geom(B, H, W, &g)) return TSG_E_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return TSG_E_ALIGN;
@@ -543,7 +561,7 @@ int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, c
   const int occ = c6_occ();                              // also fixes the number of statistics partials
   const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
 #define C6_GO(ST, OC, AF) hipLaunchKernelGGL((conv64_fwd_k<ST, OC, AF>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
-                                             (const bf16_t*)w, (bf16_t*)y, g, partial, in_ab)
+                                             (const bf16_t*)w, (bf16_t*)y, g, partial, in_ab, (const bf16_t*)addend)
   if (in_ab) { if (partial) C6_GO(true, 2, true); else C6_GO(false, 2, true); }
   else if (partial) { if (occ == 1) C6_GO(true, 1, false); else C6_GO(true, 2, false); }
   else { if (occ == 1) C6_GO(false, 1, false); else C6_GO(false, 2, false); }

@@ -48,10 +48,17 @@ class BasicBlock(_Block):
 
     def forward(self, x):
         if x.is_cuda:                                   # bn1 + relu applied while conv2 loads its input, where covered
-            from torchseg_amd.convwrw import bn_relu_conv
-            out = bn_relu_conv(self.bn1, self.relu, self.conv1(x), self.conv2)
-        else:
-            out = self.conv2(norm_act(self.bn1, self.relu, self.conv1(x)))
+            from torchseg_amd.convwrw import bn_relu_conv, conv_with_skip
+            skip = None
+            if self.downsample is None and self.stride == 1:
+                # the skip connection is x itself: route it through conv1's autograd node, whose data-gradient kernel
+                # then adds the skip path's gradient in its epilogue (no separate pass over three tensors)
+                c1, skip = conv_with_skip(self.conv1, x)
+            else:
+                c1 = self.conv1(x)
+            out = bn_relu_conv(self.bn1, self.relu, c1, self.conv2)
+            return norm_act(self.bn2, self.relu_inplace, out, residual=skip if skip is not None else self._identity(x))
+        out = self.conv2(norm_act(self.bn1, self.relu, self.conv1(x)))
         return norm_act(self.bn2, self.relu_inplace, out, residual=self._identity(x))
 
 

@@ -563,7 +563,7 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_c64_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                        weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1, in_ab=None):
+    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1, in_ab=None, addend=None):
         """x [B,64,H,W] bf16 channels_last, wb bf16 [64,64,3,3] channels_last, 3x3 / stride 1 or 2 / padding 1
         -> y (channels_last) or (y, partial [S,2,64]).  in_ab: fp32 [>=2, 64] whose rows 0 / 1 are the a / b of a BN forward
         pack: the convolution reads relu(a x + b) (normalise-on-load)."""
@@ -584,7 +584,18 @@ class HipKernels:
         if with_stats:
             S = self._count(("c64_stats", stride, B, H, W), lambda: cnt(B, H, W), what)
             partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
-        L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), B, H, W, L.stream_ptr(x)), what)
+        if addend is not None:
+            if stride != 1 or with_stats or addend.shape != y.shape or addend.dtype != y.dtype \
+                    or not addend.is_contiguous(memory_format=torch.channels_last):
+                raise ValueError("conv3x3_c64_fwd: addend needs stride 1, no statistics, a bf16 channels_last tensor of y's shape")
+            L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), None, L.ptr(in_ab), addend.data_ptr(), B, H, W,
+                       L.stream_ptr(x)), what)
+            return y
+        if stride == 1:
+            L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), None, B, H, W,
+                       L.stream_ptr(x)), what)
+        else:
+            L.check(fn(x.data_ptr(), wb.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), B, H, W, L.stream_ptr(x)), what)
         return (y, partial) if with_stats else y
 
     def conv3x3_gen_supported(self, x, weight, stride, padding, dilation, groups):
@@ -616,9 +627,10 @@ class HipKernels:
                                                      bn, L.stream_ptr(weight)), "tsg_conv3x3_gen_prep_filter")
         return out, bn
 
-    def conv3x3_gen_fwd(self, x, wf, Cout, with_stats=False, in_ab=None):
+    def conv3x3_gen_fwd(self, x, wf, Cout, with_stats=False, in_ab=None, addend=None):
         """x [B,Cin,H,W] bf16 channels_last, wf = conv3x3_gen_prep_filter(..., like=x) -> y [B,Cout,H,W] channels_last, or
-        (y, partial [S,2,Cout]).  in_ab: fp32 [>=2, Cin] BN forward pack: the convolution reads relu(a x + b)."""
+        (y, partial [S,2,Cout]).  in_ab: fp32 [>=2, Cin] BN forward pack: the convolution reads relu(a x + b).
+        addend: bf16 channels_last [B,Cout,H,W], y = bf16(bf16(conv) + addend)."""
         if not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.bfloat16:
             raise ValueError("conv3x3_gen_fwd expects a bf16 channels_last input")
         B, Cin, H, W = x.shape
@@ -628,14 +640,17 @@ class HipKernels:
         if in_ab is not None and (in_ab.dtype != torch.float32 or not in_ab.is_contiguous() or in_ab.shape[-1] != Cin):
             raise ValueError("conv3x3_gen_fwd: in_ab must be a contiguous fp32 [>=2, Cin] pack")
         y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        if addend is not None and (with_stats or addend.shape != y.shape or addend.dtype != y.dtype
+                                   or not addend.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("conv3x3_gen_fwd: addend must be a bf16 channels_last tensor of the output's shape (no statistics)")
         partial = None
         if with_stats:
             S = self._count(("g3_stats", B, H, W, Cin, Cout, bn),
                             lambda: self.lib.tsg_conv3x3_gen_stats_partials(B, H, W, Cin, Cout, bn),
                             "tsg_conv3x3_gen_stats_partials")
             partial = torch.empty((S, 2, Cout), dtype=torch.float32, device=x.device)
-        L.check(self.lib.tsg_conv3x3_gen_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab), B, H, W,
-                                             Cin, Cout, bn, L.stream_ptr(x)), "tsg_conv3x3_gen_fwd")
+        L.check(self.lib.tsg_conv3x3_gen_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab),
+                                             L.ptr(addend), B, H, W, Cin, Cout, bn, L.stream_ptr(x)), "tsg_conv3x3_gen_fwd")
         return (y, partial) if with_stats else y
 
     def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw):
