@@ -370,8 +370,9 @@ def main():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--trace-loss", action="store_true", help="debug: print the loss of every timed step (syncs)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "0")),
-                    help="torch.backends.cudnn.benchmark (train.py:35); 0 = immediate mode on the shipped MIOpen find-db (same speed, 100 s faster start)")
+    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("TSG_MIOPEN_FIND", "-1")),
+                    help="torch.backends.cudnn.benchmark (train.py:35); 0 = immediate mode on the shipped MIOpen find-db (same "
+                         "speed, 100 s faster start: the default)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.batch is None:
@@ -409,6 +410,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", init_method="env://")
+    if args.miopen_find < 0:
+        # immediate mode on the shipped find-db (torchseg_amd/miopen_db: the entries MIOpen's find mode wrote for the
+        # four configs at their bench shapes, tools/gpu_r3_g.sh; same speed as cudnn.benchmark = True — train.py:35 —
+        # and a 100 s faster start).  Without entries immediate mode picks kernels 5-10x off (1 ms igemm forwards for
+        # PSPNet's dilated 3x3 layers, profiles/r03_kernel_stats_pspnet.csv, before the db had them)
+        args.miopen_find = 0
     torch.backends.cudnn.benchmark = bool(args.miopen_find)            # train.py:35
 
     from torchseg_amd import kernels as K

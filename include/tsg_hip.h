@@ -171,6 +171,17 @@ int tsg_gap_fwd(const void* x, void* out, int dtype, int layout,
 int tsg_gap_bwd(const void* dout, void* dx, int dtype, int layout,
                 int64_t N, int64_t C, int64_t HW, void* stream);
 
+/* Adaptive average pooling to a small grid, channels_last — nn.AdaptiveAvgPool2d(1 / 2 / 3 / 6) of PSPNet's pyramid
+ * pooling (model/pspnet/ade.pspnet.R50_v1c/network.py:75-109) and PSANet's conv6 input.  x [N,H,W,C] -> out [N,OH,OW,C];
+ * bin o of a dimension covers [floor(o * H / OH), ceil((o + 1) * H / OH)) (ATen's convention), OH <= H, OW <= W.  Forward
+ * = a row-split partial-sum pass + a fold (fp32 workspace of tsg_adaptive_avgpool_nhwc_ws_bytes); backward: every input
+ * pixel gathers the <= 4 bins that contain it.  Deterministic. */
+size_t tsg_adaptive_avgpool_nhwc_ws_bytes(int dtype, int64_t N, int C, int H, int W, int OH, int OW);
+int tsg_adaptive_avgpool_nhwc_fwd(const void* x, void* out, int dtype, int64_t N, int C, int H, int W, int OH, int OW,
+                                  void* ws, size_t ws_bytes, void* stream);
+int tsg_adaptive_avgpool_nhwc_bwd(const void* dout, void* dx, int dtype, int64_t N, int C, int H, int W, int OH, int OW,
+                                  void* stream);
+
 /* Channel gate y = x * s[n,c] (+ x when add_identity): the squeeze-excite
  * multiply of AttentionRefinement (`fm * fm_se`, seg_oprs.py:209-210) and
  * FeatureFusion (`fm + fm * fm_se`, seg_oprs.py:236-237).  s / ds are [N, C] in

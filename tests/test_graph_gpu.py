@@ -26,7 +26,7 @@ def _run(cuda, mode, fused):
     losses = []
     if mode == 0:
         for it in range(WARM + STEPS):
-            loss = bench.train_step(model, opt, imgs, gts, pol, it, 1)
+            loss = bench.train_step(model, opt, (imgs, gts), pol, it, 1)
             if it >= WARM:
                 losses.append(loss.item())
         return losses
@@ -34,9 +34,9 @@ def _run(cuda, mode, fused):
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         for it in range(WARM):
-            bench.train_step(model, opt, imgs, gts, pol, it, 1)
+            bench.train_step(model, opt, (imgs, gts), pol, it, 1)
         torch.cuda.synchronize()
-        graphed = bench.GraphedStep(model, opt, imgs, gts, 1, opt_inside=mode == 2)
+        graphed = bench.GraphedStep(model, opt, (imgs, gts), 1, opt_inside=mode == 2)
         for it in range(STEPS):
             bench.set_lr(opt, pol, WARM + it)
             loss = graphed()

@@ -100,3 +100,34 @@ def test_maxpool_channels_last(cuda, shape, k, s, p, dtype):
     torch.testing.assert_close(y.detach().float().cpu(), yr.detach(), rtol=0, atol=0)
     tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)
+
+
+@pytest.mark.parametrize("case", [(2, 2048, 90, 90, 6), (2, 2048, 90, 90, 3), (2, 2048, 90, 90, 2), (2, 512, 60, 60, 6),
+                                  (3, 24, 7, 10, 3), (1, 64, 33, 47, (5, 4)), (2, 128, 8, 8, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adaptive_avg_pool_channels_last(cuda, case, dtype):
+    """nn.AdaptiveAvgPool2d(s) on channels_last maps (PSPNet's pyramid pooling, pspnet network.py:75-109) against the
+    CPU op the reference calls, in fp64 on the same (bf16-rounded) input: forward and backward, windows that overlap
+    (90 -> 6 ... 7 -> 3) included.  Also through the module the DDP wrapper installs."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torchseg_amd.pool import AdaptiveAvgPool2d, install_adaptive_pool
+    N, C, H, W, out = case
+    if dtype == torch.bfloat16 and C % 8:
+        pytest.skip("bf16 vectors are 8 channels")
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    m = nn.Sequential(nn.AdaptiveAvgPool2d(out))
+    assert install_adaptive_pool(m) == 1 and isinstance(m[0], AdaptiveAvgPool2d)
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = m(xd)
+    xr = x.double().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, out)
+    assert tuple(y.shape) == tuple(yr.shape) and y.is_contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(yr.shape, generator=g).to(dtype)
+    y.backward(dy.to(cuda).contiguous(memory_format=torch.channels_last))
+    yr.backward(dy.double())
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
+    assert xd.grad.is_contiguous(memory_format=torch.channels_last)

@@ -45,7 +45,7 @@ def stats(model, loss):
 model, opt, pol = make()
 ref = []
 for it in range(a.warm + a.steps):
-    loss = bench.train_step(model, opt, imgs, gts, pol, it, 1)
+    loss = bench.train_step(model, opt, (imgs, gts), pol, it, 1)
     if it >= a.warm:
         torch.cuda.synchronize(); ref.append(stats(model, loss))
 del model, opt
@@ -58,7 +58,7 @@ def warm(stream, its):
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         for it in its:
-            bench.train_step(model, opt, imgs, gts, pol, it, 1)
+            bench.train_step(model, opt, (imgs, gts), pol, it, 1)
     torch.cuda.current_stream().wait_stream(stream); torch.cuda.synchronize()
 if a.side == 0:   warm(D, range(a.warm))                                  # everything eager on the default stream
 elif a.side == 1: warm(torch.cuda.Stream(), range(a.warm))               # warm-up on X, capture on Y
@@ -66,7 +66,7 @@ elif a.side == 2: warm(Y, range(a.warm))                                 # warm-
 elif a.side == 3: warm(D, range(1)); warm(Y, range(1, a.warm))           # first step (lazy state) on D, rest on Y
 elif a.side == 4: warm(Y, range(a.warm))                                 # as 2, and the replays + optimizer run on Y too
 elif a.side == 5: warm(Y, range(a.warm - 1)); warm(D, range(a.warm - 1, a.warm))   # last eager step on D
-gr = bench.GraphedStep(model, opt, imgs, gts, 1)
+gr = bench.GraphedStep(model, opt, (imgs, gts), 1)
 run_stream = Y if a.side == 4 else D
 for it in range(a.steps):
     with torch.cuda.stream(run_stream):

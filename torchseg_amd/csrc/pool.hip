@@ -339,6 +339,127 @@ __global__ __launch_bounds__(kT) void maxpool_bwd_nhwc(const T* __restrict__ dy,
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Adaptive average pooling to a SMALL grid, channels_last — the pyramid pooling of PSPNet / PSANet's conv6 input
+// (pspnet network.py:75-109: nn.AdaptiveAvgPool2d(1 / 2 / 3 / 6) of a [2, 2048, 90, 90] map).  The framework's NHWC kernel
+// takes 2.6 ms per call there (one thread per output element walking its 2000-pixel window; profiles/
+// r03_kernel_stats_pspnet.csv: 20 % of the PSPNet step).  Here a window is split over blocks by rows and over the threads
+// of a block by rows again, channels across lanes (16-byte loads), fixed-order folds: two launches, deterministic.
+// Bin boundaries as ATen: [floor(o * H / OH), ceil((o + 1) * H / OH)).
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int ap_start(int o, int in, int out) { return (int)(((int64_t)o * in) / out); }
+__host__ __device__ __forceinline__ int ap_end(int o, int in, int out) { return (int)((((int64_t)o + 1) * in + out - 1) / out); }
+
+// stage 1: block (bin, z, channel tile): rows z, z + RZ, ... of the bin's window -> partial[bin][z][C] (fp32 sums)
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void apool_partial_nhwc(const T* __restrict__ x, int H, int W, int C, int OH, int OW,
+                                                         int gpb, int RZ, float* __restrict__ partial) {
+  __shared__ float red[kT * V];
+  const int G = C / V, RS = kT / gpb;
+  const int tid = threadIdx.x, gl = tid % gpb, rs = tid / gpb;
+  const int g = blockIdx.z * gpb + gl;
+  int64_t t = blockIdx.x;
+  const int ow = (int)(t % OW); t /= OW;
+  const int oh = (int)(t % OH);
+  const int64_t n = t / OH;
+  const int h0 = ap_start(oh, H, OH), h1 = ap_end(oh, H, OH), w0 = ap_start(ow, W, OW), w1 = ap_end(ow, W, OW);
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  if (rs < RS && g < G) {
+    const T* b = x + n * H * (int64_t)W * C + (int64_t)g * V;
+    for (int h = h0 + blockIdx.y * RS + rs; h < h1; h += RZ * RS)
+      for (int w = w0; w < w1; ++w) {
+        PV<T, V> p;
+        p.load(b + ((int64_t)h * W + w) * C);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += p.v[j];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[tid * V + j] = acc[j];
+  __syncthreads();
+  if (rs == 0 && g < G) {
+    float* o = partial + ((int64_t)blockIdx.x * RZ + blockIdx.y) * C + (int64_t)g * V;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float sum = 0.f;
+      for (int q = 0; q < RS; ++q) sum += red[(q * gpb + gl) * V + j];
+      o[j] = sum;
+    }
+  }
+}
+
+// stage 2: out[bin][c] = (sum over z of partial[bin][z][c]) / window size
+template <typename T>
+__global__ __launch_bounds__(kT) void apool_finish(const float* __restrict__ partial, int64_t bins, int C, int RZ, int H,
+                                                   int W, int OH, int OW, T* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= bins * C) return;
+  const int64_t bin = i / C;
+  const int c = (int)(i % C);
+  const int ow = (int)(bin % OW), oh = (int)((bin / OW) % OH);
+  const float cnt = (float)((ap_end(oh, H, OH) - ap_start(oh, H, OH)) * (ap_end(ow, W, OW) - ap_start(ow, W, OW)));
+  float sum = 0.f;
+  for (int z = 0; z < RZ; ++z) sum += partial[(bin * RZ + z) * C + c];
+  st1<T>(out + i, sum / cnt);
+}
+
+// backward: dx[n, h, w, :] = sum over the bins that contain (h, w) of dout[n, oh, ow, :] / window size
+template <typename T, int V>
+__global__ __launch_bounds__(kT) void apool_bwd_nhwc(const T* __restrict__ dout, int64_t N, int H, int W, int C, int OH,
+                                                     int OW, T* __restrict__ dx) {
+  const int64_t G = C / V, total = N * H * (int64_t)W * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int64_t g = i % G;
+    int64_t t = i / G;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int64_t n = t / H;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    const int oh_c = (int)(((int64_t)h * OH) / H), ow_c = (int)(((int64_t)w * OW) / W);
+    for (int oh = oh_c > 0 ? oh_c - 1 : 0; oh <= oh_c + 1 && oh < OH; ++oh) {
+      const int h0 = ap_start(oh, H, OH), h1 = ap_end(oh, H, OH);
+      if (h < h0 || h >= h1) continue;
+      for (int ow = ow_c > 0 ? ow_c - 1 : 0; ow <= ow_c + 1 && ow < OW; ++ow) {
+        const int w0 = ap_start(ow, W, OW), w1 = ap_end(ow, W, OW);
+        if (w < w0 || w >= w1) continue;
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+        PV<T, V> p;
+        p.load(dout + ((n * OH + oh) * OW + ow) * C + g * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += p.v[j] * inv;
+      }
+    }
+    PV<T, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = acc[j];
+    o.store(dx + i * V);
+  }
+}
+
+struct ApGeom { int gpb, RZ, ctiles; };
+static ApGeom ap_geom(int64_t N, int C, int H, int OH, int OW, int V) {
+  ApGeom g;
+  const int G = C / V;
+  g.gpb = kT;
+  while (g.gpb > G) g.gpb >>= 1;
+  if (g.gpb < 1) g.gpb = 1;
+  g.ctiles = (G + g.gpb - 1) / g.gpb;
+  const int RS = kT / g.gpb;
+  const int rows = (H + OH - 1) / OH + 1;                            // longest window
+  int64_t rz = (1024 + N * OH * OW * g.ctiles - 1) / (N * OH * OW * g.ctiles);   // ~1024 blocks in all
+  const int64_t rz_max = (rows + RS - 1) / RS;                       // at least one row per splitter
+  if (rz > rz_max) rz = rz_max;
+  if (rz < 1) rz = 1;
+  if (rz > 64) rz = 64;
+  g.RZ = (int)rz;
+  return g;
+}
+
 struct GapGeom { int gt, R, S; int64_t rpb; };
 static GapGeom gap_geom(int64_t N, int64_t C, int64_t HW, int V) {
   GapGeom g;
@@ -410,6 +531,63 @@ int tsg_gap_fwd(const void* x, void* out, int dtype, int layout, int64_t N, int6
     hipLaunchKernelGGL((gap_finish<float>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, inv, (float*)out);
   else
     hipLaunchKernelGGL((gap_finish<bf16_t>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, inv, (bf16_t*)out);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t tsg_adaptive_avgpool_nhwc_ws_bytes(int dtype, int64_t N, int C, int H, int W, int OH, int OW) {
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return 0;
+  const ApGeom g = ap_geom(N, C, H, OH, OW, V);
+  return (size_t)N * OH * OW * g.RZ * C * sizeof(float);
+}
+
+int tsg_adaptive_avgpool_nhwc_fwd(const void* x, void* out, int dtype, int64_t N, int C, int H, int W, int OH, int OW,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out || !ws) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || OH > H || OW > W) return TSG_E_SHAPE;
+  if (N * OH * (int64_t)OW > 0x7fffffffLL) return TSG_E_SHAPE;
+  if (ws_bytes < tsg_adaptive_avgpool_nhwc_ws_bytes(dtype, N, C, H, W, OH, OW)) return TSG_E_WS;
+  if (!aligned16(x) || !aligned16(ws)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const ApGeom g = ap_geom(N, C, H, OH, OW, V);
+  const int64_t bins = N * OH * OW;
+  const dim3 grid((unsigned)bins, (unsigned)g.RZ, (unsigned)g.ctiles);
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((apool_partial_nhwc<float, 4>), grid, dim3(kT), 0, st, (const float*)x, H, W, C, OH, OW, g.gpb, g.RZ,
+                       (float*)ws);
+  else
+    hipLaunchKernelGGL((apool_partial_nhwc<bf16_t, 8>), grid, dim3(kT), 0, st, (const bf16_t*)x, H, W, C, OH, OW, g.gpb, g.RZ,
+                       (float*)ws);
+  TSG_CHECK_LAUNCH();
+  const dim3 fgrid((unsigned)ceil_div_i(bins * C, kT));
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((apool_finish<float>), fgrid, dim3(kT), 0, st, (const float*)ws, bins, C, g.RZ, H, W, OH, OW, (float*)out);
+  else
+    hipLaunchKernelGGL((apool_finish<bf16_t>), fgrid, dim3(kT), 0, st, (const float*)ws, bins, C, g.RZ, H, W, OH, OW,
+                       (bf16_t*)out);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_adaptive_avgpool_nhwc_bwd(const void* dout, void* dx, int dtype, int64_t N, int C, int H, int W, int OH, int OW,
+                                  void* stream) {
+  if (!dout || !dx) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (N <= 0 || C <= 0 || C % V || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || OH > H || OW > W) return TSG_E_SHAPE;
+  if (!aligned16(dout) || !aligned16(dx)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (N * H * (int64_t)W * (C / V) + kT - 1) / kT;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((apool_bwd_nhwc<float, 4>), dim3((unsigned)blocks), dim3(kT), 0, st, (const float*)dout, N, H, W, C, OH,
+                       OW, (float*)dx);
+  else
+    hipLaunchKernelGGL((apool_bwd_nhwc<bf16_t, 8>), dim3((unsigned)blocks), dim3(kT), 0, st, (const bf16_t*)dout, N, H, W, C,
+                       OH, OW, (bf16_t*)dx);
   TSG_CHECK_LAUNCH();
   return 0;
 }

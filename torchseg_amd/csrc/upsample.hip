@@ -592,7 +592,13 @@ int tsg_upsample_bilinear_ac_nhwc_bwd(const void* dy, void* dx, int dtype, int64
   // few source pixels, each with a footprint of many rows: split the rows over the threads of a block
   const int G = C / V;
   if (N * IH * (int64_t)IW * G < 65536 && OH >= 8 * IH && N * IH * (int64_t)IW <= 0x7fffffffLL) {
-    const int gpb = G < 256 ? G : 256;
+    // channel groups per block: as few as 8 (= 32 row splitters per source pixel) until the launch has ~512 blocks — with
+    // 64 groups and 4 splitters a thread walked 2000 footprint pixels one dependent load at a time (554 us at 2 x 512 x
+    // 6 x 6 -> 90 x 90, profiles/r03_kernel_stats_pspnet.csv)
+    int gpb = 256;
+    while (gpb > G) gpb >>= 1;
+    if (gpb < 1) gpb = 1;
+    while (gpb > 8 && N * IH * (int64_t)IW * ((G + gpb - 1) / gpb) < 512) gpb >>= 1;
     const dim3 grid2((unsigned)(N * IH * IW), (unsigned)((G + gpb - 1) / gpb));
     if (dtype == TSG_F32)
       hipLaunchKernelGGL((up_bwd_nhwc_split<float, 4>), grid2, dim3(256), 0, st, (const float*)dy, (float*)dx, N, C, IH, IW,

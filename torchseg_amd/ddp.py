@@ -49,6 +49,7 @@ upsample overrides.  Controlled by env so train.py needs no edit:
                         the full-resolution logits; any other consumer materialises it.  fusion.py)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
   TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
+  TSG_ADAPTIVE_POOL=1|0 (default 1 on GPU: nn.AdaptiveAvgPool2d on channels_last maps -> tsg_adaptive_avgpool_nhwc_*)
   TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw;
                         TSG_CONV_WRW_IMPL=tr|v1 picks the kernel variant, default tr)
 """
@@ -373,6 +374,9 @@ class DistributedDataParallel(nn.Module):
             if _env_flag("TSG_CONV_WRW", True):
                 from .convwrw import install_conv_wrw
                 install_conv_wrw(self.module)
+            if _env_flag("TSG_ADAPTIVE_POOL", True):
+                from .pool import install_adaptive_pool
+                install_adaptive_pool(self.module)
 
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None

@@ -204,6 +204,32 @@ class HipKernels:
                                      L.stream_ptr(dout)), "tsg_gap_bwd")
         return dx
 
+    def adaptive_avgpool_supported(self, x, OH, OW):
+        """channels_last-dense [N,C,H,W] (f32 / bf16, C a multiple of the 16-byte vector) pooled to OH <= H, OW <= W"""
+        return (x.dim() == 4 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+                and 0 < OH <= x.shape[2] and 0 < OW <= x.shape[3])
+
+    def adaptive_avgpool_fwd(self, x, OH, OW):
+        """x [N,C,H,W] channels_last -> [N,C,OH,OW] channels_last (nn.AdaptiveAvgPool2d)"""
+        N, Cc, H, W = x.shape
+        wsb = self.lib.tsg_adaptive_avgpool_nhwc_ws_bytes(L.dtype_code(x), N, Cc, H, W, OH, OW)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+        out = torch.empty((N, Cc, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_adaptive_avgpool_nhwc_fwd(x.data_ptr(), out.data_ptr(), L.dtype_code(x), N, Cc, H, W, OH, OW,
+                                                       ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
+                "tsg_adaptive_avgpool_nhwc_fwd")
+        return out
+
+    def adaptive_avgpool_bwd(self, dout, H, W):
+        """dout [N,C,OH,OW] channels_last -> dx [N,C,H,W] channels_last"""
+        N, Cc, OH, OW = dout.shape
+        dx = torch.empty((N, Cc, H, W), dtype=dout.dtype, device=dout.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_adaptive_avgpool_nhwc_bwd(dout.data_ptr(), dx.data_ptr(), L.dtype_code(dout), N, Cc, H, W, OH,
+                                                       OW, L.stream_ptr(dout)), "tsg_adaptive_avgpool_nhwc_bwd")
+        return dx
+
     def chanscale_fwd(self, x, s, layout, N, Cc, HW, add_identity):
         y = torch.empty_like(x)
         L.check(self.lib.tsg_chanscale_fwd(x.data_ptr(), s.data_ptr(), y.data_ptr(), L.dtype_code(x), layout,
