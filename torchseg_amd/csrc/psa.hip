@@ -442,6 +442,7 @@ struct MmArgs {
   int tiles_m, tiles_n;             // tile grid per batch
   int per_xcd;                      // ceil(tiles / 8): every XCD gets a contiguous run of tiles
   int m_fastest;                    // tile order inside the run (0: N fastest, the default)
+  int ablate;                       // diagnosis only (TSG_PSA_ABLATE): 1 no A reloads, 2 no B reloads, 4 no exp, 8 no MFMA
   int64_t batch;
 };
 
@@ -536,12 +537,17 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
   for (int q = 0; q < G::ACH; ++q) pa[q] += (int64_t)ka[q] * sa_k;
 #pragma unroll
   for (int q = 0; q < G::BCH; ++q) pb[q] += (int64_t)kb[q] * sb_k;
+  const int ablate = g.ablate;
   auto fetch = [&](uint4* qa, uint4* qb, int k0) {
     if (k0 + MM_BK <= Kd) {
+      if (!(ablate & 1) || k0 == 0) {
 #pragma unroll
-      for (int q = 0; q < G::ACH; ++q) { qa[q] = ld16(pa[q]); pa[q] += step_a; }
+        for (int q = 0; q < G::ACH; ++q) { qa[q] = ld16(pa[q]); pa[q] += step_a; }
+      }
+      if (!(ablate & 2) || k0 == 0) {
 #pragma unroll
-      for (int q = 0; q < G::BCH; ++q) { qb[q] = ld16(pb[q]); pb[q] += step_b; }
+        for (int q = 0; q < G::BCH; ++q) { qb[q] = ld16(pb[q]); pb[q] += step_b; }
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < G::ACH; ++q) {
@@ -575,7 +581,8 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
     for (int q = 0; q < G::BCH; ++q) {
       uint4 v = qb[q];
       const bool in = vb[q] && k0 + kb[q] < Kd;            // the K tail (and the padding) must be exact zeros, not exp(-lse)
-      if (EXPB == 1) {
+      if (ablate & 4) {
+      } else if (EXPB == 1) {
         v = expchunk(v, bl[EXPB == 1 ? q : 0]);
       } else if (EXPB == 2) {
         const int k = k0 + kb[q] < kb_max ? k0 + kb[q] : kb_max;
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
         if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (kt + 1) * MM_BK);
         if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (kt + 1 + PF) * MM_BK);
       }
-      if (!computes) continue;
+      if (!computes || (ablate & 8)) continue;
       const bf16_t* sa = lds + (size_t)(kt & 1) * G::STAGE;
       const bf16_t* sb = sa + G::A_ELEMS;
 #pragma unroll
@@ -720,6 +727,7 @@ static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.batch;
   g.per_xcd = (int)((tiles + 7) / 8);
   { const char* o = getenv("TSG_PSA_ORDER"); g.m_fastest = (o && o[0] == 'm') ? 1 : 0; }
+  { const char* o = getenv("TSG_PSA_ABLATE"); g.ablate = o ? atoi(o) : 0; }
   constexpr size_t lds_bytes = MmGeom<BM, BN>::LDS;
   TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
