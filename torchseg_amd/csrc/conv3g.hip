@@ -87,7 +87,11 @@ __device__ __forceinline__ uint4 g3_affine_relu(uint4 v, const float* __restrict
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int BN, int NW, bool AFF, bool STATS>
+// GLDS: the filter slab goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, destination =
+// wave-uniform base + lane x 16 B — exactly the fragment-ordered slab, which is a linear copy), not through registers and
+// ds_write_b128.  63 % of the bytes a block stages per chunk then bypass the register -> LDS write path (79 B / clk / CU,
+// the path the PSA ablations found saturated) and 12-20 VGPRs are free.
+template <int BN, int NW, bool AFF, bool STATS, bool GLDS>
 __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
                                                              bf16_t* __restrict__ y, G3Geom g,
                                                              const float* __restrict__ in_ab,
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
     const int v = tid + G3_THREADS * u, pp = v >> 1;
     prc[u] = v < G3_NPV ? ((pp / G3_PW) | ((pp % G3_PW) << 8) | ((v & 1) << 16)) : -1;
   }
-  uint4 rf[NFU], rp[NPU];
+  uint4 rf[GLDS ? 1 : NFU], rp[NPU];
+  constexpr int NFW = (Cfg::NFV / 64 + NW - 1) / NW;       // GLDS: 1 KB pieces of a slab per wave (5 / 3 / 5)
   const bf16_t* wslab = wf + (int64_t)oct * g.nchunks * Cfg::FELEMS;
 
   // STATS: the thread's 8 channels (16-byte part tid % (BN / 8)) over the pixels it stores: tid / (BN / 8) + k * 4096 / BN
@@ -131,13 +136,24 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
     const int bimg = tile / (g.tiles_w * g.tiles_h);
     const bf16_t* ximg = x + (int64_t)bimg * g.H * g.W * g.Cin;
 
-    auto fetch = [&](int chunk) {
+    auto fetch = [&](int chunk, int buf) {
       const bf16_t* ws = wslab + (int64_t)chunk * Cfg::FELEMS;
+      if (GLDS) {
+        unsigned char* fb = reinterpret_cast<unsigned char*>(fbuf + buf * Cfg::FELEMS);
 #pragma unroll
-      for (int u = 0; u < NFU; ++u) {
-        const int v = tid + G3_THREADS * u;
-        rf[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (u < NFU - 1 || v < Cfg::NFV) rf[u] = *reinterpret_cast<const uint4*>(ws + (int64_t)v * 8);
+        for (int u = 0; u < NFW; ++u) {
+          const int q = wave + NW * u;                           // wave-uniform piece index
+          if (u < NFW - 1 || q < Cfg::NFV / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + ((int64_t)q * 64 + lane) * 8),
+                                             (__attribute__((address_space(3))) void*)(fb + q * 1024), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NFU; ++u) {
+          const int v = tid + G3_THREADS * u;
+          rf[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (u < NFU - 1 || v < Cfg::NFV) rf[u] = *reinterpret_cast<const uint4*>(ws + (int64_t)v * 8);
+        }
       }
 #pragma unroll
       for (int u = 0; u < NPU; ++u) {
@@ -149,11 +165,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
       }
     };
     auto stage = [&](int chunk, int buf) {
-      bf16_t* fb = fbuf + buf * Cfg::FELEMS;
+      if (!GLDS) {
+        bf16_t* fb = fbuf + buf * Cfg::FELEMS;
 #pragma unroll
-      for (int u = 0; u < NFU; ++u) {
-        const int v = tid + G3_THREADS * u;
-        if (u < NFU - 1 || v < Cfg::NFV) *reinterpret_cast<uint4*>(fb + v * 8) = rf[u];
+        for (int u = 0; u < NFU; ++u) {
+          const int v = tid + G3_THREADS * u;
+          if (u < NFU - 1 || v < Cfg::NFV) *reinterpret_cast<uint4*>(fb + v * 8) = rf[u];
+        }
       }
       bf16_t* pbw = pbuf + buf * G3_PATCH;
 #pragma unroll
@@ -181,14 +199,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    fetch(0);
-    __syncthreads();                                     // the previous tile's epilogue is done with the buffers; abs_ visible
+    if (GLDS) __syncthreads();                           // the DMA writes LDS at once: the previous tile's epilogue must be done
+    fetch(0, 0);
+    if (!GLDS) __syncthreads();                          // the previous tile's epilogue is done with the buffers; abs_ visible
     stage(0, 0);
     __syncthreads();
 
     for (int c = 0; c < g.nchunks; ++c) {
       const int buf = c & 1;
-      if (c + 1 < g.nchunks) fetch(c + 1);               // in flight during the MFMAs of this chunk
+      if (c + 1 < g.nchunks) fetch(c + 1, buf ^ 1);      // in flight during the MFMAs of this chunk
       const bf16_t* pb = pbuf + buf * G3_PATCH + ((2 * wp) * G3_PW + p) * G3_PS + half * 8;
       const bf16_t* fa = fbuf + buf * Cfg::FELEMS + ((wo * NOB) * 64 + lane) * 8;
       g3_bf16x8 bq[4][3];
@@ -322,6 +341,13 @@ static int g3_bn(int64_t B, int64_t H, int64_t W, int Cout) {
   return 64;
 }
 
+// TSG_CONV3G_GLDS=1|0 (default 1): filter slab by LDS-DMA.  profiles/r03_conv3g_glds.log: per step of forwards 1258 vs
+// 1320 us, data gradients 1211 vs 1220 us, the bench 1125.3 vs 1123.3 img/s in two interleaved pairs — small, repeatable
+static bool g3_glds() {
+  static const int v = [] { const char* e = getenv("TSG_CONV3G_GLDS"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
 // waves per block: 4 (two blocks per CU) for 64-wide tiles unless TSG_CONV3G_NW=8
 static int g3_nw(int BN) {
   static const int forced = [] { const char* e = getenv("TSG_CONV3G_NW"); return e ? atoi(e) : 0; }();
@@ -410,23 +436,26 @@ int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, 
   if (!aligned16(x) || !aligned16(wf) || !aligned16(y) || (in_ab && !aligned16(in_ab))) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int grid = g.nslots * g.noct;
-#define G3_GO(BNN, NWW, AF, STT)                                                                                    \
+#define G3_GO(BNN, NWW, AF, STT, GL)                                                                                \
   do {                                                                                                              \
     constexpr size_t lds_bytes = G3Cfg<BNN, NWW>::LDS;                                                              \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3g_fwd_k<BNN, NWW, AF, STT>),                    \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3g_fwd_k<BNN, NWW, AF, STT, GL>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                       \
-    hipLaunchKernelGGL((conv3g_fwd_k<BNN, NWW, AF, STT>), dim3(grid), dim3(64 * NWW), lds_bytes, st,                \
+    hipLaunchKernelGGL((conv3g_fwd_k<BNN, NWW, AF, STT, GL>), dim3(grid), dim3(64 * NWW), lds_bytes, st,            \
                        (const bf16_t*)x, (const bf16_t*)wf, (bf16_t*)y, g, in_ab, partial, (const bf16_t*)addend);  \
   } while (0)
-#define G3_PICK(BNN, NWW)                                                                                           \
+#define G3_PICK2(BNN, NWW, GL)                                                                                      \
   do {                                                                                                              \
-    if (in_ab) { if (partial) G3_GO(BNN, NWW, true, true); else G3_GO(BNN, NWW, true, false); }                     \
-    else { if (partial) G3_GO(BNN, NWW, false, true); else G3_GO(BNN, NWW, false, false); }                         \
+    if (in_ab) { if (partial) G3_GO(BNN, NWW, true, true, GL); else G3_GO(BNN, NWW, true, false, GL); }             \
+    else { if (partial) G3_GO(BNN, NWW, false, true, GL); else G3_GO(BNN, NWW, false, false, GL); }                 \
   } while (0)
+#define G3_PICK(BNN, NWW)                                                                                           \
+  do { if (g3_glds()) G3_PICK2(BNN, NWW, true); else G3_PICK2(BNN, NWW, false); } while (0)
   if (BN == 128) G3_PICK(128, 8);
   else if (g3_nw(64) == 8) G3_PICK(64, 8);
   else G3_PICK(64, 4);
 #undef G3_PICK
+#undef G3_PICK2
 #undef G3_GO
   TSG_CHECK_LAUNCH();
   return 0;
