@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 script=$1; pat=$2; tag=${3:-pmc}
 out=$PWD/gpurun_out/pmc_$tag
 rm -rf $out; mkdir -p $out
-C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"
+C=${PMC_C:-"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"}
 (cd /tmp && MIOPEN_LOG_LEVEL=1 timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $out -o pmc -- python $OLDPWD/$script > $out.log 2>&1)
 echo "rc=$?"
 PAT=$pat OUT=$out python - <<'PY'

@@ -613,10 +613,20 @@ __device__ __forceinline__ void tail_sums(const float* __restrict__ partial, int
   sh[0][ts][tc] = p1;
   sh[1][ts][tc] = p2;
   __syncthreads();
+  // fixed two-level order: 8 slice-lanes fold 8 consecutive lanes each, the owner folds those 8 (a 64-long serial chain
+  // of dependent LDS reads + fp64 adds was ~1/3 of these kernels' 6 us)
+  if (ts < 8) {                                          // slots ts * 8 .. + 7 of column tc are read by this thread only
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a1 += sh[0][ts * 8 + q][tc]; a2 += sh[1][ts * 8 + q][tc]; }
+    sh[0][ts * 8][tc] = a1; sh[1][ts * 8][tc] = a2;
+  }
+  __syncthreads();
   owner = (ts == 0) && (c < C);
   t1 = 0.0; t2 = 0.0;
   if (owner) {
-    for (int q = 0; q < kTs; ++q) { t1 += sh[0][q][tc]; t2 += sh[1][q][tc]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { t1 += sh[0][q * 8][tc]; t2 += sh[1][q * 8][tc]; }
   }
 }
 

@@ -216,19 +216,28 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
           bq[pr][kw] = *reinterpret_cast<const g3_bf16x8*>(pb + (pr * G3_PW + kw) * G3_PS);
+      // the filter fragments of tap t + 1 are read while the MFMAs of tap t run (two register sets; with one, every tap
+      // began with an exposed LDS latency: ds_read, s_waitcnt lgkmcnt(0), 4 MFMAs in the ISA)
+      g3_bf16x8 af[2][NOB];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int j = 0; j < NOB; ++j) af[0][j] = *reinterpret_cast<const g3_bf16x8*>(fa + (j * 64) * 8);
+      // (the scheduler otherwise sinks every read to just before its first use, to save registers this kernel has to spare)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int t = kh * 3 + kw;
+      for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t % 3;
+        if (t + 1 < 9) {
 #pragma unroll
-          for (int j = 0; j < NOB; ++j) {
-            const g3_bf16x8 af = *reinterpret_cast<const g3_bf16x8*>(fa + ((t * OCB + j) * 64) * 8);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[i + kh][kw], acc[j][i], 0, 0, 0);
-          }
+          for (int j = 0; j < NOB; ++j)
+            af[(t + 1) & 1][j] = *reinterpret_cast<const g3_bf16x8*>(fa + (((t + 1) * OCB + j) * 64) * 8);
+          __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int j = 0; j < NOB; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][j], bq[i + kh][kw], acc[j][i], 0, 0, 0);
+      }
       if (c + 1 < g.nchunks) stage(c + 1, buf ^ 1);
       __syncthreads();
     }

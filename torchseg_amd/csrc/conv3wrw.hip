@@ -319,7 +319,7 @@ template <int S> struct W3S {
 // PF = true: one block per CU, the next tile's operands are prefetched into registers while the MFMAs run.
 // PF = false: no register prefetch (the 44 registers it costs go), two blocks per CU that cover for each other's loads,
 // staging and barriers — with one block per CU the MFMA pipe idles ~2/3 of the time during those phases.
-template <int S, bool PF, bool AFF>
+template <int S, bool PF, bool AFF, bool SH = true>
 __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ part, W3GenGeom g, const float* __restrict__ in_ab) {
   typedef W3S<S> P;
@@ -402,22 +402,54 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
       }
     __syncthreads();
     if (PF && tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
+    // dy fragments of the 8 k steps (16 output pixels each: tile row ks >> 1, columns 16 (ks & 1) + 8 half ..) stay in
+    // registers; the x fragments are read once per PATCH row: the fragment tap kh of tile row r needs (patch row S r + kh,
+    // columns S 16 c + kw ..) is the one tap kh - S of tile row r + 1 needs, so walking patch rows instead of (row, kh)
+    // pairs reads 36 (stride 1) / 54 (stride 2) fragments per tile instead of 72 -- this loop is bound by LDS reads
+    // (two ds_read_b64_tr per MFMA before; round 3)
+    union Frag { v4i16 q[2]; bf16x8 v; };
+    if (!SH) {                                          // round-2 order (TSG_WRW_SHARE=0): one x fragment per MFMA
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {                  // 16 output pixels: tile row ks >> 1, columns 16 (ks & 1) + 8 half ..
-      union { v4i16 q[2]; bf16x8 v; } fa;
-      fa.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
-      fa.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
+      for (int ks = 0; ks < 8; ++ks) {
+        Frag fa1;
+        fa1.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
+        fa1.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int px = (S * (ks >> 1) + kh) * P::PC + S * (ks & 1) * 16 + kw;
+            Frag fb;
+            fb.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 0) * (T3_RBE / 4)));
+            fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4 * S) * (T3_RBE / 4)));
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1.v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
+          }
+      }
+      continue;
+    }
+    Frag fa[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      fa[ks].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
+      fa[ks].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
+    }
+#pragma unroll
+    for (int pr = 0; pr < S * 3 + 3; ++pr)            // patch rows S r + kh, r < 4, kh < 3
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int px = (S * (ks >> 1) + kh) * P::PC + S * (ks & 1) * 16 + kw;   // patch pixel of the fragment's first K
-          union { v4i16 q[2]; bf16x8 v; } fb;
+          const int px = pr * P::PC + S * c * 16 + kw;       // patch pixel of the fragment's first K
+          Frag fb;
           fb.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 0) * (T3_RBE / 4)));
           fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4 * S) * (T3_RBE / 4)));
-          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int rr = pr - kh;
+            if (rr >= 0 && rr % S == 0 && rr / S < 4)
+              acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * (rr / S) + c].v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
+          }
         }
-    }
   }
   // partial of this (pair, slot): [pair][slot][64 oc][9 taps][64 ci]
   float* out = part + ((int64_t)pair * g.bpp + slot) * W3_C * W3_N;
@@ -608,17 +640,20 @@ static int conv3_wrw_gen_common(const void* x, const float* in_ab, const void* d
   if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, Hin, Win, Cin, Cout, stride)) return TSG_E_WS;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-#define W3_GO(SS, PFF, AF)                                                                                        \
+  static const bool share = [] { const char* e = getenv("TSG_WRW_SHARE"); return !(e && e[0] == '0'); }();
+#define W3_GO1(SS, PFF, AF, SHH)                                                                                  \
   do {                                                                                                            \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF>),                     \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF, SHH>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<SS>::LDS));                  \
-    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,       \
+    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF, SHH>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,  \
                        (const bf16_t*)x, (const bf16_t*)dy, (float*)ws, g, in_ab);                                \
   } while (0)
+#define W3_GO(SS, PFF, AF) do { if (share) W3_GO1(SS, PFF, AF, true); else W3_GO1(SS, PFF, AF, false); } while (0)
   if (stride == 1 && w3_occ2(g.ntiles)) { if (in_ab) W3_GO(1, false, true); else W3_GO(1, false, false); }
   else if (stride == 1) { if (in_ab) W3_GO(1, true, true); else W3_GO(1, true, false); }
   else { if (in_ab) W3_GO(2, true, true); else W3_GO(2, true, false); }
 #undef W3_GO
+#undef W3_GO1
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
   TSG_CHECK_LAUNCH();

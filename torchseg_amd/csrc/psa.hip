@@ -245,9 +245,55 @@ __global__ __launch_bounds__(256) void psa_delta_fold(const float* __restrict__ 
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t b = blockIdx.y;
   if (j >= N) return;
+  float v[kDeltaChunks];
+#pragma unroll
+  for (int c = 0; c < kDeltaChunks; ++c) v[c] = part[(b * kDeltaChunks + c) * N + j];   // independent loads, fixed order sum
   float acc = 0.f;
-  for (int c = 0; c < kDeltaChunks; ++c) acc += part[(b * kDeltaChunks + c) * N + j];
+#pragma unroll
+  for (int c = 0; c < kDeltaChunks; ++c) acc += v[c];
   delta[b * N + j] = acc;
+}
+
+// Vectorised stage 1 (N % V == 0): block = 4 row groups x 64 column vectors; a thread keeps 8 rows of both tensors in
+// flight (16 independent 16-byte loads; the scalar kernel above issued 2-byte loads one row at a time: 11.6 us for the
+// 15 MB of PSANet's shape), the four groups meet in LDS in a fixed order.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void psa_delta_vec(const T* __restrict__ out, const T* __restrict__ dout,
+                                                     int64_t Cx, int64_t N, float* __restrict__ part) {
+  __shared__ float red[3][64][V];
+  const int vc = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t j = ((int64_t)blockIdx.x * 64 + vc) * V;
+  const int chunk = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t per = (Cx + kDeltaChunks - 1) / kDeltaChunks, sub = (per + 3) / 4;
+  int64_t c0 = chunk * per + grp * sub, c1 = c0 + sub, cend = (chunk + 1) * per < Cx ? (chunk + 1) * per : Cx;
+  if (c1 > cend) c1 = cend;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  if (j < N) {
+    for (int64_t c = c0; c < c1; c += 8) {
+      ColVec<T, V> a[8], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c + u < c1) { a[u].load(out + (b * Cx + c + u) * N + j); d[u].load(dout + (b * Cx + c + u) * N + j); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c + u < c1) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] += a[u].v[e] * d[u].v[e];
+        }
+    }
+  }
+  if (grp) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[grp - 1][vc][e] = acc[e];
+  }
+  __syncthreads();
+  if (grp == 0 && j < N) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) part[(b * kDeltaChunks + chunk) * N + j + e] = ((acc[e] + red[0][vc][e]) + red[1][vc][e]) + red[2][vc][e];
+  }
 }
 
 // fp32 path: dA = exp(A - lse_j) * (dP - delta_j)
@@ -443,10 +489,43 @@ struct MmArgs {
   int per_xcd;                      // ceil(tiles / 8): every XCD gets a contiguous run of tiles
   int m_fastest;                    // tile order inside the run (0: N fastest, the default)
   int ablate;                       // diagnosis only (TSG_PSA_ABLATE): 1 no A reloads, 2 no B reloads, 4 no exp, 8 no MFMA
+  const bf16_t* Af; int64_t sAf;    // AF: the NT A operand in MFMA fragment order (psa_frag_k), batch stride in elements
+  int MB, KS;                       // AF: 32-row blocks of A, 16-wide k steps (4 per K tile, zero padded)
   int64_t batch;
 };
 
+// Global loads the compiler's waitcnt pass does not see.  Around a prefetch that lives across the back edge of the K loop
+// the pass is conservative: it drained EVERY outstanding load before the first MFMA of a tile (s_waitcnt vmcnt(7) .. (0) in
+// the ISA of round 3's first AF build), so the tile time was one full memory latency whatever the prefetch depth.  These
+// loads are paired with vm_wait<N>, which names the registers it makes valid (the "+v" operands order their consumers
+// after it); loads return in order, so "at most N outstanding" with N = the loads issued AFTER the set that is needed.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define TSG_ASM_LD16(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
+template <int N>
+__device__ __forceinline__ void vm_wait(u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N)); }
+__device__ __forceinline__ void vm_tie(u32x4& a) { asm volatile("" : "+v"(a)); }
+
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// AF (round 3): the NT A operand (X for the forward, dOut for dX) never goes through LDS.  psa_frag_k lays it out once per
+// call in MFMA fragment order, Xf[b][32-row block][k step][lane][8] with lane l = row (l & 31), k = 16 ks + 8 (l >> 5) ..
+// (zero padded to whole K tiles), so that an MFMA wave loads an A fragment as ONE coalesced 1 KB read straight into
+// registers.  The ablations (profiles/r03_psa_ablations.txt) showed psa_mm bound by its register -> LDS write path
+// (768 B per MFMA at 128 x 64 tiles): without the A tile only the exponentiated B tile is left on it (8 KB per K tile).
+__global__ __launch_bounds__(256) void psa_frag_k(const bf16_t* __restrict__ X, int64_t M, int64_t K, int MB, int KS,
+                                                  bf16_t* __restrict__ Xf) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 16-byte vector per thread
+  const int64_t per_b = (int64_t)MB * KS * 64;
+  const int64_t b = blockIdx.y;
+  if (v >= per_b) return;
+  const int l = (int)(v % 64);
+  const int ks = (int)((v / 64) % KS);
+  const int mb = (int)(v / (64 * (int64_t)KS));
+  const int64_t m = (int64_t)mb * 32 + (l & 31), k = (int64_t)ks * 16 + (l >> 5) * 8;
+  uint4 o = make_uint4(0u, 0u, 0u, 0u);
+  if (m < M && k + 8 <= K) o = *reinterpret_cast<const uint4*>(X + (b * M + m) * K + k);
+  *reinterpret_cast<uint4*>(Xf + (b * per_b + v) * 8) = o;
+}
 
 // SPLIT (round 3): 8 waves, two per SIMD with different jobs.  Waves 0-3 only read fragments and issue MFMAs; waves 4-7
 // only fetch, transform (the fused softmax: 32 v_exp_f32 + ~130 other VALU instructions per thread and K tile) and
@@ -454,9 +533,13 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // its counters (profiles/r03_psa_sq_counters.txt) show SQ_ACTIVE_INST_ANY at 48 % of the wave cycles with the MFMA pipe
 // busy 17 % of the time — issue-bound on the staging code.  The matrix pipe and the VALU are separate pipes, so a
 // staging wave and an MFMA wave on one SIMD run concurrently (MI355X_MICROARCH.md, wave scheduling).
-template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN == 64) ? 2 : 1)) void psa_mm(MmArgs g) {
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT, bool AF = false>
+__global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, ((SPLIT && !(AF && BM == 256)) || (BM == 128 && BN == 64) ? 2 : 1))
+void psa_mm(MmArgs g) {
   typedef MmGeom<BM, BN> G;
+  // AF is instantiated with PF = 2 only: a deeper pipeline spills at 256 VGPRs, and a spill of a register an untracked
+  // load is still writing stores garbage (af256x64x3 failed its parity test exactly so)
+  static_assert(!AF || (!A_TR && SPLIT && PF == 2), "AF: NT A operand, MFMA / staging wave split, two register sets");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const bool producer = SPLIT && threadIdx.x >= MM_T;    // wave-uniform
   const bool stages = !SPLIT || producer, computes = !SPLIT || !producer;
@@ -540,7 +623,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
   const int ablate = g.ablate;
   auto fetch = [&](uint4* qa, uint4* qb, int k0) {
     if (k0 + MM_BK <= Kd) {
-      if (!(ablate & 1) || k0 == 0) {
+      if (!AF && (!(ablate & 1) || k0 == 0)) {
 #pragma unroll
         for (int q = 0; q < G::ACH; ++q) { qa[q] = ld16(pa[q]); pa[q] += step_a; }
       }
@@ -549,10 +632,12 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
         for (int q = 0; q < G::BCH; ++q) { qb[q] = ld16(pb[q]); pb[q] += step_b; }
       }
     } else {
+      if (!AF) {
 #pragma unroll
-      for (int q = 0; q < G::ACH; ++q) {
-        const int over = k0 + ka[q] - ka_max;                  // > 0: this chunk lies beyond K, read the last valid one
-        qa[q] = ld16(pa[q] - (over > 0 ? (int64_t)over * sa_k : 0));
+        for (int q = 0; q < G::ACH; ++q) {
+          const int over = k0 + ka[q] - ka_max;                // > 0: this chunk lies beyond K, read the last valid one
+          qa[q] = ld16(pa[q] - (over > 0 ? (int64_t)over * sa_k : 0));
+        }
       }
 #pragma unroll
       for (int q = 0; q < G::BCH; ++q) {
@@ -572,11 +657,13 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   };
-  auto stash = [&](const uint4* qa, const uint4* qb, int stage, int k0) {
+  auto stash = [&](const uint4* qa, const uint4* qb, int stage, int k0, const u32x4* lpre = nullptr) {
     bf16_t* sa = lds + (size_t)stage * G::STAGE;
     bf16_t* sb = sa + G::A_ELEMS;
+    if (!AF) {
 #pragma unroll
-    for (int q = 0; q < G::ACH; ++q) *reinterpret_cast<uint4*>(sa + oa[q]) = qa[q];
+      for (int q = 0; q < G::ACH; ++q) *reinterpret_cast<uint4*>(sa + oa[q]) = qa[q];
+    }
 #pragma unroll
     for (int q = 0; q < G::BCH; ++q) {
       uint4 v = qb[q];
@@ -584,6 +671,12 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
       if (ablate & 4) {
       } else if (EXPB == 1) {
         v = expchunk(v, bl[EXPB == 1 ? q : 0]);
+      } else if (EXPB == 2 && AF) {                        // lse of the chunk's 8 k positions came with the tile (fetch_b)
+        const u32x4 l0 = lpre[2 * q], l1 = lpre[2 * q + 1];
+        const float l2[8] = {__uint_as_float(l0.x) * kLog2e, __uint_as_float(l0.y) * kLog2e, __uint_as_float(l0.z) * kLog2e,
+                             __uint_as_float(l0.w) * kLog2e, __uint_as_float(l1.x) * kLog2e, __uint_as_float(l1.y) * kLog2e,
+                             __uint_as_float(l1.z) * kLog2e, __uint_as_float(l1.w) * kLog2e};
+        v = expchunk(v, l2);
       } else if (EXPB == 2) {
         const int k = k0 + kb[q] < kb_max ? k0 + kb[q] : kb_max;
         const float4 l0 = *reinterpret_cast<const float4*>(lse + k), l1 = *reinterpret_cast<const float4*>(lse + k + 4);
@@ -612,8 +705,72 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
   const int b_tr = (8 * half + (i16 >> 2)) * G::B_TR_ROW + wn * 64 + 16 * sub + 4 * (i16 & 3);
 
   // tile t travels in register set t % PF: fetched PF iterations before it is written to LDS
+  // AF: the MFMA waves fetch their own A fragments (1 KB coalesced reads) PF - 1 K tiles ahead, PF register sets
+  u32x4 xa[AF ? PF : 1][AF ? G::MI : 1][4];
+  const bf16_t* afp[AF ? G::MI : 1];                      // next K tile to fetch (tiles are fetched in order)
+  if (AF) {
+#pragma unroll
+    for (int i = 0; i < G::MI; ++i) {
+      int mb = (int)((m0 + wm * WROWS) / 32) + i;
+      if (mb > g.MB - 1) mb = g.MB - 1;                    // rows beyond M are never stored
+      afp[i] = g.Af + b * g.sAf + ((int64_t)mb * g.KS * 64 + lane) * 8;
+    }
+  }
+  // ADV: pointer step after the load, 0 once the last tile has been requested (the tail re-reads it: the number of loads
+  // in flight never changes, so ONE s_waitcnt site with a constant serves every iteration -- a branch around the wait
+  // makes the compiler merge register copies of the set, and it may place them BEFORE the wait)
+#define TSG_AF_LOAD(SET, ADV)                                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < (AF ? G::MI : 1); ++i_) {                                       \
+    TSG_ASM_LD16(xa[SET][i_][0], afp[i_], 0);    TSG_ASM_LD16(xa[SET][i_][1], afp[i_], 1024);             \
+    TSG_ASM_LD16(xa[SET][i_][2], afp[i_], 2048); TSG_ASM_LD16(xa[SET][i_][3], afp[i_], 3072);             \
+    afp[i_] += (ADV);                                                                                     \
+  }
+  // AF, staging waves: the B tile (and, EXPB 2, the lse of its k positions) by the same untracked loads, PF tiles ahead;
+  // ONE load site per register (the pointer is selected, not the load) and one wait site, as for the fragments.  Tiles
+  // beyond the last one re-read the last one, so (PF - 1) sets are in flight behind the one being written to LDS.
+  constexpr int LPC = AF ? (EXPB == 2 ? 3 : 1) : 1;        // loads per chunk
+  u32x4 xb[AF ? PF : 1][AF ? G::BCH : 1], xl[AF && EXPB == 2 ? PF : 1][AF && EXPB == 2 ? 2 * G::BCH : 1];
+#define TSG_AF_FETCH_B(SET, K0, ADV)                                                                      \
+  _Pragma("unroll") for (int q_ = 0; q_ < (AF ? G::BCH : 1); ++q_) {                                      \
+    const int over_ = (K0) + kb[q_] - kb_max;          /* > 0 only in the partial last tile */            \
+    const bf16_t* p_ = pb[q_] - (over_ > 0 ? (int64_t)over_ * sb_k : 0);                                  \
+    TSG_ASM_LD16(xb[SET][q_], p_, 0);                                                                     \
+    if (EXPB == 2) {                                                                                      \
+      const float* l_ = lse + ((K0) + kb[q_] < kb_max ? (K0) + kb[q_] : kb_max);                          \
+      TSG_ASM_LD16(xl[EXPB == 2 ? SET : 0][EXPB == 2 ? 2 * q_ : 0], l_, 0);                               \
+      TSG_ASM_LD16(xl[EXPB == 2 ? SET : 0][EXPB == 2 ? 2 * q_ + 1 : 0], l_, 16);                          \
+    }                                                                                                     \
+    pb[q_] += (ADV);                                                                                      \
+  }
+#define TSG_AF_STASH_B(SET, STAGE_, K0)                                                                   \
+  {                                                                                                       \
+    uint4 tb_[AF ? G::BCH : 1];                                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < (AF ? G::BCH : 1); ++q_)                                      \
+      tb_[q_] = make_uint4(xb[SET][q_].x, xb[SET][q_].y, xb[SET][q_].z, xb[SET][q_].w);                   \
+    stash(nullptr, tb_, STAGE_, K0, xl[EXPB == 2 ? SET : 0]);                                             \
+  }
+#define TSG_AF_WAIT_B(SET, N_)                                                                            \
+  {                                                                                                       \
+    vm_wait<N_>(xb[SET][0]);                                                                              \
+    _Pragma("unroll") for (int q_ = 1; q_ < (AF ? G::BCH : 1); ++q_) vm_tie(xb[SET][q_]);                 \
+    if (EXPB == 2) { _Pragma("unroll") for (int q_ = 0; q_ < 2 * (AF ? G::BCH : 1); ++q_)                 \
+      vm_tie(xl[EXPB == 2 ? SET : 0][EXPB == 2 ? q_ : 0]); }                                              \
+  }
   const int nk = (int)((g.K + MM_BK - 1) / MM_BK);
-  if (stages) {
+  if (AF && computes) {
+#pragma unroll
+    for (int u = 0; u + 1 < PF; ++u) { TSG_AF_LOAD(AF ? u : 0, u + 1 < nk ? 4 * 512 : 0) }
+  }
+  if (AF && stages) {
+    TSG_AF_FETCH_B(0, 0, nk > 1 ? step_b : 0)
+    TSG_AF_WAIT_B(0, 0)
+    TSG_AF_STASH_B(0, 0, 0)
+#pragma unroll
+    for (int u = 1; u <= PF; ++u) {                       // tile min(u, nk - 1) into set u % PF
+      const int tu = u < nk ? u : nk - 1;
+      TSG_AF_FETCH_B(AF ? u % PF : 0, tu * MM_BK, u + 1 < nk ? step_b : 0)
+    }
+  } else if (stages) {
     fetch(ra[0], rb[0], 0);
     stash(ra[0], rb[0], 0, 0);
 #pragma unroll
@@ -627,45 +784,69 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
       if (kt >= nk) break;
       const int s = (u + 1) % PF;                        // == (kt + 1) % PF: kt0 is a multiple of PF
       __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
-      if (stages) {
+      if (AF && stages) {
+        TSG_AF_WAIT_B(AF ? s : 0, (PF - 1) * LPC * (AF ? G::BCH : 1))   // set s = tile kt + 1 (or a re-read of the last one)
+        if (kt + 1 < nk) TSG_AF_STASH_B(AF ? s : 0, (kt + 1) & 1, (kt + 1) * MM_BK)
+        const int tn_ = kt + 1 + PF < nk ? kt + 1 + PF : nk - 1;
+        TSG_AF_FETCH_B(AF ? s : 0, tn_ * MM_BK, kt + 2 + PF < nk ? step_b : 0)
+      } else if (stages) {
         if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (kt + 1) * MM_BK);
         if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (kt + 1 + PF) * MM_BK);
       }
       if (!computes || (ablate & 8)) continue;
+      if (AF) {                                                        // set u holds tile kt (kt0 is a multiple of PF)
+        TSG_AF_LOAD(AF ? (u + PF - 1) % PF : 0, kt + PF < nk ? 4 * 512 : 0)
+        vm_wait<(PF - 1) * (AF ? G::MI : 1) * 4>(xa[AF ? u : 0][0][0]);   // all but the PF - 1 later sets have landed
+#pragma unroll
+        for (int i = 0; i < (AF ? G::MI : 1); ++i)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            if (i + ks) vm_tie(xa[AF ? u : 0][i][ks]);
+      }
       const bf16_t* sa = lds + (size_t)(kt & 1) * G::STAGE;
       const bf16_t* sb = sa + G::A_ELEMS;
-#pragma unroll
-      for (int ks = 0; ks < MM_BK / 16; ++ks) {
-        union { v4i16 q[2]; bf16x8 v; } fa[G::MI], fb[2];
+      // fragments of k step ks + 1 are read while the MFMAs of step ks run (two register sets: with one, every step
+      // exposed an LDS latency -- the MFMA waves have nothing else to issue)
+      union Frag { v4i16 q[2]; bf16x8 v; };
+      Frag fa[2][G::MI], fb[2][2];
+      auto read_frags = [&](Frag* fa_, Frag* fb_, int ks) {
 #pragma unroll
         for (int i = 0; i < G::MI; ++i) {
-          if (A_TR) {
+          if (AF) {
+            fa_[i].v = __builtin_bit_cast(bf16x8, xa[AF ? u : 0][AF ? i : 0][ks]);
+          } else if (A_TR) {
             const lds_v4i16* p = (const lds_v4i16*)(sa + a_tr + ks * 16 * G::A_TR_ROW + i * 32);
-            fa[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
-            fa[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (G::A_TR_ROW / 4)));
+            fa_[i].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
+            fa_[i].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (G::A_TR_ROW / 4)));
           } else {
-            fa[i].v = *reinterpret_cast<const bf16x8*>(sa + a_nt + i * 32 * MM_NT_ROW + ks * 16);
+            fa_[i].v = *reinterpret_cast<const bf16x8*>(sa + a_nt + i * 32 * MM_NT_ROW + ks * 16);
           }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (B_TR) {
             const lds_v4i16* p = (const lds_v4i16*)(sb + b_tr + ks * 16 * G::B_TR_ROW + j * 32);
-            fb[j].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
-            fb[j].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (G::B_TR_ROW / 4)));
+            fb_[j].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)p);
+            fb_[j].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p + 4 * (G::B_TR_ROW / 4)));
           } else {
-            fb[j].v = *reinterpret_cast<const bf16x8*>(sb + b_nt + j * 32 * MM_NT_ROW + ks * 16);
+            fb_[j].v = *reinterpret_cast<const bf16x8*>(sb + b_nt + j * 32 * MM_NT_ROW + ks * 16);
           }
         }
+      };
+      read_frags(fa[0], fb[0], 0);
+#pragma unroll
+      for (int ks = 0; ks < MM_BK / 16; ++ks) {
+        if (ks + 1 < MM_BK / 16) read_frags(fa[(ks + 1) & 1], fb[(ks + 1) & 1], ks + 1);
 #pragma unroll
         for (int i = 0; i < G::MI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i].v, fb[ks & 1][j].v, acc[i][j], 0, 0, 0);
       }
     }
   }
 
+  if (AF) asm volatile("s_waitcnt vmcnt(0)");             // the tail's re-reads still target xa / xb: land them before reuse
   // ---- epilogue through LDS: acc (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half) -> fp32 image
   // [BM][BN + 4], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
   __syncthreads();
@@ -720,7 +901,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, (SPLIT || (BM == 128 && BN
   }
 }
 
-template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT = false>
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT = false, bool AF = false>
 static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   g.tiles_m = (int)((g.M + BM - 1) / BM);
   g.tiles_n = (int)((g.N + BN - 1) / BN);
@@ -729,38 +910,61 @@ static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   { const char* o = getenv("TSG_PSA_ORDER"); g.m_fastest = (o && o[0] == 'm') ? 1 : 0; }
   { const char* o = getenv("TSG_PSA_ABLATE"); g.ablate = o ? atoi(o) : 0; }
   constexpr size_t lds_bytes = MmGeom<BM, BN>::LDS;
-  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT>),
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT, AF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT>), dim3((unsigned)(8 * g.per_xcd)),
+  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT, AF>), dim3((unsigned)(8 * g.per_xcd)),
                      dim3(SPLIT ? 2 * MM_T : MM_T), lds_bytes, st, g);
   TSG_CHECK_LAUNCH();
   return 0;
 }
 
-// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (64-column tiles, round 2), "128x128x<PF>" (round 3: 2 x 2 wave grid)
-// or "split<BM>x<BN>x<PF>" (round 3: 4 MFMA waves + 4 staging waves); bring-up / tuning knob, read once; default chosen
-// by measurement
+// tile configuration: TSG_PSA_CFG = "<BM>x<PF>" (64-column tiles, round 2), "128x128x<PF>" (round 3: 2 x 2 wave grid),
+// "split<BM>x<BN>x<PF>" (round 3: 4 MFMA waves + 4 staging waves) or "af<BM>x<BN>" (round 3: split, and the NT A operand
+// comes from global memory in fragment order with untracked prefetches -- the products with a transposed A operand, dA,
+// run split128x64x1 then); bring-up / tuning knob, read once; default chosen by measurement
 static int mm_cfg() {
   static int cfg = -1;
   if (cfg < 0) {
     const char* e = getenv("TSG_PSA_CFG");
-    cfg = 9128641;       // split128x64x1: fwd 92 / bwd 163 us at B = 2, 512 x 3600^2 (128x1 of round 2: 94 / 178), r03 profiles
+    cfg = 72560642;      // af256x64: fwd 76 / bwd 136 us at B = 2, 512 x 3600^2 (split128x64x1: 95 / 180; 128x1 of round 2: 94 / 178)
     if (e) {
       if (!strcmp(e, "256x1")) cfg = 2561; else if (!strcmp(e, "256x2")) cfg = 2562;
       else if (!strcmp(e, "128x1")) cfg = 1281; else if (!strcmp(e, "128x2")) cfg = 1282;
       else if (!strcmp(e, "128x128x1")) cfg = 1281281; else if (!strcmp(e, "128x128x2")) cfg = 1281282;
       else if (!strcmp(e, "split128x128x1")) cfg = 91281281; else if (!strcmp(e, "split128x128x2")) cfg = 91281282;
       else if (!strcmp(e, "split128x64x1")) cfg = 9128641; else if (!strcmp(e, "split256x64x1")) cfg = 9256641;
+      else if (!strncmp(e, "af", 2)) {                 // af<BM>x<BN>[x<PF>]: A fragments from global, PF - 1 tiles ahead
+        int bm = 0, bn = 0, pf = 2;
+        if (sscanf(e, "af%dx%dx%d", &bm, &bn, &pf) >= 2) cfg = 70000000 + bm * 10000 + bn * 10 + pf;
+      }
     }
   }
   return cfg;
+}
+
+// AF configurations apply to the products whose A operand is NT and for which the caller prepared the fragment image
+template <bool A_TR, bool B_TR, int EXPB, int EPI>
+static int launch_mm_af(MmArgs g, hipStream_t st, int cfg) {
+  if constexpr (!A_TR) {
+    switch (cfg) {
+      case 71280642: return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
+      case 71281282: return launch_mm_cfg<128, 128, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
+      default:       return launch_mm_cfg<256, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
+    }
+  }
+  return TSG_E_SHAPE;
 }
 
 template <bool A_TR, bool B_TR, int EXPB, int EPI>
 static int launch_mm(MmArgs g, hipStream_t st) {
   if (g.M % 8 || g.N % 8 || g.K % 8) return TSG_E_SHAPE;
   if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return TSG_E_ALIGN;
-  switch (mm_cfg()) {
+  const int cfg = mm_cfg();
+  if (cfg / 10000000 == 7) {
+    if (!A_TR && g.Af) return launch_mm_af<A_TR, B_TR, EXPB, EPI>(g, st, cfg);
+    return launch_mm_cfg<128, 64, 1, A_TR, B_TR, EXPB, EPI, true>(g, st);      // products without a fragment image
+  }
+  switch (cfg) {
     case 2561: return launch_mm_cfg<256, 64, 1, A_TR, B_TR, EXPB, EPI>(g, st);
     case 2562: return launch_mm_cfg<256, 64, 2, A_TR, B_TR, EXPB, EPI>(g, st);
     case 1282: return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI>(g, st);
@@ -786,10 +990,27 @@ struct PsaWs {
   float* delta;
   float* delta_part;                 // [B, kDeltaChunks, N]
   float* dP;                         // fp32 path bwd: [B, K, N]
+  bf16_t* Af;                        // bf16 path: the NT A operand (X fwd, dOut bwd) in MFMA fragment order
   size_t total;
 };
 
 constexpr int kChunks = 240;          // row chunks of the column statistics (workspace [B][kChunks][N] x 2)
+
+static inline int af_mb(int64_t M) { return (int)((M + 31) / 32); }
+static inline int af_ks(int64_t K) { return 4 * (int)((K + MM_BK - 1) / MM_BK); }
+static inline size_t af_elems(int64_t B, int64_t M, int64_t K) { return (size_t)B * af_mb(M) * af_ks(K) * 512; }
+
+// lay the NT A operand out in fragment order when the configured tile wants it (TSG_PSA_CFG=af...)
+static int af_prepare(MmArgs& m, bf16_t* Af, hipStream_t st) {
+  if (mm_cfg() / 10000000 != 7 || !Af) return 0;
+  m.MB = af_mb(m.M); m.KS = af_ks(m.K);
+  const int64_t per_b = (int64_t)m.MB * m.KS * 64;
+  hipLaunchKernelGGL(psa_frag_k, dim3((unsigned)((per_b + 255) / 256), (unsigned)m.batch), dim3(256), 0, st, m.A,
+                     m.M, m.K, m.MB, m.KS, Af);
+  TSG_CHECK_LAUNCH();
+  m.Af = Af; m.sAf = per_b * 8;
+  return 0;
+}
 
 static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, bool f32, bool bwd) {
   PsaWs w;
@@ -805,6 +1026,7 @@ static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, 
   w.X_hi = f32 ? (bf16_t*)take((size_t)B * Cx * K * 2) : nullptr;
   w.X_lo = f32 ? (bf16_t*)take((size_t)B * Cx * K * 2) : nullptr;
   w.D_hi = w.D_lo = w.Dt_hi = w.Dt_lo = nullptr; w.delta = nullptr; w.delta_part = nullptr; w.dP = nullptr;
+  w.Af = f32 ? nullptr : (bf16_t*)take(af_elems(B, Cx, bwd ? N : K) * 2);
   if (bwd) {
     w.D_hi = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
     w.D_lo = f32 ? (bf16_t*)take((size_t)B * Cx * N * 2) : nullptr;
@@ -828,7 +1050,9 @@ template <typename T>
 static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float* lse, hipStream_t st) {
   constexpr int V = sizeof(T) == 2 ? 8 : 4;
   if (N % V == 0 && aligned16(A)) {
-    const int rpc = (int)((K + kChunks - 1) / kChunks);
+    static const int want = [] { const char* e = getenv("TSG_PSA_COLCHUNKS"); const int v = e ? atoi(e) : kChunks;
+                                 return v < 1 ? 1 : (v > kChunks ? kChunks : v); }();
+    const int rpc = (int)((K + want - 1) / want);
     const int nch = (int)((K + rpc - 1) / rpc);                        // chunks that actually hold rows
     const int64_t nv = N / V;
     hipLaunchKernelGGL((psa_colstat1_vec<T, V, 15>), dim3((unsigned)((nv + 127) / 128), (unsigned)nch, (unsigned)B),
@@ -897,6 +1121,7 @@ int tsg_psa_fwd(const void* X, const void* A, void* out, float* lse, int dtype, 
     MmArgs m = {};
     m.A = (const bf16_t*)X; m.B = (const bf16_t*)A; m.C = (bf16_t*)out;
     m.M = Cx; m.N = N; m.K = K; m.sA = Cx * K; m.sB = K * N; m.sC = Cx * N; m.lse = lse; m.sL = N; m.batch = B;
+    if ((e = af_prepare(m, w.Af, st))) return e;
     if ((e = launch_mm<false, true, 1, 0>(m, st))) return e;
   }
   return 0;
@@ -926,7 +1151,11 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
   if (f32) {
     hipLaunchKernelGGL((psa_prob<float, true>), pgrid, dim3(256), 0, st, (const float*)A, lse, K, N, w.P_hi, w.P_lo);
     TSG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((psa_delta<float>), dgrid3, dim3(256), 0, st, (const float*)out, (const float*)dout, Cx, N, w.delta_part);
+    if (N % 4 == 0 && aligned16(out) && aligned16(dout))
+      hipLaunchKernelGGL((psa_delta_vec<float, 4>), dim3((unsigned)((N / 4 + 63) / 64), (unsigned)kDeltaChunks, (unsigned)B),
+                         dim3(256), 0, st, (const float*)out, (const float*)dout, Cx, N, w.delta_part);
+    else
+      hipLaunchKernelGGL((psa_delta<float>), dgrid3, dim3(256), 0, st, (const float*)out, (const float*)dout, Cx, N, w.delta_part);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL(psa_delta_fold, jgrid, dim3(256), 0, st, w.delta_part, N, w.delta);
     TSG_CHECK_LAUNCH();
@@ -956,13 +1185,18 @@ int tsg_psa_bwd(const void* X, const void* A, const void* out, const void* dout,
     hipLaunchKernelGGL(psa_da_f32, pgrid, dim3(256), 0, st, (const float*)A, lse, w.dP, w.delta, K, N, (float*)dA);
     TSG_CHECK_LAUNCH();
   } else {
-    hipLaunchKernelGGL((psa_delta<bf16_t>), dgrid3, dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta_part);
+    if (N % 8 == 0 && aligned16(out) && aligned16(dout))
+      hipLaunchKernelGGL((psa_delta_vec<bf16_t, 8>), dim3((unsigned)((N / 8 + 63) / 64), (unsigned)kDeltaChunks, (unsigned)B),
+                         dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta_part);
+    else
+      hipLaunchKernelGGL((psa_delta<bf16_t>), dgrid3, dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, Cx, N, w.delta_part);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL(psa_delta_fold, jgrid, dim3(256), 0, st, w.delta_part, N, w.delta);
     TSG_CHECK_LAUNCH();
     MmArgs mx = {};   // dX[c][i] = sum_j dOut[c][j] * exp(A[i][j] - lse[j])
     mx.A = (const bf16_t*)dout; mx.B = (const bf16_t*)A; mx.C = (bf16_t*)dX;
     mx.M = Cx; mx.N = K; mx.K = N; mx.sA = Cx * N; mx.sB = K * N; mx.sC = Cx * K; mx.lse = lse; mx.sL = N; mx.batch = B;
+    if ((e = af_prepare(mx, w.Af, st))) return e;
     if ((e = launch_mm<false, false, 2, 0>(mx, st))) return e;
     MmArgs ma = {};   // dA[i][j] = P[i][j] * (sum_c X[c][i] * dOut[c][j] - delta[j])
     ma.A = (const bf16_t*)X; ma.B = (const bf16_t*)dout; ma.C = (bf16_t*)dA;
