@@ -933,10 +933,8 @@ static int mm_cfg() {
       else if (!strcmp(e, "128x128x1")) cfg = 1281281; else if (!strcmp(e, "128x128x2")) cfg = 1281282;
       else if (!strcmp(e, "split128x128x1")) cfg = 91281281; else if (!strcmp(e, "split128x128x2")) cfg = 91281282;
       else if (!strcmp(e, "split128x64x1")) cfg = 9128641; else if (!strcmp(e, "split256x64x1")) cfg = 9256641;
-      else if (!strncmp(e, "af", 2)) {                 // af<BM>x<BN>[x<PF>]: A fragments from global, PF - 1 tiles ahead
-        int bm = 0, bn = 0, pf = 2;
-        if (sscanf(e, "af%dx%dx%d", &bm, &bn, &pf) >= 2) cfg = 70000000 + bm * 10000 + bn * 10 + pf;
-      }
+      else if (!strncmp(e, "af128x64", 8)) cfg = 71280642;   // A fragments from global, one K tile ahead
+      else if (!strncmp(e, "af256x64", 8)) cfg = 72560642;
     }
   }
   return cfg;
@@ -948,7 +946,6 @@ static int launch_mm_af(MmArgs g, hipStream_t st, int cfg) {
   if constexpr (!A_TR) {
     switch (cfg) {
       case 71280642: return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
-      case 71281282: return launch_mm_cfg<128, 128, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
       default:       return launch_mm_cfg<256, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
     }
   }
