@@ -1,0 +1,67 @@
+"""Build-time guards on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles).
+
+psa.hip's fragment-order kernels (`psa_mm<..., SPLIT = true, AF = true>`) prefetch with global loads the compiler does
+not track (`TSG_ASM_LD16` + a hand-placed `s_waitcnt`).  That is only sound while the registers those loads
+write are never spilled or copied before the wait: a spill stores a register the load has not written yet (the
+af256x64x3 instantiation failed its parity test exactly so).  So: no scratch, no VGPR spills in any AF instantiation, and
+every untracked load is followed by a wait before the kernel ends."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def psa_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "psa.s"
+    cmd = [HIPCC, "-x", "hip", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-ffp-contract=off",
+           "--cuda-device-only", "-S", os.path.join(ROOT, "torchseg_amd", "csrc", "psa.hip"),
+           "-I", os.path.join(ROOT, "include"), "-o", str(out)]
+    subprocess.run(cmd, check=True, cwd=str(out.parent), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _kernel_meta(isa):
+    """name -> {vgpr_spill_count, private_segment_fixed_size} from the amdhsa.kernels metadata."""
+    meta = {}
+    for block in isa.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        spill = re.search(r"\.vgpr_spill_count:\s+(\d+)", block)
+        scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+        if name and spill and scratch:
+            meta[name.group(1)] = (int(spill.group(1)), int(scratch.group(1)))
+    return meta
+
+
+def test_fragment_order_psa_kernels_do_not_spill(psa_isa):
+    meta = _kernel_meta(psa_isa)
+    af = {k: v for k, v in meta.items() if "psa_mm" in k and k.endswith("Lb1ELb1EEEvNS_6MmArgsE")}
+    assert len(af) >= 4, sorted(meta)            # forward + dX for 128x64 and 256x64
+    for name, (spill, scratch) in af.items():
+        assert spill == 0 and scratch == 0, (name, spill, scratch)
+
+
+def test_untracked_loads_are_waited_for(psa_isa):
+    """Every AF kernel holds the inline-asm loads, the per-set inline-asm waits with a non-zero count (prefetch in
+    flight behind the set that is consumed) and the drain `s_waitcnt vmcnt(0)` in front of the epilogue."""
+    bodies = re.split(r"\n(_ZN3tsg6psa_mmI\w+):", psa_isa)
+    checked = 0
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        if not name.endswith("Lb1ELb1EEEvNS_6MmArgsE"):
+            continue
+        body = body.split("s_endpgm")[0]
+        asm = re.findall(r";;#ASMSTART\n(.*?)\n\s*;;#ASMEND", body, flags=re.S)
+        stmts = [a.strip() for a in asm if a.strip()]
+        assert any(s.startswith("global_load_dwordx4") for s in stmts), name
+        waits = [s for s in stmts if s.startswith("s_waitcnt vmcnt(")]
+        assert "s_waitcnt vmcnt(0)" in waits, (name, waits)                     # prologue wait / drain
+        assert any(w != "s_waitcnt vmcnt(0)" for w in waits), (name, waits)     # counted waits of the K loop
+        checked += 1
+    assert checked >= 4
