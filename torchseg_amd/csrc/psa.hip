@@ -533,13 +533,17 @@ __global__ __launch_bounds__(256) void psa_frag_k(const bf16_t* __restrict__ X, 
 // its counters (profiles/r03_psa_sq_counters.txt) show SQ_ACTIVE_INST_ANY at 48 % of the wave cycles with the MFMA pipe
 // busy 17 % of the time — issue-bound on the staging code.  The matrix pipe and the VALU are separate pipes, so a
 // staging wave and an MFMA wave on one SIMD run concurrently (MI355X_MICROARCH.md, wave scheduling).
-template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT, bool AF = false>
-__global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T, ((SPLIT && !(AF && BM == 256)) || (BM == 128 && BN == 64) ? 2 : 1))
+// UT (round 3): the staging waves prefetch with untracked loads (all AF kernels; and, without AF, the products whose A
+// operand is staged too -- dA with its 8 K tiles per output tile is pure load latency, PF = 3 keeps three tiles in flight)
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT, bool AF = false, bool UT = AF>
+__global__ __launch_bounds__(SPLIT ? 2 * MM_T : MM_T,
+                             (UT && !AF && BM == 128 && PF == 2) ? 4 : ((SPLIT && !(AF && BM == 256)) || (BM == 128 && BN == 64) ? 2 : 1))
 void psa_mm(MmArgs g) {
   typedef MmGeom<BM, BN> G;
   // AF is instantiated with PF = 2 only: a deeper pipeline spills at 256 VGPRs, and a spill of a register an untracked
   // load is still writing stores garbage (af256x64x3 failed its parity test exactly so)
   static_assert(!AF || (!A_TR && SPLIT && PF == 2), "AF: NT A operand, MFMA / staging wave split, two register sets");
+  static_assert((!AF || UT) && (!UT || (SPLIT && PF >= 2)), "UT: staging waves of their own, at least two register sets");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const bool producer = SPLIT && threadIdx.x >= MM_T;    // wave-uniform
   const bool stages = !SPLIT || producer, computes = !SPLIT || !producer;
@@ -671,7 +675,7 @@ void psa_mm(MmArgs g) {
       if (ablate & 4) {
       } else if (EXPB == 1) {
         v = expchunk(v, bl[EXPB == 1 ? q : 0]);
-      } else if (EXPB == 2 && AF) {                        // lse of the chunk's 8 k positions came with the tile (fetch_b)
+      } else if (EXPB == 2 && UT) {                        // lse of the chunk's 8 k positions came with the tile (TSG_UT_FETCH)
         const u32x4 l0 = lpre[2 * q], l1 = lpre[2 * q + 1];
         const float l2[8] = {__uint_as_float(l0.x) * kLog2e, __uint_as_float(l0.y) * kLog2e, __uint_as_float(l0.z) * kLog2e,
                              __uint_as_float(l0.w) * kLog2e, __uint_as_float(l1.x) * kLog2e, __uint_as_float(l1.y) * kLog2e,
@@ -725,14 +729,26 @@ void psa_mm(MmArgs g) {
     TSG_ASM_LD16(xa[SET][i_][2], afp[i_], 2048); TSG_ASM_LD16(xa[SET][i_][3], afp[i_], 3072);             \
     afp[i_] += (ADV);                                                                                     \
   }
-  // AF, staging waves: the B tile (and, EXPB 2, the lse of its k positions) by the same untracked loads, PF tiles ahead;
-  // ONE load site per register (the pointer is selected, not the load) and one wait site, as for the fragments.  Tiles
-  // beyond the last one re-read the last one, so (PF - 1) sets are in flight behind the one being written to LDS.
-  constexpr int LPC = AF ? (EXPB == 2 ? 3 : 1) : 1;        // loads per chunk
-  u32x4 xb[AF ? PF : 1][AF ? G::BCH : 1], xl[AF && EXPB == 2 ? PF : 1][AF && EXPB == 2 ? 2 * G::BCH : 1];
-#define TSG_AF_FETCH_B(SET, K0, ADV)                                                                      \
-  _Pragma("unroll") for (int q_ = 0; q_ < (AF ? G::BCH : 1); ++q_) {                                      \
-    const int over_ = (K0) + kb[q_] - kb_max;          /* > 0 only in the partial last tile */            \
+  // UT, staging waves: the B tile (EXPB 2: and the lse of its k positions; without AF: and the A tile) by the same
+  // untracked loads, PF tiles ahead; ONE load site per register (the pointer is selected, not the load) and one wait site,
+  // as for the fragments.  Tiles beyond the last one re-read the last one, so (PF - 1) sets are in flight behind the one
+  // being written to LDS.
+  constexpr bool UTA = UT && !AF;                          // the A tile is staged as well
+  constexpr int LPC = UT ? (EXPB == 2 ? 3 : 1) : 1;        // loads per B chunk
+  constexpr int LPS = UT ? (UTA ? G::ACH : 0) + LPC * G::BCH : 1;   // loads per set
+  u32x4 ya[UTA ? PF : 1][UTA ? G::ACH : 1];
+  u32x4 xb[UT ? PF : 1][UT ? G::BCH : 1], xl[UT && EXPB == 2 ? PF : 1][UT && EXPB == 2 ? 2 * G::BCH : 1];
+#define TSG_UT_FETCH(SET, K0, ADV_A, ADV_B)                                                               \
+  if (UTA) {                                                                                              \
+    _Pragma("unroll") for (int q_ = 0; q_ < (UTA ? G::ACH : 1); ++q_) {                                   \
+      const int over_ = (K0) + ka[q_] - ka_max;        /* > 0 only in the partial last tile */            \
+      const bf16_t* p_ = pa[q_] - (over_ > 0 ? (int64_t)over_ * sa_k : 0);                                \
+      TSG_ASM_LD16(ya[UTA ? SET : 0][UTA ? q_ : 0], p_, 0);                                               \
+      pa[q_] += (ADV_A);                                                                                  \
+    }                                                                                                     \
+  }                                                                                                       \
+  _Pragma("unroll") for (int q_ = 0; q_ < (UT ? G::BCH : 1); ++q_) {                                      \
+    const int over_ = (K0) + kb[q_] - kb_max;                                                             \
     const bf16_t* p_ = pb[q_] - (over_ > 0 ? (int64_t)over_ * sb_k : 0);                                  \
     TSG_ASM_LD16(xb[SET][q_], p_, 0);                                                                     \
     if (EXPB == 2) {                                                                                      \
@@ -740,20 +756,24 @@ void psa_mm(MmArgs g) {
       TSG_ASM_LD16(xl[EXPB == 2 ? SET : 0][EXPB == 2 ? 2 * q_ : 0], l_, 0);                               \
       TSG_ASM_LD16(xl[EXPB == 2 ? SET : 0][EXPB == 2 ? 2 * q_ + 1 : 0], l_, 16);                          \
     }                                                                                                     \
-    pb[q_] += (ADV);                                                                                      \
+    pb[q_] += (ADV_B);                                                                                    \
   }
-#define TSG_AF_STASH_B(SET, STAGE_, K0)                                                                   \
+#define TSG_UT_STASH(SET, STAGE_, K0)                                                                     \
   {                                                                                                       \
-    uint4 tb_[AF ? G::BCH : 1];                                                                           \
-    _Pragma("unroll") for (int q_ = 0; q_ < (AF ? G::BCH : 1); ++q_)                                      \
+    uint4 ta_[UTA ? G::ACH : 1], tb_[UT ? G::BCH : 1];                                                    \
+    if (UTA) { _Pragma("unroll") for (int q_ = 0; q_ < (UTA ? G::ACH : 1); ++q_) {                        \
+      const u32x4 v_ = ya[UTA ? SET : 0][UTA ? q_ : 0]; ta_[q_] = make_uint4(v_.x, v_.y, v_.z, v_.w); } } \
+    _Pragma("unroll") for (int q_ = 0; q_ < (UT ? G::BCH : 1); ++q_)                                      \
       tb_[q_] = make_uint4(xb[SET][q_].x, xb[SET][q_].y, xb[SET][q_].z, xb[SET][q_].w);                   \
-    stash(nullptr, tb_, STAGE_, K0, xl[EXPB == 2 ? SET : 0]);                                             \
+    stash(ta_, tb_, STAGE_, K0, xl[EXPB == 2 ? SET : 0]);                                                 \
   }
-#define TSG_AF_WAIT_B(SET, N_)                                                                            \
+#define TSG_UT_WAIT(SET, N_)                                                                              \
   {                                                                                                       \
     vm_wait<N_>(xb[SET][0]);                                                                              \
-    _Pragma("unroll") for (int q_ = 1; q_ < (AF ? G::BCH : 1); ++q_) vm_tie(xb[SET][q_]);                 \
-    if (EXPB == 2) { _Pragma("unroll") for (int q_ = 0; q_ < 2 * (AF ? G::BCH : 1); ++q_)                 \
+    _Pragma("unroll") for (int q_ = 1; q_ < (UT ? G::BCH : 1); ++q_) vm_tie(xb[SET][q_]);                 \
+    if (UTA) { _Pragma("unroll") for (int q_ = 0; q_ < (UTA ? G::ACH : 1); ++q_)                          \
+      vm_tie(ya[UTA ? SET : 0][UTA ? q_ : 0]); }                                                          \
+    if (EXPB == 2) { _Pragma("unroll") for (int q_ = 0; q_ < 2 * (UT ? G::BCH : 1); ++q_)                 \
       vm_tie(xl[EXPB == 2 ? SET : 0][EXPB == 2 ? q_ : 0]); }                                              \
   }
   const int nk = (int)((g.K + MM_BK - 1) / MM_BK);
@@ -761,14 +781,14 @@ void psa_mm(MmArgs g) {
 #pragma unroll
     for (int u = 0; u + 1 < PF; ++u) { TSG_AF_LOAD(AF ? u : 0, u + 1 < nk ? 4 * 512 : 0) }
   }
-  if (AF && stages) {
-    TSG_AF_FETCH_B(0, 0, nk > 1 ? step_b : 0)
-    TSG_AF_WAIT_B(0, 0)
-    TSG_AF_STASH_B(0, 0, 0)
+  if (UT && stages) {
+    TSG_UT_FETCH(0, 0, nk > 1 ? step_a : 0, nk > 1 ? step_b : 0)
+    TSG_UT_WAIT(0, 0)
+    TSG_UT_STASH(0, 0, 0)
 #pragma unroll
     for (int u = 1; u <= PF; ++u) {                       // tile min(u, nk - 1) into set u % PF
       const int tu = u < nk ? u : nk - 1;
-      TSG_AF_FETCH_B(AF ? u % PF : 0, tu * MM_BK, u + 1 < nk ? step_b : 0)
+      TSG_UT_FETCH(UT ? u % PF : 0, tu * MM_BK, u + 1 < nk ? step_a : 0, u + 1 < nk ? step_b : 0)
     }
   } else if (stages) {
     fetch(ra[0], rb[0], 0);
@@ -784,11 +804,11 @@ void psa_mm(MmArgs g) {
       if (kt >= nk) break;
       const int s = (u + 1) % PF;                        // == (kt + 1) % PF: kt0 is a multiple of PF
       __syncthreads();                                   // tile kt is complete in LDS; tile kt-1's reads are done
-      if (AF && stages) {
-        TSG_AF_WAIT_B(AF ? s : 0, (PF - 1) * LPC * (AF ? G::BCH : 1))   // set s = tile kt + 1 (or a re-read of the last one)
-        if (kt + 1 < nk) TSG_AF_STASH_B(AF ? s : 0, (kt + 1) & 1, (kt + 1) * MM_BK)
+      if (UT && stages) {
+        TSG_UT_WAIT(UT ? s : 0, (PF - 1) * LPS)            // set s = tile kt + 1 (or a re-read of the last one)
+        if (kt + 1 < nk) TSG_UT_STASH(UT ? s : 0, (kt + 1) & 1, (kt + 1) * MM_BK)
         const int tn_ = kt + 1 + PF < nk ? kt + 1 + PF : nk - 1;
-        TSG_AF_FETCH_B(AF ? s : 0, tn_ * MM_BK, kt + 2 + PF < nk ? step_b : 0)
+        TSG_UT_FETCH(UT ? s : 0, tn_ * MM_BK, kt + 2 + PF < nk ? step_a : 0, kt + 2 + PF < nk ? step_b : 0)
       } else if (stages) {
         if (kt + 1 < nk) stash(ra[s], rb[s], (kt + 1) & 1, (kt + 1) * MM_BK);
         if (kt + 1 + PF < nk) fetch(ra[s], rb[s], (kt + 1 + PF) * MM_BK);
@@ -846,7 +866,7 @@ void psa_mm(MmArgs g) {
     }
   }
 
-  if (AF) asm volatile("s_waitcnt vmcnt(0)");             // the tail's re-reads still target xa / xb: land them before reuse
+  if (UT) asm volatile("s_waitcnt vmcnt(0)");             // the tail's re-reads still target xa / xb / ya: land them before reuse
   // ---- epilogue through LDS: acc (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half) -> fp32 image
   // [BM][BN + 4], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
   __syncthreads();
@@ -901,7 +921,7 @@ void psa_mm(MmArgs g) {
   }
 }
 
-template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT = false, bool AF = false>
+template <int BM, int BN, int PF, bool A_TR, bool B_TR, int EXPB, int EPI, bool SPLIT = false, bool AF = false, bool UT = AF>
 static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   g.tiles_m = (int)((g.M + BM - 1) / BM);
   g.tiles_n = (int)((g.N + BN - 1) / BN);
@@ -910,9 +930,9 @@ static int launch_mm_cfg(MmArgs g, hipStream_t st) {
   { const char* o = getenv("TSG_PSA_ORDER"); g.m_fastest = (o && o[0] == 'm') ? 1 : 0; }
   { const char* o = getenv("TSG_PSA_ABLATE"); g.ablate = o ? atoi(o) : 0; }
   constexpr size_t lds_bytes = MmGeom<BM, BN>::LDS;
-  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT, AF>),
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT, AF, UT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT, AF>), dim3((unsigned)(8 * g.per_xcd)),
+  hipLaunchKernelGGL((psa_mm<BM, BN, PF, A_TR, B_TR, EXPB, EPI, SPLIT, AF, UT>), dim3((unsigned)(8 * g.per_xcd)),
                      dim3(SPLIT ? 2 * MM_T : MM_T), lds_bytes, st, g);
   TSG_CHECK_LAUNCH();
   return 0;
@@ -959,7 +979,14 @@ static int launch_mm(MmArgs g, hipStream_t st) {
   const int cfg = mm_cfg();
   if (cfg / 10000000 == 7) {
     if (!A_TR && g.Af) return launch_mm_af<A_TR, B_TR, EXPB, EPI>(g, st, cfg);
-    return launch_mm_cfg<128, 64, 1, A_TR, B_TR, EXPB, EPI, true>(g, st);      // products without a fragment image
+    // products without a fragment image (dA): both tiles staged by tracked loads, one tile ahead.  TSG_PSA_UT_PF=2 runs
+    // them with two sets of untracked prefetch instead: measured 151 vs 141-147 us for the backward call (three sets at one
+    // block per CU: 193 us) -- with 8 K tiles per output tile dA is not bound by the depth of its K pipeline
+    if constexpr (A_TR) {
+      static const int ut_pf = [] { const char* e = getenv("TSG_PSA_UT_PF"); return e ? atoi(e) : 1; }();
+      if (ut_pf == 2) return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI, true, false, true>(g, st);
+    }
+    return launch_mm_cfg<128, 64, 1, A_TR, B_TR, EXPB, EPI, true>(g, st);
   }
   switch (cfg) {
     case 2561: return launch_mm_cfg<256, 64, 1, A_TR, B_TR, EXPB, EPI>(g, st);
