@@ -16,16 +16,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def psa_isa(tmp_path_factory):
+def _isa(tmp_path_factory, src):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "psa.s"
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
     cmd = [HIPCC, "-x", "hip", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-ffp-contract=off",
-           "--cuda-device-only", "-S", os.path.join(ROOT, "torchseg_amd", "csrc", "psa.hip"),
+           "--cuda-device-only", "-S", os.path.join(ROOT, "torchseg_amd", "csrc", src),
            "-I", os.path.join(ROOT, "include"), "-o", str(out)]
     subprocess.run(cmd, check=True, cwd=str(out.parent), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def psa_isa(tmp_path_factory):
+    return _isa(tmp_path_factory, "psa.hip")
+
+
+@pytest.fixture(scope="module")
+def wrw_isa(tmp_path_factory):
+    return _isa(tmp_path_factory, "conv3wrw.hip")
 
 
 def _kernel_meta(isa):
@@ -65,3 +74,21 @@ def test_untracked_loads_are_waited_for(psa_isa):
         assert any(w != "s_waitcnt vmcnt(0)" for w in waits), (name, waits)     # counted waits of the K loop
         checked += 1
     assert checked >= 5
+
+
+def test_two_tiles_ahead_weight_gradient_does_not_spill(wrw_isa):
+    """conv3_wrw_gen_k<S, PF = 2, AFF>: two register sets of untracked loads (44 VGPRs each at stride 1).  The stride-2
+    instantiation spilled (23 loads per set) and is therefore not built at all."""
+    meta = _kernel_meta(wrw_isa)
+    pf2 = {k: v for k, v in meta.items() if "conv3_wrw_gen_kILi" in k and "ELi2ELb" in k}
+    assert len(pf2) == 2, sorted(meta)           # stride 1, with / without BN-on-load
+    for name, (spill, scratch) in pf2.items():
+        assert name.startswith("_ZN3tsg15conv3_wrw_gen_kILi1ELi2E"), name
+        assert spill == 0 and scratch == 0, (name, spill, scratch)
+    bodies = re.split(r"\n(_ZN3tsg15conv3_wrw_gen_kI\w+):", wrw_isa)
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        if name not in pf2:
+            continue
+        asm = [a.strip() for a in re.findall(r";;#ASMSTART\n(.*?)\n\s*;;#ASMEND", body.split("s_endpgm")[0], flags=re.S)]
+        assert sum(a.startswith("global_load_dwordx4") for a in asm) == 4 * 11     # prologue 2 sets + one per loop half
+        assert "s_waitcnt vmcnt(11)" in asm and "s_waitcnt vmcnt(0)" in asm, name

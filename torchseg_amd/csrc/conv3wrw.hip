@@ -316,10 +316,16 @@ template <int S> struct W3S {
   static constexpr size_t LDS = (size_t)(T3_DY + NPX * T3_RBE) * sizeof(bf16_t);    // 63,744 B / 136,896 B
 };
 
-// PF = true: one block per CU, the next tile's operands are prefetched into registers while the MFMAs run.
-// PF = false: no register prefetch (the 44 registers it costs go), two blocks per CU that cover for each other's loads,
+// PF = 1: one block per CU, the next tile's operands are prefetched into registers while the MFMAs run.
+// PF = 0: no register prefetch (the 44 registers it costs go), two blocks per CU that cover for each other's loads,
 // staging and barriers — with one block per CU the MFMA pipe idles ~2/3 of the time during those phases.
-template <int S, bool PF, bool AFF, bool SH = true>
+// PF = 2 (round 3): one block per CU, TWO tiles ahead by untracked loads (tsg_common.h: TSG_ASM_LD16 / vm_wait).  A tile
+// is 72 MFMAs per wave = ~1 us and the measured tile time 2.1 us (128 -> 128 at 64^2: 32 tiles per block in 68 us, MFMA
+// pipe busy 0.36-0.45), which looked like one tile of prefetch against a ~2 us load latency -- but with two tiles in flight
+// the kernel is SLOWER (opt-in, see w3_pf2()).  The loads are unconditional (a position outside the image reads the tensor's first element
+// and is zeroed when the set is written to LDS; a tile index beyond the block's last one re-reads the last one), so the
+// number of loads in flight behind the set being consumed is the constant the s_waitcnt needs.
+template <int S, int PF, bool AFF>
 __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ part, W3GenGeom g, const float* __restrict__ in_ab) {
   typedef W3S<S> P;
@@ -380,53 +386,34 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
                   : make_uint4(0, 0, 0, 0);
     }
   };
-
-  int tile = slot;
-  if (PF && tile < g.ntiles) fetch(tile);
-  for (; tile < g.ntiles; tile += g.bpp) {
-    if (!PF) fetch(tile);
-    __syncthreads();
+  // one tile's operands, registers -> LDS.  REZERO (PF = 2): the loads were unconditional, positions outside the image
+  // become the exact zeros the predicated loads of PF 0 / 1 return
+  auto stage = [&](const uint4* qd_, const uint4* qx_, int tile_, bool rezero) {
+    const int cur_ow0 = (tile_ % g.tiles_w) * W3_TW, cur_oh0 = ((tile_ / g.tiles_w) % g.tiles_h) * W3_TH;
 #pragma unroll
-    for (int u = 0; u < W3_TH; ++u)
-      *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = rd[u];
-    const int cur_ow0 = (tile % g.tiles_w) * W3_TW, cur_oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
+    for (int u = 0; u < W3_TH; ++u) {
+      uint4 v = qd_[u];
+      if (rezero && !(cur_oh0 + u < g.H && cur_ow0 + spix < g.W)) v = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(dyL + (spix + 32 * u) * T3_RBE + spart * 8) = v;
+    }
 #pragma unroll
     for (int u = 0; u < P::XU; ++u)
       if (u < P::XU - 1 || xr[u] >= 0) {
-        uint4 v = rx[u];
-        if (AFF) {
-          const int ih = S * cur_oh0 - 1 + xr[u], iw = S * cur_ow0 - 1 + xc[u];
-          if (ih >= 0 && ih < g.Hin && iw >= 0 && iw < g.Win) v = w3_affine_relu(v, abs_, spart * 8);
-        }
+        uint4 v = qx_[u];
+        const int ih = S * cur_oh0 - 1 + xr[u], iw = S * cur_ow0 - 1 + xc[u];
+        const bool in = ih >= 0 && ih < g.Hin && iw >= 0 && iw < g.Win;
+        if (AFF && in) v = w3_affine_relu(v, abs_, spart * 8);
+        if (rezero && !in) v = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(xL + (spix + 32 * u) * T3_RBE + spart * 8) = v;
       }
-    __syncthreads();
-    if (PF && tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
-    // dy fragments of the 8 k steps (16 output pixels each: tile row ks >> 1, columns 16 (ks & 1) + 8 half ..) stay in
-    // registers; the x fragments are read once per PATCH row: the fragment tap kh of tile row r needs (patch row S r + kh,
-    // columns S 16 c + kw ..) is the one tap kh - S of tile row r + 1 needs, so walking patch rows instead of (row, kh)
-    // pairs reads 36 (stride 1) / 54 (stride 2) fragments per tile instead of 72 -- this loop is bound by LDS reads
-    // (two ds_read_b64_tr per MFMA before; round 3)
-    union Frag { v4i16 q[2]; bf16x8 v; };
-    if (!SH) {                                          // round-2 order (TSG_WRW_SHARE=0): one x fragment per MFMA
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        Frag fa1;
-        fa1.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 0) * (T3_RBE / 4)));
-        fa1.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(afr + (ks * 16 + 4) * (T3_RBE / 4)));
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int px = (S * (ks >> 1) + kh) * P::PC + S * (ks & 1) * 16 + kw;
-            Frag fb;
-            fb.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 0) * (T3_RBE / 4)));
-            fb.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(bfr + (px + 4 * S) * (T3_RBE / 4)));
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1.v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
-          }
-      }
-      continue;
-    }
+  };
+  union Frag { v4i16 q[2]; bf16x8 v; };
+  // the MFMAs of the tile in LDS.  dy fragments of the 8 k steps (16 output pixels each: tile row ks >> 1, columns
+  // 16 (ks & 1) + 8 half ..) stay in registers; the x fragments are read once per PATCH row: the fragment tap kh of tile
+  // row r needs (patch row S r + kh, columns S 16 c + kw ..) is the one tap kh - S of tile row r + 1 needs, so walking
+  // patch rows instead of (row, kh) pairs reads 36 (stride 1) / 54 (stride 2) fragments per tile instead of 72 (neutral
+  // in the step: this loop is not bound by LDS reads, profiles/r03_conv3wrw_shared_fragments.txt)
+  auto mfma_tile = [&]() {
     Frag fa[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -450,6 +437,73 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
               acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * (rr / S) + c].v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
           }
         }
+  };
+
+  if (PF == 2) {
+    constexpr int L = W3_TH + P::XU;                    // loads per set
+    u32x4 qd[PF == 2 ? 2 : 1][W3_TH], qx[PF == 2 ? 2 : 1][PF == 2 ? P::XU : 1];
+    // the block's last tile: what indices beyond it re-read
+    const int last = slot < g.ntiles ? slot + (g.ntiles - 1 - slot) / g.bpp * g.bpp : 0;
+#define TSG_W3_FETCH(SET, TILE)                                                                               \
+    {                                                                                                         \
+      const int t_ = (TILE) < g.ntiles ? (TILE) : last;                                                       \
+      const int ow0_ = (t_ % g.tiles_w) * W3_TW, oh0_ = ((t_ / g.tiles_w) % g.tiles_h) * W3_TH;               \
+      const int b_ = t_ / (g.tiles_w * g.tiles_h);                                                            \
+      const int64_t pix_ = ((int64_t)b_ * g.H + oh0_) * g.W + ow0_;                                           \
+      const bf16_t* dt_ = dy + (pix_ + spix) * g.Cout + oc0 + spart * 8;                                      \
+      _Pragma("unroll") for (int u_ = 0; u_ < W3_TH; ++u_) {                                                  \
+        const bf16_t* p_ = (oh0_ + u_ < g.H && ow0_ + spix < g.W) ? dt_ + (int64_t)u_ * g.W * g.Cout : dy;    \
+        TSG_ASM_LD16(qd[SET][u_], p_, 0);                                                                     \
+      }                                                                                                       \
+      const int ih0_ = S * oh0_ - 1, iw0_ = S * ow0_ - 1;                                                     \
+      const bf16_t* xo_ = x + (((int64_t)b_ * g.Hin + ih0_) * g.Win + iw0_) * g.Cin + ci0 + spart * 8;        \
+      _Pragma("unroll") for (int u_ = 0; u_ < P::XU; ++u_) {                                                  \
+        const int ih_ = ih0_ + xr[u_], iw_ = iw0_ + xc[u_];                                                   \
+        const bf16_t* p_ = (xr[u_] >= 0 && ih_ >= 0 && ih_ < g.Hin && iw_ >= 0 && iw_ < g.Win)                \
+                               ? xo_ + ((int64_t)xr[u_] * g.Win + xc[u_]) * g.Cin : x;                        \
+        TSG_ASM_LD16(qx[SET][PF == 2 ? u_ : 0], p_, 0);                                                       \
+      }                                                                                                       \
+    }
+    int tile = slot;
+    if (tile < g.ntiles) {
+      TSG_W3_FETCH(0, tile)
+      TSG_W3_FETCH(1, tile + g.bpp)
+      for (bool more = true; more;) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          __syncthreads();                               // the previous tile's fragment reads are done
+          vm_wait<L>(qd[PF == 2 ? s_ : 0][0]);           // all but the other set's L loads have landed
+#pragma unroll
+          for (int u = 1; u < W3_TH; ++u) vm_tie(qd[PF == 2 ? s_ : 0][u]);
+#pragma unroll
+          for (int u = 0; u < P::XU; ++u) vm_tie(qx[PF == 2 ? s_ : 0][PF == 2 ? u : 0]);
+          uint4 td[W3_TH], tx[P::XU];
+#pragma unroll
+          for (int u = 0; u < W3_TH; ++u) { const u32x4 v = qd[PF == 2 ? s_ : 0][u]; td[u] = make_uint4(v.x, v.y, v.z, v.w); }
+#pragma unroll
+          for (int u = 0; u < P::XU; ++u) { const u32x4 v = qx[PF == 2 ? s_ : 0][PF == 2 ? u : 0]; tx[u] = make_uint4(v.x, v.y, v.z, v.w); }
+          stage(td, tx, tile, true);
+          __syncthreads();
+          TSG_W3_FETCH(PF == 2 ? s_ : 0, tile + 2 * g.bpp)   // into the set just written out; re-reads `last` at the tail
+          mfma_tile();
+          tile += g.bpp;
+          if (tile >= g.ntiles) { more = false; break; }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)");                // the tail's re-reads still target qd / qx
+    }
+#undef TSG_W3_FETCH
+  } else {
+    int tile = slot;
+    if (PF == 1 && tile < g.ntiles) fetch(tile);
+    for (; tile < g.ntiles; tile += g.bpp) {
+      if (PF == 0) fetch(tile);
+      __syncthreads();
+      stage(rd, rx, tile, false);
+      __syncthreads();
+      if (PF == 1 && tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
+      mfma_tile();
+    }
   }
   // partial of this (pair, slot): [pair][slot][64 oc][9 taps][64 ci]
   float* out = part + ((int64_t)pair * g.bpp + slot) * W3_C * W3_N;
@@ -593,9 +647,16 @@ int tsg_conv3x3_wrw_tr_norm(const void* x, const float* in_ab, const void* dy, f
 // kernel (no register prefetch).  tools/bench_conv3wrw.py, us per layer, 1 -> 2: layer2 97 -> 88, layer3 107 -> 87,
 // layer4 127 -> 104, head1 193 -> 156 (0.99 PF), head2 99 -> 89; the 64^2 / 32^2 maps (<= 512 tiles) are a few us better
 // with one prefetching block per CU and keep it.
+// TSG_CONV_WRW_PF2=1 (opt-in): the stride-1 layers on the two-tiles-ahead kernel, one block per CU.  Measured SLOWER
+// (profiles/r03_conv3wrw_two_tiles_ahead.txt: 2.76 vs 2.37 ms per step, 1100 vs 1125 img/s on one box; layer3 at the same
+// occupancy 123 vs 105 us): the tile time is not the load latency the 2.1 us per tile suggested
+static bool w3_pf2() {
+  static const bool v = [] { const char* e = getenv("TSG_CONV_WRW_PF2"); return e && e[0] == '1'; }();
+  return v;
+}
 static bool w3_occ2(int64_t ntiles) {
   static const int v = [] { const char* e = getenv("TSG_CONV_WRW_OCC"); return e ? atoi(e) : 2; }();
-  return v == 2 && ntiles >= 1024;
+  return !w3_pf2() && v == 2 && ntiles >= 1024;
 }
 
 static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t Hin, int64_t Win, int Cin, int Cout, int stride) {
@@ -640,20 +701,20 @@ static int conv3_wrw_gen_common(const void* x, const float* in_ab, const void* d
   if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, Hin, Win, Cin, Cout, stride)) return TSG_E_WS;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  static const bool share = [] { const char* e = getenv("TSG_WRW_SHARE"); return !(e && e[0] == '0'); }();
-#define W3_GO1(SS, PFF, AF, SHH)                                                                                  \
+#define W3_GO(SS, PFF, AF)                                                                                        \
   do {                                                                                                            \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF, SHH>),                \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF>),                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<SS>::LDS));                  \
-    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF, SHH>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,  \
+    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,       \
                        (const bf16_t*)x, (const bf16_t*)dy, (float*)ws, g, in_ab);                                \
   } while (0)
-#define W3_GO(SS, PFF, AF) do { if (share) W3_GO1(SS, PFF, AF, true); else W3_GO1(SS, PFF, AF, false); } while (0)
-  if (stride == 1 && w3_occ2(g.ntiles)) { if (in_ab) W3_GO(1, false, true); else W3_GO(1, false, false); }
-  else if (stride == 1) { if (in_ab) W3_GO(1, true, true); else W3_GO(1, true, false); }
-  else { if (in_ab) W3_GO(2, true, true); else W3_GO(2, true, false); }
+  // stride 2 stays on PF = 1: two sets of its 23 loads do not fit the register file (the build spilled 72-84 VGPRs,
+  // and a spilled register of an in-flight load is garbage)
+  if (stride == 1 && w3_pf2()) { if (in_ab) W3_GO(1, 2, true); else W3_GO(1, 2, false); }
+  else if (stride == 1 && w3_occ2(g.ntiles)) { if (in_ab) W3_GO(1, 0, true); else W3_GO(1, 0, false); }
+  else if (stride == 1) { if (in_ab) W3_GO(1, 1, true); else W3_GO(1, 1, false); }
+  else { if (in_ab) W3_GO(2, 1, true); else W3_GO(2, 1, false); }
 #undef W3_GO
-#undef W3_GO1
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
   TSG_CHECK_LAUNCH();

@@ -78,6 +78,17 @@ template <> struct Vec<bf16_t> {
   }
 };
 
+// Global loads the compiler's waitcnt pass does not see.  Around a prefetch that lives across the back edge of the K loop
+// the pass is conservative: it drained EVERY outstanding load before the first MFMA of a tile (s_waitcnt vmcnt(7) .. (0) in
+// the ISA of round 3's first fragment-order PSA build), so the tile time was one full memory latency whatever the prefetch depth.  These
+// loads are paired with vm_wait<N>, which names the registers it makes valid (the "+v" operands order their consumers
+// after it); loads return in order, so "at most N outstanding" with N = the loads issued AFTER the set that is needed.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define TSG_ASM_LD16(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
+template <int N>
+__device__ __forceinline__ void vm_wait(u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N)); }
+__device__ __forceinline__ void vm_tie(u32x4& a) { asm volatile("" : "+v"(a)); }
+
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
