@@ -325,7 +325,15 @@ template <int S> struct W3S {
 // the kernel is SLOWER (opt-in, see w3_pf2()).  The loads are unconditional (a position outside the image reads the tensor's first element
 // and is zeroed when the set is written to LDS; a tile index beyond the block's last one re-reads the last one), so the
 // number of loads in flight behind the set being consumed is the constant the s_waitcnt needs.
-template <int S, int PF, bool AFF>
+// BUF (round 3; default, TSG_CONV_WRW_BUF=0 selects the pointer loads): the fetch as raw buffer loads.  The ISA of the pointer version spends 293 instructions per tile and wave on the 11 loads
+// (64-bit address arithmetic, one divergent branch per predicated load) before the tile's first MFMA can issue.  Here a
+// thread's byte offsets are tile-independent 32-bit constants computed once, the tile contributes a scalar base (the
+// buffer descriptor), and a position outside the image gets the offset 0x80000000, which the buffer unit answers with
+// zeros (num_records 0x7fffffff): no branches, no 64-bit VALU, one basic block the scheduler places under the MFMAs
+// (175 -> ~125 instructions, interleaved with the tile's MFMAs in the ISA).  Bit-equal to the pointer version on the
+// bench's layers, ragged sizes, stride 2 and BN-on-load; 109 -> 90 us (256 -> 256 at 64^2), 138 -> 104 us (512 -> 512 at
+// 32^2), 77 -> 61 us (stride 2, 128 -> 256 at 128^2), 88 -> 86 us (two blocks per CU): profiles/r03_conv3wrw_buffer_fetch.txt.
+template <int S, int PF, bool AFF, bool BUF = false>
 __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ part, W3GenGeom g, const float* __restrict__ in_ab) {
   typedef W3S<S> P;
@@ -367,10 +375,54 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
 
   uint4 rd[W3_TH];
   uint4 rx[P::XU];
+  // BUF: tile-independent byte offsets of this thread's chunks (relative to the tile's first dy pixel / patch pixel (0, 0))
+  uint32_t dyo[BUF ? W3_TH : 1], xo32[BUF ? P::XU : 1];
+  if (BUF) {
+#pragma unroll
+    for (int u = 0; u < W3_TH; ++u) dyo[BUF ? u : 0] = (uint32_t)((((int64_t)u * g.W + spix) * g.Cout + spart * 8) * 2);
+#pragma unroll
+    for (int u = 0; u < P::XU; ++u)
+      xo32[BUF ? u : 0] = (uint32_t)((((int64_t)(xr[u] < 0 ? 0 : xr[u]) * g.Win + xc[u]) * g.Cin + spart * 8) * 2);
+  }
+  // BUF: the fetched tiles are slot, slot + bpp, ...: their (image, tile row, tile column) advance by constant steps with
+  // carries instead of three integer divisions per tile (~60 scalar instructions of the fetch)
+  int ftw = 0, fth = 0, fb = 0;
+  const int dtw = g.bpp % g.tiles_w, dth = (g.bpp / g.tiles_w) % g.tiles_h, db = g.bpp / (g.tiles_w * g.tiles_h);
+  if (BUF) { ftw = slot % g.tiles_w; fth = (slot / g.tiles_w) % g.tiles_h; fb = slot / (g.tiles_w * g.tiles_h); }
   auto fetch = [&](int tile) {
-    const int ow0 = (tile % g.tiles_w) * W3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
-    const int b = tile / (g.tiles_w * g.tiles_h);
+    const int ow0 = BUF ? ftw * W3_TW : (tile % g.tiles_w) * W3_TW;
+    const int oh0 = BUF ? fth * W3_TH : ((tile / g.tiles_w) % g.tiles_h) * W3_TH;
+    const int b = BUF ? fb : tile / (g.tiles_w * g.tiles_h);
     const int64_t pix = ((int64_t)b * g.H + oh0) * g.W + ow0;
+    if (BUF) {
+      constexpr uint32_t kOob = 0x80000000u;             // >= num_records: the buffer unit returns zeros
+      const int ih0 = S * oh0 - 1, iw0 = S * ow0 - 1;
+      const bf16_t* dbase = dy + pix * g.Cout + oc0;     // uniform: descriptor bases of this tile
+      const bf16_t* xbase = x + (((int64_t)b * g.Hin + ih0) * g.Win + iw0) * g.Cin + ci0;
+      const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, 0x7fffffff, 0x00020000);
+      const bool live = tile < g.ntiles;                 // beyond the block's last tile every lane is out of bounds: no access
+      const bool colok = live && ow0 + spix < g.W;
+#pragma unroll
+      for (int u = 0; u < W3_TH; ++u) {
+        const uint32_t off = (colok && oh0 + u < g.H) ? dyo[BUF ? u : 0] : kOob;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rd_, (int)off, 0, 0);
+        rd[u] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+#pragma unroll
+      for (int u = 0; u < P::XU; ++u) {
+        // 0 <= ih0 + xr < Hin and 0 <= iw0 + xc < Win as two unsigned compares (xr = -1 marks a thread beyond the patch)
+        const bool ok = live && (uint32_t)(ih0 + xr[u]) < (uint32_t)g.Hin && (uint32_t)(iw0 + xc[u]) < (uint32_t)g.Win && xr[u] >= 0;
+        const uint32_t off = ok ? xo32[BUF ? u : 0] : kOob;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx_, (int)off, 0, 0);
+        rx[u] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+      // the next tile of this block
+      ftw += dtw; if (ftw >= g.tiles_w) { ftw -= g.tiles_w; ++fth; }
+      fth += dth; if (fth >= g.tiles_h) { fth -= g.tiles_h; ++fb; }
+      fb += db;
+      return;
+    }
     const bf16_t* dt = dy + (pix + spix) * g.Cout + oc0 + spart * 8;
 #pragma unroll
     for (int u = 0; u < W3_TH; ++u)
@@ -501,7 +553,9 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
       __syncthreads();
       stage(rd, rx, tile, false);
       __syncthreads();
-      if (PF == 1 && tile + g.bpp < g.ntiles) fetch(tile + g.bpp);
+      // BUF: issued unconditionally (beyond the last tile all of its lanes are out of bounds), so that the fetch and the
+      // MFMAs are ONE basic block and the scheduler may issue the scalar / address work in the shadow of the MFMAs
+      if (PF == 1 && (BUF || tile + g.bpp < g.ntiles)) fetch(tile + g.bpp);
       mfma_tile();
     }
   }
@@ -701,13 +755,18 @@ static int conv3_wrw_gen_common(const void* x, const float* in_ab, const void* d
   if (ws_bytes < tsg_conv3x3_wrw_gen_ws_bytes(B, Hin, Win, Cin, Cout, stride)) return TSG_E_WS;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-#define W3_GO(SS, PFF, AF)                                                                                        \
+  // raw buffer loads in the fetch (see the kernel's comment) unless TSG_CONV_WRW_BUF=0 or a thread's offsets inside a
+  // tile could reach the 2 GB the descriptor covers (the base is per tile, so this takes a row of > 10^8 elements)
+  static const bool buf_env = [] { const char* e = getenv("TSG_CONV_WRW_BUF"); return !(e && e[0] == '0'); }();
+  const bool buf = buf_env && (int64_t)(3 * stride + 4) * Win * Cin * 2 < 0x40000000LL && (int64_t)5 * g.W * Cout * 2 < 0x40000000LL;
+#define W3_GO2(SS, PFF, AF, BF)                                                                                   \
   do {                                                                                                            \
-    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF>),                     \
+    TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wrw_gen_k<SS, PFF, AF, BF>),                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3S<SS>::LDS));                  \
-    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,       \
+    hipLaunchKernelGGL((conv3_wrw_gen_k<SS, PFF, AF, BF>), dim3(g.npairs * g.bpp), dim3(256), W3S<SS>::LDS, st,   \
                        (const bf16_t*)x, (const bf16_t*)dy, (float*)ws, g, in_ab);                                \
   } while (0)
+#define W3_GO(SS, PFF, AF) do { if (buf && PFF != 2) W3_GO2(SS, (PFF == 2 ? 1 : PFF), AF, true); else W3_GO2(SS, PFF, AF, false); } while (0)
   // stride 2 stays on PF = 1: two sets of its 23 loads do not fit the register file (the build spilled 72-84 VGPRs,
   // and a spilled register of an in-flight load is garbage)
   if (stride == 1 && w3_pf2()) { if (in_ab) W3_GO(1, 2, true); else W3_GO(1, 2, false); }
@@ -715,6 +774,7 @@ static int conv3_wrw_gen_common(const void* x, const float* in_ab, const void* d
   else if (stride == 1) { if (in_ab) W3_GO(1, 1, true); else W3_GO(1, 1, false); }
   else { if (in_ab) W3_GO(2, 1, true); else W3_GO(2, 1, false); }
 #undef W3_GO
+#undef W3_GO2
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
   TSG_CHECK_LAUNCH();
