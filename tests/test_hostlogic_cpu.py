@@ -107,3 +107,32 @@ def test_native_builders_defer_only_hip_logits_and_shadows_refuse_cpu_parameters
     assert torch.equal(up, nn.functional.interpolate(z, scale_factor=8, mode="bilinear", align_corners=True))
     with pytest.raises(TsgError):
         _Bank().register(nn.Parameter(torch.randn(64, 64, 3, 3)), want_rot=True)
+
+
+def test_wrw_tile_coordinates_advance_with_carries():
+    """conv3wrw.hip (BUF fetch): a block's tiles are slot, slot + bpp, ...; the kernel keeps (tile column, tile row,
+    image) and adds the constant step (bpp % tiles_w, (bpp / tiles_w) % tiles_h, bpp / (tiles_w tiles_h)) with one carry
+    per digit instead of dividing per tile.  Same arithmetic here against the divisions, over random geometries
+    (bpp as w3gen_geom makes it: <= ntiles, rounded up to a multiple of 8)."""
+    import random
+    rnd = random.Random(3)
+    for _ in range(3000):
+        tw, th, B = rnd.randint(1, 40), rnd.randint(1, 300), rnd.randint(1, 16)
+        ntiles = B * tw * th
+        npairs = rnd.choice([1, 2, 4, 8, 16, 64])
+        bpp = (rnd.choice([256, 512]) + npairs - 1) // npairs
+        bpp = (max(1, min(bpp, ntiles)) + 7) // 8 * 8
+        slot = rnd.randrange(bpp)
+        dtw, dth, db = bpp % tw, (bpp // tw) % th, bpp // (tw * th)
+        ftw, fth, fb = slot % tw, (slot // tw) % th, slot // (tw * th)
+        t = slot
+        for _ in range(24):
+            assert (ftw, fth, fb) == (t % tw, (t // tw) % th, t // (tw * th))
+            ftw += dtw
+            if ftw >= tw:
+                ftw -= tw; fth += 1
+            fth += dth
+            if fth >= th:
+                fth -= th; fb += 1
+            fb += db
+            t += bpp
