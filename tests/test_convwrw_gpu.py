@@ -175,3 +175,20 @@ def test_dgrad_through_forward_convolution_matches_oracle(cuda):
     rel = ((dx.double().cpu() - xz.grad).norm() / xz.grad.norm()).item()
     assert rel <= 5e-3, rel                                            # bf16 output rounding
     assert convwrw._DGRAD_FWD
+
+
+def test_buffer_fetch_is_bit_equal_to_pointer_fetch(cuda, tmp_path):
+    """conv3_wrw_gen_k fetches its operands by raw buffer loads (default) or by predicated pointer loads
+    (TSG_CONV_WRW_BUF=0; read once per process, hence two subprocesses).  Only the addressing differs, so the fp32
+    results must be identical bit for bit — bench layers, ragged sizes, stride 2, BN-on-load (tools/ab_wrw_buf.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for buf in ("0", "1"):
+        env = dict(os.environ, TSG_CONV_WRW_BUF=buf, TSG_AB_DIR=str(tmp_path))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_wrw_buf.py")], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[buf] = r.stdout
+    assert "RESULT OK" in out["1"], out["1"]
+    assert out["1"].count("bit-equal") == out["0"].count("saved") >= 7, out["1"]

@@ -27,10 +27,11 @@ for name, B, Cin, Cout, H, W, s, aff in CASES:
         kp.conv3x3_wrw(x, dy, variant="gen", stride=s, in_ab=ab)
     en.record(); torch.cuda.synchronize()
     us = st.elapsed_time(en) / 10 * 1e3
-    f = "/tmp/ab_wrw_%s.pt" % name.split()[0].replace("/", "_") + str(Cin) + str(Cout) + str(H)
+    f = os.path.join(os.environ.get("TSG_AB_DIR", "/tmp"), "ab_wrw_%s_%d_%d_%d_%d.pt" % (name.split()[0].replace("/", "_"), Cin, Cout, H, s))
     if buf == "0":
         torch.save(dw.cpu(), f); msg = "saved"
     else:
         ref = torch.load(f); same = torch.equal(dw.cpu(), ref); ok &= same; msg = "bit-equal" if same else "DIFFERENT max|d| %.3e" % (dw.cpu() - ref).abs().max().item()
     print("BUF=%s %-28s %8.1f us  %s" % (buf, name, us, msg), flush=True)
 print("RESULT", "OK" if ok else "MISMATCH")
+sys.exit(0 if ok else 1)
