@@ -1,5 +1,6 @@
 #!/bin/bash
 # conv3 weight gradient: x fragments shared between tile rows (TSG_WRW_SHARE=1) against one fragment per MFMA (=0):
+# (historical: the TSG_WRW_SHARE switch this script toggles was removed after the comparison; kept as the record of how profiles/r03_conv3wrw_shared_fragments.txt was made)
 # parity, headline bench A/B on one box, per-kernel times
 cd "$(dirname "$0")/.." || exit 1
 O=$PWD/gpurun_out/r3o; mkdir -p $O
