@@ -136,3 +136,48 @@ def test_wrw_tile_coordinates_advance_with_carries():
                 fth -= th; fb += 1
             fb += db
             t += bpp
+
+
+def test_wrw_buffer_fetch_addresses_equal_pointer_fetch():
+    """conv3wrw.hip: the buffer-load fetch (descriptor base per tile + a thread's constant 32-bit byte offsets, invalid
+    positions out of bounds) against the pointer fetch (full address per load, predicated), restated in Python over
+    random geometries, tiles and threads: same validity, same byte address, offsets below the 2 GB the descriptor covers
+    (the unsigned-compare form of the halo predicate included)."""
+    import random
+    rnd = random.Random(5)
+    TH, TW = 4, 32
+    checked = 0
+    for _ in range(600):
+        S = rnd.choice([1, 2]); B = rnd.randint(1, 4); Hin = rnd.randint(1, 70); Win = rnd.randint(1, 140)
+        Cin, Cout = 64 * rnd.randint(1, 4), 64 * rnd.randint(1, 4)
+        H, W = (Hin - 1) // S + 1, (Win - 1) // S + 1
+        th, tw = (H + TH - 1) // TH, (W + TW - 1) // TW
+        PR, PC = S * TH + 3 - S, S * TW + 3 - S
+        NPX = PR * PC; XU = (NPX * 8 + 255) // 256
+        oc0, ci0 = 64 * rnd.randrange(Cout // 64), 64 * rnd.randrange(Cin // 64)
+        for _ in range(6):
+            tile = rnd.randrange(B * th * tw); tid = rnd.randrange(256); spart, spix = tid & 7, tid >> 3
+            ow0, oh0, b = (tile % tw) * TW, ((tile // tw) % th) * TH, tile // (tw * th)
+            pix = (b * H + oh0) * W + ow0
+            for u in range(TH):
+                ok = oh0 + u < H and ow0 + spix < W
+                if ok:
+                    ptr = (pix + spix) * Cout + oc0 + spart * 8 + u * W * Cout
+                    assert 2 * ptr == 2 * (pix * Cout + oc0) + ((u * W + spix) * Cout + spart * 8) * 2
+                    assert 0 <= ptr and ptr + 8 <= B * H * W * Cout
+                    checked += 1
+            ih0, iw0 = S * oh0 - 1, S * ow0 - 1
+            xbase = ((b * Hin + ih0) * Win + iw0) * Cin + ci0
+            for u in range(XU):
+                pp = spix + 32 * u
+                xr, xc = (pp // PC if pp < NPX else -1), pp % PC
+                ok_ptr = xr >= 0 and 0 <= ih0 + xr < Hin and 0 <= iw0 + xc < Win
+                ok_buf = ((ih0 + xr) & 0xffffffff) < Hin and ((iw0 + xc) & 0xffffffff) < Win and xr >= 0
+                assert ok_ptr == ok_buf
+                if ok_ptr:
+                    ptr = xbase + spart * 8 + (xr * Win + xc) * Cin
+                    off = ((xr * Win + xc) * Cin + spart * 8) * 2
+                    assert 2 * ptr == 2 * xbase + off and off < 0x80000000
+                    assert 0 <= ptr and ptr + 8 <= B * Hin * Win * Cin
+                    checked += 1
+    assert checked > 10000
