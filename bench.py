@@ -14,8 +14,10 @@ not legal).  Same JSON schema for every config.
 A step = zero_grad -> loss = model(imgs, gts) -> backward (incl. bucketed RCCL
 gradient all-reduce) -> SGD step, i.e. the body of the reference's loop
 (model/bisenet/cityscapes.bisenet.R18/train.py:115-142) without its tqdm/.item()
-display.  Inputs are resident in HBM before the timed region.  Weak scaling:
-every rank keeps batch 16.  Rank 0 prints ONE JSON line.
+display.  Inputs are resident in HBM before the timed region.  --scaling weak
+(default): every rank keeps batch 16.  --scaling strong: the reference's own setting, a
+GLOBAL batch of 16 split over the ranks (dataloader.py:51-53 batch_size // world_size,
+min_kept scaled with it, train.py:48-49).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import contextlib
@@ -279,6 +281,75 @@ def ohem_kth_branch_probe(device, batch, size, reps=5):
     return out
 
 
+def ohem_kth_branch_oracle(device, batch, size):
+    """The oracle's selection (oracle.ohem_ref = loss_opr.py:68-98 on the host) on the SAME trained-like head input the
+    probe above times: threshold / kept / loss to print beside the device's.  ~15 s of host time at 16 x 19 x 1024^2."""
+    import torch.nn.functional as F
+    from oracle import ohem_ref
+    g = torch.Generator(device=device).manual_seed(1)
+    low = size // 8
+    cells = max(low // 64, 1)
+    lab_low = torch.randint(0, NUM_CLASSES, (batch, cells, cells), generator=g, device=device)
+    lab_low = lab_low.repeat_interleave(low // cells, 1).repeat_interleave(low // cells, 2)
+    target = lab_low.repeat_interleave(8, 1).repeat_interleave(8, 2)
+    redraw = torch.rand(batch, low, low, generator=g, device=device) < 0.01
+    lab2 = torch.where(redraw, torch.randint(0, NUM_CLASSES, (batch, low, low), generator=g, device=device), lab_low)
+    z_tr = (8.0 * F.one_hot(lab2, NUM_CLASSES).permute(0, 3, 1, 2).float()
+            + torch.randn(batch, NUM_CLASSES, low, low, generator=g, device=device)).to(torch.bfloat16)
+    target[:, :8] = 255
+    with torch.no_grad():
+        logits = F.interpolate(z_tr.float().cpu(), size=(size, size), mode="bilinear", align_corners=True)
+        loss, info = ohem_ref.ohem_cross_entropy(logits, target.cpu(), 255, 0.7, batch * size * size // 16, None,
+                                                 return_info=True)
+    return {"threshold": round(float(info["threshold"]), 6), "kept": int(info["n_kept"]), "valid": int(info["num_valid"]),
+            "kth_branch_taken": bool(info["branch"] == 1), "loss": round(float(loss), 5)}
+
+
+def psa_probe(device, reps=10, with_oracle=True):
+    """SURVEY 8 row a9 in front of the driver: one collect (or distribute) attention of PSANet-R101 at BASELINE configs[4]'s
+    per-rank size — out = X @ softmax(A, dim=1), X [2, 512, 3600], A [2, 3600, 3600], bf16 (psanet network.py:119-137) —
+    forward and backward (dX, dA) through the C-ABI, HIP-event timed on the launch stream; flops 2 B Cx K N forward, twice
+    that backward; `frac` against the 2.5 PF dense bf16 MFMA peak.  With the oracle importable the forward is also checked
+    against oracle.psa_ref on the host (the same bf16-rounded operands, fp32 softmax + bmm)."""
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cx, Lk = 2, 512, 3600
+    g = torch.Generator(device=device).manual_seed(2)
+    X = torch.relu(torch.randn(B, Cx, Lk, device=device, generator=g)).to(torch.bfloat16)
+    A = torch.randn(B, Lk, Lk, device=device, generator=g).to(torch.bfloat16)
+    dout = torch.randn(B, Cx, Lk, device=device, generator=g).to(torch.bfloat16)
+    out, lse = kp.psa_fwd(X, A)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+
+    t_f = timed(lambda: kp.psa_fwd(X, A))
+    t_b = timed(lambda: kp.psa_bwd(X, A, out, dout, lse))
+    flop = 2.0 * B * Cx * Lk * Lk
+    rec = {"shape": f"X [{B}, {Cx}, {Lk}] x softmax(A [{B}, {Lk}, {Lk}], dim=1), bf16", "fwd_us": round(t_f, 1),
+           "bwd_us": round(t_b, 1), "fwd_TFLOPs": round(flop / t_f / 1e6, 1), "bwd_TFLOPs": round(2 * flop / t_b / 1e6, 1),
+           "peak_TFLOPs": 2500.0, "fwd_frac": round(flop / t_f / 1e6 / 2500.0, 4),
+           "bwd_frac": round(2 * flop / t_b / 1e6 / 2500.0, 4)}
+    if with_oracle:
+        try:
+            from oracle import psa_ref
+            want = psa_ref.psa_attention(X[:1].float().cpu(), A[:1].float().cpu())
+            got = out[:1].float().cpu()
+            rec["fwd_max_err_vs_oracle"] = float(((got - want).abs().max() / want.abs().max()).item())
+        except ImportError:
+            pass
+    return rec
+
+
 def cpu_baseline(headline=True):
     """The oracle (CPU port of the reference path: the reference's BiSeNet-R18 architecture with plain
     nn.BatchNorm2d + the loss_opr.py restatement + torch.optim.SGD, fp32) timed on this host's cores.  Bounded
@@ -328,9 +399,9 @@ def self_launch(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def launch_check(world, rank):
+def launch_check(world, rank, args=None):
     """--launch-check: rendezvous only (gloo when there is no GPU), so that the launcher logic is testable on a CPU
-    box: every rank joins, the world size is all-reduced, rank 0 prints it."""
+    box: every rank joins, the world size is all-reduced, rank 0 prints it (and the batch split --scaling implies)."""
     backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -342,7 +413,11 @@ def launch_check(world, rank):
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"launch_check": ok, "n_gpus": n, "backend": backend}), flush=True)
+        rec = {"launch_check": ok, "n_gpus": n, "backend": backend}
+        if args is not None:
+            rec.update({"scaling": args.scaling, "per_rank_batch": args.batch, "global_batch": args.batch * n,
+                        "min_kept": int(args.batch * args.size * args.size // 16)})
+        print(json.dumps(rec), flush=True)
     return 0 if ok else 1
 
 
@@ -359,6 +434,13 @@ def main():
                     help="label dtype on the device: u8 (what the GPU loader emits; default for the ignore-255 families) "
                          "or i64 (what the reference's DataLoader hands over)")
     ap.add_argument("--no-ohem-probe", action="store_true", help="skip the k-th-branch head record (bisenet only)")
+    ap.add_argument("--no-psa-probe", action="store_true", help="skip the PSA attention record (SURVEY 8 row a9)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's batch on EVERY rank (default); strong: the config's batch is the GLOBAL batch, "
+                         "split over the ranks as the reference does (dataloader.py:51-53; min_kept follows, train.py:48-49)")
+    ap.add_argument("--i64-steps", type=int, default=10,
+                    help="after the timed region, time this many extra steps with int64 labels (what the reference's "
+                         "DataLoader hands over) and report them beside the uint8 default; 0 = skip")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-headline", type=int, default=1,
@@ -389,8 +471,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.scaling == "strong":
+        if args.batch % world or args.batch // world < 2:
+            sys.exit(f"bench.py: --scaling strong needs the global batch {args.batch} to split into >= 2 images on each of "
+                     f"{world} ranks (the global-context BatchNorm sees [B, 128, 1, 1])")
+        args.batch //= world                                           # dataloader.py:51-53
     if args.launch_check:
-        sys.exit(launch_check(world, rank))
+        sys.exit(launch_check(world, rank, args))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's banner off stdout (one JSON line contract)
@@ -495,6 +582,26 @@ def main():
     elif dominant is not None:
         timer = roof_probe
     final_loss = float(loss.item())
+    # The reference's DataLoader hands the criterion int64 labels; the GPU loader of this package emits uint8 (the default
+    # here, disclosed as config.labels).  A few extra steps with int64 labels, outside the timed region, put the other
+    # figure beside it (the label width must be visibly neutral).
+    i64_rec = None
+    if args.i64_steps > 0 and args.labels == "u8" and not use_graph:
+        b64 = tuple(t.to(torch.int64) if t.dtype == torch.uint8 else t for t in batch)
+        for it in range(2):
+            train_step(model, opt, b64, pol, args.warmup + args.steps + it, world)
+        sync()
+        t1 = time.perf_counter()
+        for it in range(args.i64_steps):
+            train_step(model, opt, b64, pol, args.warmup + args.steps + 2 + it, world)
+        sync()
+        d64 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(d64, op=dist.ReduceOp.MAX)
+        i64_rec = {"value": round(args.batch * world * args.i64_steps / float(d64.item()), 2), "unit": "img/s",
+                   "steps": args.i64_steps, "ms_per_step": round(float(d64.item()) / args.i64_steps * 1e3, 3),
+                   "note": "same step with int64 labels (what the reference's DataLoader hands over), timed after the "
+                           "uint8 region"}
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -511,15 +618,15 @@ def main():
                       else f"training images/sec ({args.size}x{args.size}) {cfg['model']}",
             "value": round(value, 2), "unit": "img/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['model']} {args.dtype} batch {args.batch}/GPU {args.size}x{args.size} synthetic crops, "
                                    + {"bisenet": "SyncBN + OHEM", "pspnet": "SyncBN, 150 classes, 2 CE heads",
                                       "dfn": "SyncBN, 4 CE + 4 sigmoid-focal heads",
                                       "psanet": "SyncBN, 150 classes, collect/distribute attention (MFMA)"}[args.config]
                                    + f" (BASELINE configs[{cfg['idx']}], per-rank shape; {cfg['ref']})",
-                       "labels": args.labels,
-                       "global_batch": global_batch, "parallelism": f"dp{world}",
+                       "labels": args.labels, "labels_i64": i64_rec,
+                       "global_batch": global_batch, "per_rank_batch": args.batch, "parallelism": f"dp{world}",
                        "channels_last": model.channels_last, "final_loss": round(final_loss, 4),
                        "hip_graph": bool(use_graph), "optimizer": args.optimizer},
         }
@@ -538,6 +645,13 @@ def main():
                                     "frac": round(per_gpu * gb_per_img / HBM_PEAK_GBS, 4), "target_frac": 0.70}
         if args.config == "bisenet" and world == 1 and not args.no_ohem_probe and args.dtype == "bf16":
             out["ohem_kth_branch"] = ohem_kth_branch_probe(device, args.batch, args.size)
+            if not args.no_cpu_baseline:                   # the checker beside the device's selection (host time ~15 s)
+                try:
+                    out["ohem_kth_branch"]["trained_like"]["oracle"] = ohem_kth_branch_oracle(device, args.batch, args.size)
+                except ImportError:
+                    pass
+        if world == 1 and not args.no_psa_probe and args.dtype == "bf16":
+            out["psa_probe"] = psa_probe(device, with_oracle=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(headline=bool(args.cpu_headline)) if args.config == "bisenet" \
                 else cpu_baseline_family(args.config)

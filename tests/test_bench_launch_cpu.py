@@ -21,7 +21,21 @@ def test_plain_python_gpus2_self_launches_two_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = [l for l in r.stdout.splitlines() if l.strip()][-1]
     out = json.loads(last)
-    assert out == {"launch_check": True, "n_gpus": 2, "backend": "gloo"}
+    assert out == {"launch_check": True, "n_gpus": 2, "backend": "gloo", "scaling": "weak", "per_rank_batch": 16,
+                   "global_batch": 32, "min_kept": 16 * 1024 * 1024 // 16}
+
+
+def test_strong_scaling_splits_the_global_batch_like_the_reference():
+    """--scaling strong: the reference's setting (bisenet dataloader.py:51-53 batch_size // world_size; train.py:48-49
+    min_kept from the per-rank batch): global 16 -> 8 per rank at 2 ranks, min_kept 8 * 1024^2 / 16; a split that leaves a
+    rank fewer than 2 images is refused."""
+    r = _run(["--gpus", "2", "--launch-check", "--scaling", "strong"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["scaling"] == "strong" and out["per_rank_batch"] == 8 and out["global_batch"] == 16
+    assert out["min_kept"] == 8 * 1024 * 1024 // 16
+    r = _run(["--gpus", "1", "--launch-check", "--scaling", "strong", "--batch", "1"])
+    assert r.returncode != 0 and "strong" in r.stderr
 
 
 def test_world_size_mismatch_is_refused():

@@ -194,3 +194,56 @@ def test_skip_connection_gradient_joins_the_data_gradient_in_the_epilogue(cuda, 
         res[fused] = [out.detach().float().cpu(), xin.grad.float().cpu()] + [p.grad.float().cpu() for p in blk.parameters()]
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The five geometries bench.py times, at its batch: 16 x {128 @ 128^2 (layer2, refine), 256 @ 64^2
+# (layer3), 512 @ 32^2 (layer4), 128 -> 256 @ 128^2 (head conv_3x3), 256 -> 64 @ 128^2}: furnace/base_model/resnet.py:24-29,
+# bisenet network.py:104-106,140-156.  These run the persistent tile loop (2048 / 512 / 128 pixel tiles over 512 / 256
+# blocks), the XCD block map and the LDS-DMA filter path at the tile counts of the step.  Every launch form of the step:
+# forward with the statistics epilogue, the mode-1 filter (= data gradient) without and with `addend` — each against
+# oracle/conv_ref.py (fp64) on two images from the middle of the batch (bf16-ulp bound) and against the vendor library's
+# convolution on the whole batch.
+BENCH_GEOMS = [(16, 128, 128, 128), (16, 256, 256, 64), (16, 512, 512, 32), (16, 128, 256, 128), (16, 256, 64, 128)]
+
+
+def _vs_library(y, y_lib):
+    """Both are bf16 roundings of fp32 accumulations of the same products in different orders."""
+    a, b = y.float(), y_lib.float()
+    bound = b.abs() * 2.0 ** -6 + 2e-3 * b.abs().max()
+    assert bool(((a - b).abs() <= bound).all()), ((a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("geom", BENCH_GEOMS)
+def test_bench_geometry_forward_stats_dgrad_addend(cuda, geom):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, S = geom
+    g = torch.Generator(device=cuda).manual_seed(Cin + Cout + S)
+    x = torch.randn(B, Cin, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g, device=cuda) * (2.0 / (9 * Cin)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, Cout, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(B, Cin, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    wb = w.bfloat16()
+    sl = slice(7, 9)                                        # two images from the middle of the persistent loop
+    wr = conv_ref.bf16_round(w.cpu())
+    # ---- forward + statistics epilogue
+    wf = kp.conv3x3_gen_prep_filter(w, 0, x)
+    y, partial = kp.conv3x3_gen_fwd(x, wf, Cout, with_stats=True)
+    assert torch.equal(y, kp.conv3x3_gen_fwd(x, wf, Cout))                        # the epilogue changes nothing; run-to-run equal
+    _check(y[sl], conv_ref.conv2d_ref(x[sl].double().cpu(), wr, stride=1, pad=1))
+    _vs_library(y, F.conv2d(x, wb, None, 1, 1))
+    yf = y.double()
+    ref_stats = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).cpu()
+    np.testing.assert_allclose(partial.double().sum(0).cpu().numpy(), ref_stats.numpy(), rtol=2e-5, atol=2e-2)
+    # ---- data gradient (mode-1 filter), without and with the skip-connection addend
+    wf1 = kp.conv3x3_gen_prep_filter(w, 1, dy)
+    dx = kp.conv3x3_gen_fwd(dy, wf1, Cin)
+    xr = torch.zeros(2, Cin, S, S, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, None, 1, 1).backward(dy[sl].double().cpu())
+    _check(dx[sl], xr.grad)
+    lib = torch.ops.aten.convolution_backward(dy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                              [True, False, False])[0]
+    _vs_library(dx, lib)
+    dxa = kp.conv3x3_gen_fwd(dy, wf1, Cin, addend=skip)
+    assert torch.equal(dxa, dx + skip)                      # bf16(bf16(conv) + addend): what the eager add computes

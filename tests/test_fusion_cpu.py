@@ -141,13 +141,49 @@ def test_iadd_interpolate_positional_arguments_and_late_modification(standin):
         out = F.interpolate(fm, (8, 8), None, 'bilinear', True)
     assert standin.calls == ["upsample_presum_fwd"]
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
-    with FuseMode():
+    from torchseg_amd import fusion
+    before = dict(fusion.stats)
+    with FuseMode():                                   # legal eager code must compute, not raise
         fm = a0.clone().requires_grad_(True) * 2.0
         last = b0.clone()
         fm += last
-        last.mul_(0.0)                                 # the eager program would already have consumed `last`
+        last.mul_(0.0)                                 # the eager program had already consumed `last`: the add happens first
+        out = F.interpolate(fm, size=(8, 8), mode='bilinear', align_corners=True)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(last, torch.zeros_like(last))
+    assert fusion.stats["materialized_before_mutation"] == before["materialized_before_mutation"] + 1
+    with FuseMode():                                   # same for the left operand and for out= / indexed writes
+        fm = a0.clone().requires_grad_(True) * 2.0
+        last = b0.clone()
+        fm += last
+        last[0, 0] = 7.0
+        out = F.interpolate(fm, size=(8, 8), mode='bilinear', align_corners=True)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    with FuseMode():                                   # a change behind the mode's back is still caught, loudly
+        fm = a0.clone().requires_grad_(True) * 2.0
+        last = b0.clone()
+        fm += last
+        with torch._C.DisableTorchFunction():
+            last.mul_(0.0)
         with pytest.raises(RuntimeError, match="modified in place"):
             F.interpolate(fm, size=(8, 8), mode='bilinear', align_corners=True)
+
+
+def test_the_fused_iadd_path_is_taken_on_this_interpreter(standin):
+    """the deferral depends on a reference-count calibration and a bytecode check and turns itself off
+    silently when either fails.  On the interpreter this suite runs on it must be ON, and the counters must say so."""
+    from torchseg_amd import fusion
+    from torchseg_amd.fusion import DeferredSum, FuseMode
+    assert fusion._IADD_BASE_REFS > 0
+    before = dict(fusion.stats)
+    with FuseMode():
+        fm = torch.ones(1, 8, 4, 4, requires_grad=True) * 2.0
+        fm += torch.ones(1, 8, 4, 4)
+        assert isinstance(fm, DeferredSum)
+        F.interpolate(fm, size=(8, 8), mode='bilinear', align_corners=True)
+    assert fusion.stats["iadd_deferred"] == before["iadd_deferred"] + 1
+    assert fusion.stats["presum_fused"] == before["presum_fused"] + 1
+    assert standin.calls == ["upsample_presum_fwd"]
 
 
 def test_bad_labels_are_reported_not_indexed(standin, monkeypatch):

@@ -145,8 +145,27 @@ def get_extra(group=None, tag="extra", like=None):
 
 
 def shutdown():
-    """Destroy every communicator.  Explicit, not an atexit hook: ncclCommDestroy has to run BEFORE
-    dist.destroy_process_group() and before the HIP runtime is torn down (Engine.__exit__ and bench.py call it)."""
+    """Destroy every communicator.  ncclCommDestroy has to run BEFORE dist.destroy_process_group() and before the HIP
+    runtime is torn down: Engine.__exit__ and bench.py call this explicitly; `_atexit_shutdown` is the guarded fallback
+    for every other entry point that wrapped a model (eval scripts, user code)."""
     for c in list(_comms.values()):
         c.destroy()
     _comms.clear()
+
+
+def _atexit_shutdown():
+    """Fallback for entry points that never call shutdown(): runs at interpreter exit (before the HIP runtime's static
+    destructors) and only while the process group that carried the unique id still exists — if the caller already
+    destroyed it, the ordering the docstring above warns about can no longer be kept, and the communicators are left to
+    process teardown exactly as before."""
+    if not _comms:
+        return
+    try:
+        if dist.is_available() and dist.is_initialized():
+            shutdown()
+    except Exception:                                      # never turn a clean exit into a failing one
+        pass
+
+
+import atexit as _atexit  # noqa: E402
+_atexit.register(_atexit_shutdown)

@@ -271,13 +271,18 @@ __global__ __launch_bounds__(kT) void ohem_pass_a(
 // "selection tail" of the k-th-value branch; bench.py's ohem_kth_branch record).  Every lane sums 8 consecutive bins, a
 // wave scan locates the lane whose run crosses the rank, that lane walks its 8 bins.  Integers only: the result is the
 // one the serial walk gives.
-__device__ void scan_hist(const uint32_t* hist, int bins, int shift, SelState* st) {
+// State hand-over (round 4): the rank and the running prefix come in as REGISTER values of lane 0 and are
+// broadcast by shuffles; the crossing lane's results go back to lane 0 by ballot + shuffle, and lane 0 alone writes `st`.
+// No lane reads or read-modify-writes global memory another lane wrote a moment earlier (the round-3 version relied on
+// the compiler not forwarding non-atomic accesses to a __restrict__ pointer across a fence).  Returns the new prefix
+// (valid on lane 0).
+__device__ int64_t scan_hist(const uint32_t* hist, int bins, int shift, int64_t krem_lane0, int64_t lo_lane0, SelState* st) {
   constexpr int CH = 8;
   const int lane = threadIdx.x & 63;
-  int64_t r = lane == 0 ? st->krem : 0;                  // lane 0 may have written it a moment ago (ohem_decide0)
-  r = __shfl(r, 0, 64);
+  const int64_t r = __shfl(krem_lane0, 0, 64);
   int64_t cum = 0;
-  bool done = false;
+  bool done = false, mine = false;
+  int64_t my_krem = 0, my_add = 0;
   for (int base = 0; base < bins && !done; base += 64 * CH) {
     uint32_t h[CH];
     int64_t sum = 0;
@@ -291,7 +296,7 @@ __device__ void scan_hist(const uint32_t* hist, int bins, int shift, SelState* s
       if (lane >= o) incl += t;
     }
     const int64_t total = __shfl(incl, 63, 64);
-    if (cum + total >= r) {
+    if (cum + total >= r) {                              // wave-uniform: r, cum and total are
       const int64_t excl = incl - sum;
       if (cum + excl < r && cum + incl >= r) {          // exactly one lane: the first whose run reaches the rank
         int64_t c = cum + excl;
@@ -300,18 +305,31 @@ __device__ void scan_hist(const uint32_t* hist, int bins, int shift, SelState* s
           if (c + h[j] >= r) break;
           c += h[j];
         }
-        st->krem = r - c;
-        st->lo_d += (int64_t)(b0 + j) << shift;
+        mine = true;
+        my_krem = r - c;
+        my_add = (int64_t)(b0 + j) << shift;
       }
       done = true;
     } else {
       cum += total;
     }
   }
-  if (!done && lane == 0) {                              // cannot happen when counts are consistent
-    st->krem = r - cum;
-    st->lo_d += (int64_t)(bins - 1) << shift;
+  const unsigned long long who = __ballot(mine);
+  int64_t new_krem, add;
+  if (who) {
+    const int src = __ffsll((long long)who) - 1;
+    new_krem = __shfl(my_krem, src, 64);
+    add = __shfl(my_add, src, 64);
+  } else {                                               // cannot happen when counts are consistent
+    new_krem = r - cum;
+    add = (int64_t)(bins - 1) << shift;
   }
+  const int64_t lo = lo_lane0 + add;
+  if (lane == 0) {
+    st->krem = new_krem;
+    st->lo_d = lo;
+  }
+  return lo;
 }
 
 __global__ __launch_bounds__(kT) void ohem_decide0(
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(kT) void ohem_decide0(
   __syncthreads();
   if (threadIdx.x >= 64) return;                         // wave 0 stays: lane 0 decides, all 64 lanes walk the histogram
   int branch = 0;
+  int64_t krem0 = 0;                                     // rank inside hist0 (lane 0)
   if (threadIdx.x == 0) {
     a0 = a1 = a2 = a3 = 0; c0 = c1 = c2 = 0;
     for (int i = 0; i < kT / 64; ++i) {
@@ -368,16 +387,14 @@ __global__ __launch_bounds__(kT) void ohem_decide0(
       st->thr_bits = __float_as_uint(thresh);
     } else {
       branch = 1;
-      st->krem = k - cnt_le_all;
+      krem0 = k - cnt_le_all;
     }
     st->branch = branch;
-    __threadfence();                                     // krem / lo_d visible to the other lanes' loads below
   }
   branch = __shfl(branch, 0, 64);
   if (branch != 1) return;
-  scan_hist(hist0, bins0, shift0, st);
-  __threadfence();
-  if (threadIdx.x == 0 && levels == 1) st->thr_bits = (uint32_t)(st->lo_d + tb + 1);
+  const int64_t lo = scan_hist(hist0, bins0, shift0, krem0, 0, st);      // lane 0 writes st->krem / st->lo_d
+  if (threadIdx.x == 0 && levels == 1) st->thr_bits = (uint32_t)(lo + tb + 1);
 }
 
 // refinement level l >= 1: histogram of the sub-bin index of every element
@@ -411,9 +428,10 @@ __global__ __launch_bounds__(kT) void sel_refine(
 __global__ void sel_decide(const uint32_t* __restrict__ hist, int bins, int shift, int last,
                            int64_t tb, SelState* __restrict__ st) {
   if (threadIdx.x >= 64 || blockIdx.x != 0 || st->branch != 1) return;     // one wave walks the histogram
-  scan_hist(hist, bins, shift, st);
-  __threadfence();
-  if (threadIdx.x == 0 && last) st->thr_bits = (uint32_t)(st->lo_d + tb + 1);
+  // written by the previous kernel of this stream (ohem_decide0 / the previous level's sel_decide): plain loads
+  const int64_t krem = threadIdx.x == 0 ? st->krem : 0, lo0 = threadIdx.x == 0 ? st->lo_d : 0;
+  const int64_t lo = scan_hist(hist, bins, shift, krem, lo0, st);
+  if (threadIdx.x == 0 && last) st->thr_bits = (uint32_t)(lo + tb + 1);
 }
 
 // pass C: re-sum nll over valid & p <= thr (k-th value branch only)

@@ -23,7 +23,10 @@ MI355X design (instead of apex's flatten -> all_reduce -> unflatten copies):
     the SyncBN exchanges use on the compute stream: RCCL serialises launches of
     one communicator in issue order whatever their streams, and every rank issues
     the same program order (autograd hooks of one model), so there is no
-    cross-communicator ordering to get wrong.  The price is that a SyncBN
+    cross-communicator ordering to get wrong; the reference's 1-float loss
+    all-reduce (furnace/utils/pyt_utils.py all_reduce_tensor) and late "straggler"
+    gradients go through that communicator too, so it is the ONLY one in flight
+    during a step.  The price is that a SyncBN
     exchange issued while a bucket is on the wire waits for it (<= 0.25 ms per
     40 MB bucket at 8 GPUs).  TSG_DDP_COMM=separate gives the buckets their own
     communicator (full overlap; not validated on a multi-GPU node yet);
@@ -299,17 +302,26 @@ class Reducer(object):
             if bucket.work is None:
                 # incomplete (a planned param got no grad this pass; _gather zeroes the hole) or delayed
                 self._launch(bucket)
-        for p in self._stragglers:
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
-                p.grad.div_(self.world)
-        self._stragglers = []
         for bucket in self.buckets:
             if bucket.work is not True:
                 self._wait(bucket.work, bucket.flat.device)
             bucket.work = None
             bucket.pending = len(bucket.params)
             bucket.ready = [False] * len(bucket.params)
+        # parameters outside the plan that received a gradient after all: AFTER the buckets are fenced, and through the
+        # buckets' own communicator when there is one, so that no second communicator (the ProcessGroup's) is ever in
+        # flight beside it
+        for p in self._stragglers:
+            g = p.grad
+            comm = self._comm if (self._comm is not None and g.is_cuda and g.is_contiguous()
+                                  and g.dtype in (torch.float32, torch.bfloat16)) else None
+            if comm is not None:
+                comm.all_reduce(g.view(-1))
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                g.div_(self.world)
+        self._stragglers = []
 
 
 def _broadcast_coalesced(tensors, src, group):

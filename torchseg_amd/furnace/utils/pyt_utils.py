@@ -34,6 +34,18 @@ def reduce_tensor(tensor, dst=0, op=dist.ReduceOp.SUM, world_size=1):
 def all_reduce_tensor(tensor, op=dist.ReduceOp.SUM, world_size=1):
     """pyt_utils.py:34-39: mean over ranks of a copy of `tensor`."""
     out = tensor.detach().clone()
+    if out.is_cuda and op == dist.ReduceOp.SUM and out.dtype == torch.float32:
+        # the SAME RCCL communicator the SyncBN exchanges and the gradient buckets use, on the current stream: only one
+        # communicator is ever in flight (two — this one and the ProcessGroup's — issued concurrently from different
+        # streams are the classic cross-communicator deadlock; ADVICE r3)
+        from torchseg_amd import comm as _tsg_comm
+        c = _tsg_comm.get(None, like=out)
+        if c is not None:
+            flat = out.reshape(-1) if out.is_contiguous() else None
+            if flat is not None and flat.numel() > 0:
+                c.all_reduce(flat)
+                out.div_(world_size)
+                return out
     dist.all_reduce(out, op)
     out.div_(world_size)
     return out

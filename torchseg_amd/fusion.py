@@ -102,8 +102,11 @@ class DeferredSum(_Deferred):
     def materialize(self):
         if self._value is None:
             if not self.unchanged():
+                # FuseMode performs the pending add BEFORE any in-place operation it sees on either addend (eager
+                # semantics are kept for `fm += x; x.zero_(); use(fm)`); what reaches this line changed a tensor behind
+                # the mode's back (`.data`, a raw kernel), and the eager result can no longer be reconstructed
                 raise RuntimeError("torchseg_amd.fusion: a tensor of a pending `a += b` was modified in place before the "
-                                   "sum was used; set TSG_FUSE_ADD_UP=0 for this model")
+                                   "sum was used, outside the view of the fusion mode; set TSG_FUSE_ADD_UP=0 for this model")
             self._value = self.a.add_(self.b)
         return self._value
 
@@ -187,10 +190,33 @@ def _calibrate_iadd_refs():
     return seen[0] if seen else 0
 
 
+def _mutates(func, kwargs):
+    """An in-place torch function: `x.zero_()`, `x += y` / `x.add_(y)`, `x[i] = v`, or anything called with out=."""
+    name = getattr(func, "__name__", "") or ""
+    if kwargs and kwargs.get("out") is not None:
+        return True
+    if name.startswith("__") and name.endswith("__"):
+        return name == "__setitem__" or (name.startswith("__i") and name not in ("__index__", "__int__", "__invert__",
+                                                                                "__init__", "__iter__"))
+    return name.endswith("_")
+
+
+# What the `+=` deferral did, for logs and tests: it turns itself off silently whenever the interpreter does not behave
+# like the one it was calibrated on (reference counts of the augmented assignment, the BINARY_OP bytecode), so the
+# counts say whether the fused path is actually taken (ADVICE r3)
+stats = {"iadd_deferred": 0, "iadd_declined_alias": 0, "iadd_declined_not_augmented": 0, "presum_fused": 0,
+         "materialized_before_mutation": 0}
+
+
 _LOG_SOFTMAX_FUNCS = (F.log_softmax, torch.log_softmax, torch.Tensor.log_softmax)
 _IADD_FUNCS = (torch.Tensor.__iadd__, torch.Tensor.add_)
 _ADD_FUNCS = (torch.Tensor.__add__, torch.Tensor.__radd__, torch.Tensor.add, torch.add)
 _IADD_BASE_REFS = _calibrate_iadd_refs()
+if _IADD_BASE_REFS <= 0 or (_OP_INPLACE_ADD is None and _OP_BINARY is None):
+    import logging as _logging
+    _logging.getLogger(__name__).warning(
+        "torchseg_amd.fusion: the `+=` -> interpolate fusion is OFF on this interpreter (reference-count calibration %r, "
+        "no INPLACE_ADD / BINARY_OP opcode): `fm += x; F.interpolate(fm)` runs as two kernels", _IADD_BASE_REFS)
 
 
 def _ce_args(args, kwargs):
@@ -222,9 +248,31 @@ class FuseMode(TorchFunctionMode):
     def __init__(self, psa=False, loss=True, add_up=True, head=False):
         super().__init__()
         self.psa, self.loss, self.add_up, self.head = bool(psa), bool(loss), bool(add_up), bool(head)
+        self._pending = []           # weak references to DeferredSums that have not been used yet
+
+    def _settle_before_mutation(self, func, args, kwargs):
+        """The pending `a += b` happens NOW if `func` is about to change `a` or `b` in place: the eager program had
+        already consumed them at the `+=`."""
+        live = []
+        for ref in self._pending:
+            sm = ref()
+            if sm is None or sm._value is not None:
+                continue
+            live.append(ref)
+        self._pending = live
+        if not live or not _mutates(func, kwargs):
+            return
+        flat = list(args) + list(kwargs.values())
+        for ref in live:
+            sm = ref()
+            if sm is not None and any(t is sm.a or t is sm.b for t in flat):
+                sm.materialize()
+                stats["materialized_before_mutation"] += 1
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        if self.add_up and self._pending:
+            self._settle_before_mutation(func, args, kwargs)
         if self.psa:
             from .psa import _SOFTMAX_FUNCS, _DeferredColSoftmax
             if func in _SOFTMAX_FUNCS and args and isinstance(args[0], torch.Tensor):
@@ -247,11 +295,19 @@ class FuseMode(TorchFunctionMode):
         if self.add_up:
             if func in _IADD_FUNCS and len(args) == 2 and not kwargs and _is_map(args[0]) and _is_map(args[1]) \
                     and args[0].shape == args[1].shape and args[0].dtype == args[1].dtype \
-                    and args[0].grad_fn is not None and torch.is_grad_enabled() \
-                    and sys.getrefcount(args[0]) <= _IADD_BASE_REFS and _caller_runs_augmented_add():
+                    and args[0].grad_fn is not None and torch.is_grad_enabled():
                 # an augmented assignment whose target is referenced by its own variable only: nobody can observe when
                 # (or whether) the tensor is updated.  Aliased tensors, attributes, `.add_()` calls keep the eager add.
-                return DeferredSum(args[0], args[1])
+                if sys.getrefcount(args[0]) > _IADD_BASE_REFS:
+                    stats["iadd_declined_alias"] += 1
+                elif not _caller_runs_augmented_add():
+                    stats["iadd_declined_not_augmented"] += 1
+                else:
+                    import weakref
+                    sm = DeferredSum(args[0], args[1])
+                    self._pending.append(weakref.ref(sm))
+                    stats["iadd_deferred"] += 1
+                    return sm
             if func is F.interpolate and args and isinstance(args[0], DeferredSum):
                 s = args[0]
                 size = kwargs.get("size", args[1] if len(args) > 1 else None)
@@ -260,6 +316,7 @@ class FuseMode(TorchFunctionMode):
                 ac = kwargs.get("align_corners", args[4] if len(args) > 4 else None)
                 if s._value is None and s.unchanged() and mode == "bilinear" and ac \
                         and (size is not None or scale is not None) and not kwargs.get("antialias", False):
+                    stats["presum_fused"] += 1
                     return upsample_presum(s.a, s.b, size=size, scale_factor=scale)
         if self.head and func is F.interpolate and args and _is_map(args[0]) and torch.is_grad_enabled() \
                 and args[0].requires_grad and kwargs.get("mode") == "bilinear" and kwargs.get("align_corners") \
