@@ -100,7 +100,14 @@ def test_fp32_logits_loss_and_kept_mask_at_1024(cuda, oracle_run):
         err = (got.cpu() - want).abs().max().item()
         floor = (stk - want).abs().max().item()
         print("head %d: logits max |ours - cpu| %.2e, max |stock torch - cpu| %.2e, scale %.2f" % (h, err, floor, scale))
-        assert err <= 2.0 * floor + 1e-4 * scale and err <= 4e-3 * scale, (h, err, floor, scale)
+        # round 4: the fp32 mode runs its convolutions on the reference-accuracy kernels (exactconv.py), so north_star's
+        # 1e-4 holds END TO END; stock PyTorch-ROCm modules on the vendor library's fp32 kernels (`floor`) stay 5-15x
+        # further from the CPU path (tools/diag_fp64_truth.py: they are that far from the float64 truth)
+        from torchseg_amd import exactconv
+        if exactconv.ENABLED:
+            assert err <= 1e-4 * scale, (h, err, floor, scale)
+        else:
+            assert err <= 2.0 * floor + 1e-4 * scale and err <= 4e-3 * scale, (h, err, floor, scale)
         # OHEM selection on OUR logits vs the reference selection on the ORACLE's logits
         _, nll, _, sel = kp.ohem_fwd(got.contiguous(), yd, 255, 0.7, min_kept, None)
         sel = sel.cpu()

@@ -35,6 +35,10 @@ _DGRAD_ANY = _DGRAD_MODE == "2"
 # TSG_CONV_C64=1|0 (default 1): forward and data gradient of the 64 -> 64 stride-1 layers on tsg_conv3x3_c64_fwd
 # (104 us against 172 us for the library's kernel at [16, 64, 256, 256], tools/bench_conv64.py)
 _OWN_C64 = _os.environ.get("TSG_CONV_C64", "1") != "0"
+# TSG_CONV_C64_S1=1|0 (default 1): 0 sends the STRIDE-1 64 -> 64 layers (ResNet layer1) to the general kernel
+# (csrc/conv3g.hip: 3.8 non-MFMA instructions per MFMA against conv64's 8.9, statistics epilogue) and keeps conv64 for the
+# stride-2 spatial-path layers only (A/B of VERDICT r3 item 6)
+_OWN_C64_S1 = _os.environ.get("TSG_CONV_C64_S1", "1") != "0"
 # TSG_WEIGHT_SHADOW=0|1 (default 0): bf16 / rotated filters from torchseg_amd.shadow (one refresh launch per step instead
 # of ~45 cast / rotate launches).  Measured neutral on one MI355X (1032.5 vs 1035.5 img/s: the 4-us launches it removes sit
 # back to back in the queue and cost the GPU almost nothing), so it stays opt-in for hosts that are launch-bound.
@@ -161,7 +165,8 @@ class _ConvGenFn(torch.autograd.Function):
 
 
 def _gen_eligible(xb, conv):
-    return (_OWN_GEN and conv.stride == (1, 1) and not (_OWN_C64 and conv.in_channels == 64 and conv.out_channels == 64)
+    return (_OWN_GEN and conv.stride == (1, 1)
+            and not (_OWN_C64 and _OWN_C64_S1 and conv.in_channels == 64 and conv.out_channels == 64)
             and conv.weight.is_contiguous(memory_format=torch.channels_last)
             and K.provider().conv3x3_gen_supported(xb, conv.weight, 1, conv.padding[0], conv.dilation[0], conv.groups))
 
@@ -203,7 +208,8 @@ class WrwConv2d(nn.Conv2d):
                         wb, wrt = bank.get(self.weight, want_rot=True)
                     else:
                         wb, wrt = self.weight.detach().to(torch.bfloat16), None
-                    own64 = _OWN_C64 and self.stride == (1, 1) and self.in_channels == 64 and self.out_channels == 64
+                    own64 = _OWN_C64 and _OWN_C64_S1 and self.stride == (1, 1) and self.in_channels == 64 \
+                        and self.out_channels == 64
                     if fuse and own64:
                         return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, True)
                     return ret(_ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt))
@@ -393,6 +399,7 @@ def bn_relu_conv(bn, relu, x, conv):
             and bn.momentum is not None and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
             and conv.weight.is_contiguous(memory_format=torch.channels_last)):
         c64 = (_OWN_C64 and conv.in_channels == 64 and conv.out_channels == 64
+               and (_OWN_C64_S1 or conv.stride[0] == 2)
                and K.provider().conv3x3_c64_supported(x, conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
                                                       conv.groups))
         gen = (not c64) and _GEN_BN_ON_LOAD and conv.in_channels <= 512 and _gen_eligible(x, conv) \

@@ -109,6 +109,41 @@ static int pick_vec(int dtype, int layout, int64_t C, int64_t HW, const void* p0
   return native;
 }
 
+// Accumulator of a reduction pass.  The STATISTICS of an fp32 tensor (the parity path: north_star's fp32 logits within 1e-4
+// of the reference's CPU path) are accumulated in fp64 and handed on as hi / lo fp32 row pairs: with sum x / sum x^2 in
+// fp32 — the reference's own formulation, syncbn_kernel.cu:12-23,73-89 — var = E[x^2] - mean^2 cancels, and the batch-2
+// BatchNorm of BiSeNet's global-context branch ([2, 128, 1, 1]: var = ((a - b) / 2)^2 against a^2) amplifies the 6e-8 of an
+// fp32 partial into 3-6e-4 of the logits: exactly the distance EVERY GPU path kept from the CPU (round 4,
+// tools/diag_fp64_truth.py; reproduced on the CPU by rounding the two sums to fp32).  bf16 tensors (the bench path) keep
+// fp32 accumulators: their values carry 2^-9 of rounding already.
+template <typename T, int MODE> struct RedAcc { typedef float type; };
+template <> struct RedAcc<float, 0> { typedef double type; };
+
+// Block-wide sum of two doubles, fixed order; result valid in thread 0.  `sm` needs 2 * (blockDim.x / 64) doubles.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { sm[2 * w] = a; sm[2 * w + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int i = 0; i < nw; ++i) { ta += sm[2 * i]; tb += sm[2 * i + 1]; }
+    a = ta; b = tb;
+  }
+}
+
+// one partial entry: fp32 accumulators store the value; fp64 accumulators store hi in row s and lo in row S + s (the
+// collapse / finalize kernels sum ALL rows in fp64, so the pair adds back to ~48 bits of the block's sum)
+__device__ __forceinline__ void put_partial(float* partial, int64_t C, int S, int s, int which, int64_t c, float v) {
+  partial[((int64_t)s * 2 + which) * C + c] = v;
+}
+__device__ __forceinline__ void put_partial(float* partial, int64_t C, int S, int s, int which, int64_t c, double v) {
+  const float hi = (float)v;
+  partial[((int64_t)s * 2 + which) * C + c] = hi;
+  partial[((int64_t)(S + s) * 2 + which) * C + c] = (float)(v - (double)hi);
+}
+
 // =========================================================================
 // reductions (stats and bwd_reduce share one skeleton)
 //   MODE 0: (x)          -> sum x, sum x^2
@@ -120,16 +155,17 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nchw(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
     int64_t N, int64_t C, int64_t HW, int seg, int segs, int S,
     const float* __restrict__ fp, float* __restrict__ partial) {
-  __shared__ float sm[2 * (kThreads / 64)];
+  typedef typename RedAcc<T, MODE>::type AT;
+  __shared__ AT sm[2 * (kThreads / 64)];
   const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   float mu = 0.f, ca = 0.f, cb = 0.f;
   if (MODE == 1) {
     mu = fp[2 * C + c];
     if (MASK == 2) { ca = fp[c]; cb = fp[C + c]; }
   }
-  float a1[V], a2[V];
+  AT a1[V], a2[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  for (int j = 0; j < V; ++j) { a1[j] = 0; a2[j] = 0; }
   const int64_t U = N * segs;
   for (int64_t u = s; u < U; u += S) {
     const int64_t n = u / segs;
@@ -145,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nchw(
         px.load(x + off + i);
         if (MODE == 0) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) { a1[j] += px.v[j]; a2[j] = fmaf(px.v[j], px.v[j], a2[j]); }
+          for (int j = 0; j < V; ++j) { const AT xv = px.v[j]; a1[j] += xv; a2[j] = fma(xv, xv, a2[j]); }
         } else {
           Pack<T, V> pd;
           pd.load(dy + off + i);
@@ -167,13 +203,13 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nchw(
       }
     }
   }
-  float s1 = 0.f, s2 = 0.f;
+  AT s1 = 0, s2 = 0;
 #pragma unroll
   for (int j = 0; j < V; ++j) { s1 += a1[j]; s2 += a2[j]; }
   block_sum2(s1, s2, sm);
   if (tid == 0) {
-    partial[((int64_t)s * 2 + 0) * C + c] = s1;
-    partial[((int64_t)s * 2 + 1) * C + c] = s2;
+    put_partial(partial, C, S, s, 0, c, s1);
+    put_partial(partial, C, S, s, 1, c, s2);
   }
 }
 
@@ -182,7 +218,8 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
     int64_t M, int64_t C, int GT, int R, int64_t rows_per_block,
     const float* __restrict__ fp, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][R][GT*V]
+  typedef typename RedAcc<T, MODE>::type AT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][R][GT*V] of AT
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
   const int64_t G = C / V;
@@ -190,9 +227,9 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
   const bool live = (r < R) && (g < G);
   const int64_t c0 = g * V;
   float mu[V], ca[V], cb[V];
-  float a1[V], a2[V];
+  AT a1[V], a2[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) { a1[j] = 0.f; a2[j] = 0.f; mu[j] = 0.f; ca[j] = 0.f; cb[j] = 0.f; }
+  for (int j = 0; j < V; ++j) { a1[j] = 0; a2[j] = 0; mu[j] = 0.f; ca[j] = 0.f; cb[j] = 0.f; }
   if (MODE == 1 && live) {
     ldc<V>(fp + 2 * C, c0, mu);
     if (MASK == 2) { ldc<V>(fp, c0, ca); ldc<V>(fp + C, c0, cb); }
@@ -211,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
           px.load(x + off);
           if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) { a1[j] += px.v[j]; a2[j] = fmaf(px.v[j], px.v[j], a2[j]); }
+            for (int j = 0; j < V; ++j) { const AT xv = px.v[j]; a1[j] += xv; a2[j] = fma(xv, xv, a2[j]); }
           } else {
             Pack<T, V> pd;
             pd.load(dy + off);
@@ -236,8 +273,8 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
   }
   // cross-row reduction through LDS, fixed order
   const int W = GT * V;
-  float* s1 = smem;
-  float* s2 = smem + (size_t)R * W;
+  AT* s1 = reinterpret_cast<AT*>(smem);
+  AT* s2 = s1 + (size_t)R * W;
   if (r < R) {
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -249,10 +286,10 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
   for (int t = tid; t < W; t += kThreads) {
     const int64_t c = (int64_t)blockIdx.y * W + t;
     if (c < C) {
-      float t1 = 0.f, t2 = 0.f;
+      AT t1 = 0, t2 = 0;
       for (int q = 0; q < R; ++q) { t1 += s1[q * W + t]; t2 += s2[q * W + t]; }
-      partial[((int64_t)blockIdx.x * 2 + 0) * C + c] = t1;
-      partial[((int64_t)blockIdx.x * 2 + 1) * C + c] = t2;
+      put_partial(partial, C, (int)gridDim.x, (int)blockIdx.x, 0, c, t1);
+      put_partial(partial, C, (int)gridDim.x, (int)blockIdx.x, 1, c, t2);
     }
   }
 }
@@ -735,7 +772,7 @@ static int launch_reduce(const T* x, const T* dy, const T* y, int layout, int64_
     const int64_t M = N * HW;
     NhwcGeom g = nhwc_geom(M, C, V);
     dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
-    const size_t sh = (size_t)2 * g.rows_per_iter * g.gt * V * sizeof(float);
+    const size_t sh = (size_t)2 * g.rows_per_iter * g.gt * V * sizeof(typename RedAcc<T, MODE>::type);
 #define L_(MK) hipLaunchKernelGGL((bn_reduce_nhwc<T, V, MODE, MK>), grid, dim3(kThreads), sh, st, \
       x, dy, y, M, C, g.gt, g.rows_per_iter, g.rows_per_block, fp, partial)
     if (MODE == 0 || mask == 0) L_(0); else if (mask == 1) L_(1); else L_(2);
@@ -818,7 +855,7 @@ static int bn_reduce_dispatch(int mode, const void* x, const void* dy, const voi
   if (!x || !partial) return TSG_E_NULL;
   hipStream_t st = (hipStream_t)stream;
   const int V = pick_vec(dtype, layout, C, HW, x, dy, mask == 1 ? y : nullptr, nullptr, nullptr);
-  *rows = partial_rows(layout, N, C, HW, V);
+  *rows = partial_rows(layout, N, C, HW, V) * ((mode == 0 && dtype == TSG_F32) ? 2 : 1);   // fp32 statistics: hi + lo rows
 #define GO(T, VV)                                                                          \
   (mode == 0 ? launch_reduce<T, VV, 0>((const T*)x, nullptr, nullptr, layout, N, C, HW,    \
                                        fp, 0, partial, st)                                 \
@@ -848,7 +885,7 @@ int tsg_bn_num_partials(int layout, int64_t N, int64_t C, int64_t HW) {
     const int s = partial_rows(layout, N, C, HW, V);
     if (s > best) best = s;
   }
-  return best;
+  return 2 * best;                                          // fp32 statistics write a hi and a lo row per slice
 }
 
 size_t tsg_bn_partial_ws_bytes(int layout, int64_t N, int64_t C, int64_t HW) {

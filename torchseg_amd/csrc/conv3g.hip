@@ -48,6 +48,7 @@ struct G3Geom {
   int B, H, W, Cin, Cout;
   int tiles_h, tiles_w, ntiles;                          // pixel tiles (per oc tile)
   int nchunks, noct, nslots;                             // Cin / 16, Cout / BN, persistent blocks per oc tile
+  int prio;                                              // s_setprio 1 around the 36 MFMAs of a chunk (TSG_MFMA_PRIO)
 };
 
 // BN output channels per block, NW waves: 8 waves = 2 (oc halves) x 4 (row pairs), one block per CU; 4 waves = 1 x 4 with
@@ -223,6 +224,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
       for (int j = 0; j < NOB; ++j) af[0][j] = *reinterpret_cast<const g3_bf16x8*>(fa + (j * 64) * 8);
       // (the scheduler otherwise sinks every read to just before its first use, to save registers this kernel has to spare)
       __builtin_amdgcn_sched_barrier(0);
+      // two independent blocks share a CU: the one inside its MFMA cluster outranks the one that is staging (guide T5:
+      // pays only where waves are at DIFFERENT phases, which is exactly the two-blocks-per-CU arrangement)
+      if (g.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int kh = t / 3, kw = t % 3;
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
           for (int i = 0; i < 2; ++i)
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][j], bq[i + kh][kw], acc[j][i], 0, 0, 0);
       }
+      if (g.prio) __builtin_amdgcn_s_setprio(0);
       if (c + 1 < g.nchunks) stage(c + 1, buf ^ 1);
       __syncthreads();
     }
@@ -381,6 +386,8 @@ static int g3_geom(G3Geom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout
   ns = (ns + 7) / 8 * 8;
   if (ns < 8) ns = 8;
   g->nslots = (int)ns;
+  static const int prio = [] { const char* e = getenv("TSG_MFMA_PRIO"); return e ? atoi(e) : 0; }();
+  g->prio = prio;
   return 0;
 }
 

@@ -305,6 +305,8 @@ struct W3GenGeom {
   int B, H, W, tiles_h, tiles_w, ntiles;   // H, W: OUTPUT size (= size of dy)
   int Hin, Win;                            // input size (= H, W for stride 1)
   int Cin, Cout, nci, npairs, bpp;         // channel counts, ci tiles, (oc tile, ci tile) pairs, blocks per pair
+  int xs;                                  // XCDs that share one slot's pairs: 1 (bpp % 8 == 0) or 2 (bpp % 4 == 0)
+  int prio;                                // s_setprio 1 around the MFMAs of a tile (TSG_MFMA_PRIO)
 };
 
 // stride S in {1, 2}: the x patch of a 4 x 32 output tile is (4 S + 3 - S) x (32 S + 3 - S) input pixels (6 x 34 / 9 x 65),
@@ -350,8 +352,13 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
   // operands from HBM: 2.01x the algorithmic traffic over the step's 25 launches (profiles/traffic.json, round 2).  Now the
   // pairs of a slot are consecutive ids on ONE XCD: they run at the same time on the same tiles and the re-reads are
   // L2 hits.  bpp is a multiple of 8 (w3gen_geom).
+  // xs == 2 (round 4; >= 64 pairs, i.e. 512 -> 512): a slot's pairs are split over TWO XCDs, so that 4 slots x 64 pairs
+  // = 256 blocks fill the chip in ONE round with one resident block per CU (8 slots were 512 blocks = two rounds of 16
+  // tiles each, and twice the partials); each XCD then streams every x slice and half of the dy slices of its slot.
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int pair = jb % g.npairs, slot = (jb / g.npairs) * 8 + xcd;
+  const int pps = g.npairs / g.xs;                    // pairs per XCD of a slot
+  const int pair = (g.xs == 2 ? (xcd & 1) * pps : 0) + jb % pps;
+  const int slot = (jb / pps) * (8 / g.xs) + (g.xs == 2 ? xcd >> 1 : xcd);
   const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
   if (AFF && tid < 2 * W3_C) abs_[tid] = in_ab[(tid >> 6) * g.Cin + ci0 + (tid & 63)];   // a / b rows of this ci tile
 
@@ -466,6 +473,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
   // patch rows instead of (row, kh) pairs reads 36 (stride 1) / 54 (stride 2) fragments per tile instead of 72 (neutral
   // in the step: this loop is not bound by LDS reads, profiles/r03_conv3wrw_shared_fragments.txt)
   auto mfma_tile = [&]() {
+    if (g.prio) __builtin_amdgcn_s_setprio(1);
     Frag fa[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -489,6 +497,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv3_wrw_gen_k(const bf16_t*
               acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * (rr / S) + c].v, fb.v, acc[kh * 3 + kw], 0, 0, 0);
           }
         }
+    if (g.prio) __builtin_amdgcn_s_setprio(0);
   };
 
   if (PF == 2) {
@@ -729,7 +738,13 @@ static int w3gen_geom(W3GenGeom* g, int64_t B, int64_t Hin, int64_t Win, int Cin
   int bpp = ((stride == 1 && w3_occ2(g->ntiles) ? 2 * target : target) + g->npairs - 1) / g->npairs;
   if (bpp > g->ntiles) bpp = g->ntiles;
   if (bpp < 1) bpp = 1;
-  g->bpp = (bpp + 7) / 8 * 8;                                // slots per pair: a multiple of 8 (XCD mapping of the kernel)
+  // slots per pair: a multiple of 8 (one XCD per slot residue), or of 4 with a slot's pairs on two XCDs when 8 slots
+  // would be more blocks than CUs (TSG_CONV_WRW_XS2=0 restores the round-3 mapping)
+  static const bool xs2 = [] { const char* e = getenv("TSG_CONV_WRW_XS2"); return !(e && e[0] == '0'); }();
+  g->xs = (xs2 && bpp <= 4 && g->npairs % 2 == 0 && g->npairs * 8 > target) ? 2 : 1;
+  g->bpp = g->xs == 2 ? (bpp + 3) / 4 * 4 : (bpp + 7) / 8 * 8;
+  static const int prio = [] { const char* e = getenv("TSG_MFMA_PRIO"); return e ? atoi(e) : 0; }();
+  g->prio = prio;
   return 0;
 }
 

@@ -22,11 +22,18 @@ template <typename T> struct PV<T, 1> {
   __device__ __forceinline__ void store(T* p) const { st1<T>(p, v[0]); }
 };
 
+// fp32 maps (the parity path) are summed in fp64: the pooled value feeds the batch-2 BatchNorm of BiSeNet's global-context
+// branch, which amplifies an fp32 summation error ~300x (csrc/bn.hip, RedAcc)
+template <typename T> struct GapAcc { typedef float type; };
+template <> struct GapAcc<float> { typedef double type; };
+
 // NHWC: x [N, HW, C]; block (s, n): rows [s*rpb, ...) of image n -> partial[n][s][c]
 template <typename T, int V>
 __global__ __launch_bounds__(kT) void gap_partial_nhwc(const T* __restrict__ x, int64_t HW, int64_t C, int GT,
                                                        int R, int64_t rpb, int S, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [R][C]
+  typedef typename GapAcc<T>::type AT;
+  extern __shared__ __attribute__((aligned(16))) float sm_raw[];   // [R][C] of AT
+  AT* sm = reinterpret_cast<AT*>(sm_raw);
   const int tid = threadIdx.x, gl = tid % GT, r = tid / GT;
   const int64_t n = blockIdx.y;
   const int64_t row0 = (int64_t)blockIdx.x * rpb;
@@ -35,9 +42,9 @@ __global__ __launch_bounds__(kT) void gap_partial_nhwc(const T* __restrict__ x, 
   const int G = (int)(C / V);
   for (int gb = 0; gb < G; gb += GT) {                         // channel tiles when C/V > 256
     const int g = gb + gl;
-    float acc[V];
+    AT acc[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int j = 0; j < V; ++j) acc[j] = 0;
     if (r < R && g < G) {
       const T* b = x + n * HW * C + (int64_t)g * V;
       for (int64_t row = row0 + r; row < row1; row += (int64_t)kU * R) {
@@ -62,9 +69,9 @@ __global__ __launch_bounds__(kT) void gap_partial_nhwc(const T* __restrict__ x, 
     for (int t = tid; t < GT * V; t += kT) {
       const int64_t c = (int64_t)gb * V + t;
       if (c < C) {
-        float s = 0.f;
+        AT s = 0;
         for (int q = 0; q < R; ++q) s += sm[q * (GT * V) + t];
-        partial[(n * S + blockIdx.x) * C + c] = s;
+        partial[(n * S + blockIdx.x) * C + c] = (float)s;
       }
     }
   }
@@ -74,17 +81,24 @@ __global__ __launch_bounds__(kT) void gap_partial_nhwc(const T* __restrict__ x, 
 template <typename T, int V>
 __global__ __launch_bounds__(kT) void gap_plane_nchw(const T* __restrict__ x, int64_t HW, float inv,
                                                      T* __restrict__ out) {
-  __shared__ float sm[2 * (kT / 64)];
+  typedef typename GapAcc<T>::type AT;
+  __shared__ AT sm[kT / 64];
   const T* b = x + (int64_t)blockIdx.x * HW;
-  float acc = 0.f, dummy = 0.f;
+  AT acc = 0;
   for (int64_t i = (int64_t)threadIdx.x * V; i < HW; i += (int64_t)kT * V) {
     PV<T, V> p;
     p.load(b + i);
 #pragma unroll
     for (int j = 0; j < V; ++j) acc += p.v[j];
   }
-  block_sum2(acc, dummy, sm);
-  if (threadIdx.x == 0) st1<T>(out + blockIdx.x, acc * inv);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    AT t = 0;
+    for (int i = 0; i < kT / 64; ++i) t += sm[i];
+    st1<T>(out + blockIdx.x, (float)(t * (AT)inv));
+  }
 }
 
 template <typename T>
@@ -93,10 +107,10 @@ __global__ __launch_bounds__(kT) void gap_finish(const float* __restrict__ parti
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;   // i = n*C + c
   if (i >= NC) return;
   const int64_t n = i / C, c = i - n * C;
-  float s = 0.f;
+  typename GapAcc<T>::type s = 0;
 #pragma unroll 16
   for (int q = 0; q < S; ++q) s += partial[(n * S + q) * C + c];
-  st1<T>(out + i, s * inv);
+  st1<T>(out + i, (float)(s * inv));
 }
 
 // backward: dx[n, p, c] = dout[n, c] * inv   (NHWC)   /   dx[n, c, p] (NCHW)
@@ -519,7 +533,7 @@ int tsg_gap_fwd(const void* x, void* out, int dtype, int layout, int64_t N, int6
   const int V = (C % native == 0 && aligned16(x)) ? native : 1;
   GapGeom g = gap_geom(N, C, HW, V);
   dim3 grid((unsigned)g.S, (unsigned)N);
-  const size_t sh = (size_t)g.R * g.gt * V * sizeof(float);
+  const size_t sh = (size_t)g.R * g.gt * V * (dtype == TSG_F32 ? sizeof(double) : sizeof(float));
 #define GO(T, VV) hipLaunchKernelGGL((gap_partial_nhwc<T, VV>), grid, dim3(kT), sh, st, (const T*)x, HW, C, g.gt, \
                                      g.R, g.rpb, g.S, (float*)ws)
   if (dtype == TSG_F32) { if (V == 4) GO(float, 4); else GO(float, 1); }

@@ -55,6 +55,8 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_ADAPTIVE_POOL=1|0 (default 1 on GPU: nn.AdaptiveAvgPool2d on channels_last maps -> tsg_adaptive_avgpool_nhwc_*)
   TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw;
                         TSG_CONV_WRW_IMPL=tr|v1 picks the kernel variant, default tr)
+  TSG_FP32_EXACT=1|0    (default 1: with TSG_DTYPE=fp32 every convolution runs on tsg_conv2d_f32_exact_* — exact products,
+                        fp64 accumulation — instead of the vendor library's fp32 kernels: the parity mode, exactconv.py)
 """
 import os
 
@@ -389,6 +391,11 @@ class DistributedDataParallel(nn.Module):
             if _env_flag("TSG_ADAPTIVE_POOL", True):
                 from .pool import install_adaptive_pool
                 install_adaptive_pool(self.module)
+            if self.compute_dtype == torch.float32:
+                # fp32 = the parity mode: convolutions on the reference-accuracy kernels (exactconv.py; the vendor
+                # library's fp32 kernels sit 3-6e-4 from the float64 truth, the reference's CPU path 5e-5)
+                from . import exactconv
+                exactconv.install(self.module)
 
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None

@@ -571,6 +571,47 @@ class HipKernels:
                                      ws.data_ptr(), wsb, L.stream_ptr(X)), "tsg_psa_bwd")
         return dX, dA
 
+    # ---- reference-accuracy fp32 convolution (parity path; csrc/convf32.hip) ------
+    @staticmethod
+    def _strides4(t):
+        return (C.c_int64 * 4)(*[int(v) for v in t.stride()])
+
+    def conv2d_f32_exact_fwd(self, x, w, stride, padding, dilation):
+        """y = conv2d(x, w) with exact products and fp64 accumulation; x [B,Cin,H,W] / w [Cout,Cin,KH,KW] fp32 in any
+        (dense, non-overlapping) layout; y takes x's memory format."""
+        B, Cin, H, W = x.shape
+        Cout, _, KH, KW = w.shape
+        OH = (H + 2 * padding[0] - dilation[0] * (KH - 1) - 1) // stride[0] + 1
+        OW = (W + 2 * padding[1] - dilation[1] * (KW - 1) - 1) // stride[1] + 1
+        cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device,
+                        memory_format=torch.channels_last if cl else torch.contiguous_format)
+        L.check(self.lib.tsg_conv2d_f32_exact_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, H, W, Cout, KH, KW,
+                                                  stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                                  self._strides4(x), self._strides4(w), self._strides4(y),
+                                                  L.stream_ptr(x)), "tsg_conv2d_f32_exact_fwd")
+        return y
+
+    def conv2d_f32_exact_dgrad(self, dy, w, x_like, stride, padding, dilation):
+        B, Cin, H, W = x_like.shape
+        Cout, _, KH, KW = w.shape
+        dx = torch.empty_like(x_like)
+        L.check(self.lib.tsg_conv2d_f32_exact_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cin, H, W, Cout, KH, KW,
+                                                    stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                                    self._strides4(dx), self._strides4(w), self._strides4(dy),
+                                                    L.stream_ptr(dy)), "tsg_conv2d_f32_exact_dgrad")
+        return dx
+
+    def conv2d_f32_exact_wgrad(self, x, dy, w_like, stride, padding, dilation):
+        B, Cin, H, W = x.shape
+        Cout, _, KH, KW = w_like.shape
+        dw = torch.empty_like(w_like)
+        L.check(self.lib.tsg_conv2d_f32_exact_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, KH, KW,
+                                                    stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                                    self._strides4(x), self._strides4(dw), self._strides4(dy),
+                                                    L.stream_ptr(x)), "tsg_conv2d_f32_exact_wgrad")
+        return dw
+
     def sgd_step(self, param, grad, buf, lr, momentum, weight_decay, grad_scale, first):
         L.check(self.lib.tsg_sgd_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(),
                                       float(lr), float(momentum), float(weight_decay), float(grad_scale),
