@@ -643,9 +643,10 @@ int tsg_xgmi_small_allreduce(tsg_comm* c, float* buf, int64_t count, void* strea
 /* ------------------------------------------------------------------------
  * Reference-accuracy fp32 convolution for the PARITY path (csrc/convf32.hip) — replaces the cuDNN calls behind every
  * `nn.Conv2d` of the reference (furnace/base_model/resnet.py:24-29,96-97; furnace/seg_opr/seg_oprs.py:27-31) when the
- * package computes in fp32: products exact, accumulation in fp64, one rounding to fp32 at the store.  The vendor
- * library's fp32 kernels leave the full-resolution logits 3-6e-4 from the float64 evaluation of the network, ten times
- * further than the reference's CPU path is (tools/diag_fp64_truth.py); north_star asks for 1e-4.  Any kernel size,
+ * package computes in fp32 (the parity mode): products exact, accumulation in fp64, one rounding to fp32 at the store.
+ * With them BiSeNet-R18's full-resolution fp32 logits are 1.3-1.9e-5 from the float64 evaluation of the network (the
+ * reference's CPU path: 6.9-8.3e-5; the vendor library's fp32 kernels: 4.8-6.3e-5; tools/diag_fp64_truth.py), i.e. the
+ * 1e-4 of north_star against the CPU path is the CPU's own rounding.  Any kernel size,
  * stride, padding, dilation; groups = 1; every tensor is addressed through four ELEMENT strides (x / dx: b, c, h, w;
  * w / dw: o, c, kh, kw; y / dy: b, o, oh, ow), so NCHW and channels_last need no copies.  H, W: input size.
  * Deterministic (fixed summation order).  Not a fast path: fp64 FMAs. */
@@ -655,9 +656,13 @@ int tsg_conv2d_f32_exact_fwd(const float* x, const float* w, float* y, int64_t B
 int tsg_conv2d_f32_exact_dgrad(const float* dy, const float* w, float* dx, int64_t B, int Cin, int H, int W, int Cout, int KH,
                                int KW, int sh, int sw, int ph, int pw, int dh, int dw, const int64_t* dx_strides,
                                const int64_t* w_strides, const int64_t* dy_strides, void* stream);
+/* the weight gradient splits the pixels into slices (fp64 partials in `ws`, added in slice order): ws_bytes may be 0 */
+size_t tsg_conv2d_f32_exact_wgrad_ws_bytes(int64_t B, int Cin, int H, int W, int Cout, int KH, int KW, int sh, int sw, int ph,
+                                           int pw, int dh, int dw);
 int tsg_conv2d_f32_exact_wgrad(const float* x, const float* dy, float* dw_out, int64_t B, int Cin, int H, int W, int Cout,
                                int KH, int KW, int sh, int sw, int ph, int pw, int dh, int dw, const int64_t* x_strides,
-                               const int64_t* w_strides, const int64_t* dy_strides, void* stream);
+                               const int64_t* w_strides, const int64_t* dy_strides, void* ws, size_t ws_bytes,
+                               void* stream);
 
 #ifdef __cplusplus
 }

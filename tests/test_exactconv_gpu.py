@@ -25,6 +25,8 @@ CASES = [
     (1, 80, 17, 15, 72, 3, 1, 2, 2, True),
     (1, 130, 12, 12, 70, 3, 1, 4, 4, False),
     (3, 5, 8, 8, 7, 5, 3, 1, 1, False),
+    (2, 64, 64, 72, 64, 3, 1, 1, 1, True),                 # 9216 pixels: the weight gradient runs in 4 pixel slices
+    (1, 3, 96, 100, 32, 7, 2, 3, 1, False),
 ]
 
 

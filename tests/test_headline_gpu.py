@@ -3,17 +3,19 @@ min_kept = B*H*W/16, thresh 0.7), against the CPU oracle network run live on the
 nn.BatchNorm2d, loss_opr.py restatement; bisenet network.py:75-111, loss_opr.py:68-98), plus index-width guards for
 the BN kernels at the bench's largest activations and a multi-step trajectory against stock PyTorch ops.
 
-Bars.  north_star asks for fp32 loss / logits within 1e-4 of the reference CPU path.  Every kernel of ours meets that
-against its oracle in isolation (tests/test_bn_gpu.py, test_upsample_gpu.py, test_ohem_gpu.py, ...); the LOSS meets it
-here too.  The full-resolution LOGITS of the whole 1024^2 network cannot: they pass through 30+ MIOpen fp32
-convolutions whose GPU algorithms differ from the CPU's summation by ~1e-3 of the logit scale on their own -- measured
-with stock PyTorch-ROCm modules (nn.BatchNorm2d, ATen upsample; tools/diag_fp32_logits.py: max 0.8-1.7e-3 at scale 1.6-2.3,
-any layout, Winograd / FFT / GEMM solvers on or off, and varying run to run with MIOpen's solver choice).  So the test
-measures that stock floor on the same device and asserts (a) our path is no further from the CPU than 2x it and within
-4e-3 of the logit scale, (b) loss within 1e-4, (c) the OHEM kept mask equal to the reference's except pixels whose
-probability lies within the band the MEASURED logit error of the run implies (2 x that error, relative), (d) gradients
-1e-2 in relative L2 over all parameters.  Selection exactness at the real batch (16 images, min_kept 1 048 576) is checked
-without any convolution in between by test_batch16_selection_against_the_oracle_at_the_real_min_kept."""
+Bars (round 4).  north_star asks for fp32 loss / logits within 1e-4 of the reference CPU path.  Both hold here END TO END:
+the loss to 1e-6 and the full-resolution logits of all three heads to 6.5-8.0e-5 ABSOLUTE at a logit scale of 1.6-2.3 —
+which is the CPU path's own distance from the float64 evaluation of the network (tools/diag_fp64_truth.py: CPU 6.9-8.3e-5,
+ours 1.3-1.9e-5 from the truth).  Rounds 1-3 measured 0.8-1.5e-3 and blamed the vendor library's convolutions; the cause
+was the fp32 sum / square-sum formulation of the BatchNorm statistics (the reference's own, syncbn_kernel.cu:12-23),
+whose cancellation the batch-2 BatchNorm of the global-context branch amplifies ~300x (fixed in csrc/bn.hip: fp64
+accumulators + hi / lo partial rows for fp32 tensors; csrc/pool.hip: fp64 pooling sums; csrc/convf32.hip: exact
+convolutions).  Stock PyTorch-ROCm modules on the same GPU are still measured beside ours (`floor`, 7-9e-4).  The test
+asserts (a) logits <= 1e-4 of the logit scale (measured: below 1e-4 absolute), (b) loss within 1e-4, (c) the OHEM kept mask equal to the reference's except pixels
+whose probability lies within the band the MEASURED logit error of the run implies (2 x that error, relative: 0 pixels),
+(d) gradients 1e-2 in relative L2 over all parameters (measured 3.0e-3).  Selection exactness at the real batch (16 images,
+min_kept 1 048 576) is checked without any convolution in between by
+test_batch16_selection_against_the_oracle_at_the_real_min_kept."""
 import os
 
 import numpy as np
@@ -100,14 +102,12 @@ def test_fp32_logits_loss_and_kept_mask_at_1024(cuda, oracle_run):
         err = (got.cpu() - want).abs().max().item()
         floor = (stk - want).abs().max().item()
         print("head %d: logits max |ours - cpu| %.2e, max |stock torch - cpu| %.2e, scale %.2f" % (h, err, floor, scale))
-        # round 4: the fp32 mode runs its convolutions on the reference-accuracy kernels (exactconv.py), so north_star's
-        # 1e-4 holds END TO END; stock PyTorch-ROCm modules on the vendor library's fp32 kernels (`floor`) stay 5-15x
-        # further from the CPU path (tools/diag_fp64_truth.py: they are that far from the float64 truth)
-        from torchseg_amd import exactconv
-        if exactconv.ENABLED:
-            assert err <= 1e-4 * scale, (h, err, floor, scale)
-        else:
-            assert err <= 2.0 * floor + 1e-4 * scale and err <= 4e-3 * scale, (h, err, floor, scale)
+        # round 4: north_star's 1e-4 holds END TO END and in ABSOLUTE terms (measured 6.5-8.0e-5 = the CPU path's own
+        # distance from the float64 truth, tools/diag_fp64_truth.py).  What kept rounds 1-3 at 1.1-1.6e-3 was the fp32
+        # sum / square-sum formulation of the BatchNorm statistics (csrc/bn.hip RedAcc: fp64 accumulators, hi / lo partial
+        # rows for fp32 tensors) amplified ~300x by the batch-2 BatchNorm of the global-context branch; stock
+        # PyTorch-ROCm modules (`floor`) still carry it.
+        assert err <= 1e-4 * scale, (h, err, floor, scale)      # 1e-4 of the logit scale (as for the loss); measured: < 1e-4 absolute
         # OHEM selection on OUR logits vs the reference selection on the ORACLE's logits
         _, nll, _, sel = kp.ohem_fwd(got.contiguous(), yd, 255, 0.7, min_kept, None)
         sel = sel.cpu()

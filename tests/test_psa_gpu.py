@@ -117,3 +117,53 @@ def test_psa_bf16_full_size_fwd_bwd_vs_cpu_oracle(cuda):
         assert (d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item() <= 1e-2, name
         # the last rows / columns (partial tiles) carry real values
         assert got[..., -16:].float().abs().sum().item() > 0 and got[..., -16:, :].float().abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("regime", ["one_hot_column", "all_large", "all_very_negative"])
+def test_psa_bf16_logits_outside_the_optimistic_range_take_the_guarded_path(cuda, regime):
+    """Round 4: the bf16 forward contracts X with exp(A) and normalises by the column sums it collected on the way (no
+    column-statistics pass).  That is only safe while a column's sum of exp stays in [1e-20, 1e20]; any tile that sees
+    more raises a device flag and the classic three launches (column statistics, exp(a - lse)) redo the call.  Logits far
+    outside the range — one column, every column, everything hugely negative — must give the oracle's result (the
+    reference's torch.softmax subtracts the column maximum: psanet network.py:125-126), forward, lse and gradients."""
+    from torchseg_amd import kernels as K
+    from torchseg_amd.psa import psa_attention
+    g = torch.Generator().manual_seed(5)
+    B, Cx, Kd, N = 2, 512, 264, 200
+    X = torch.relu(torch.randn(B, Cx, Kd, generator=g)).bfloat16()
+    A = torch.randn(B, Kd, N, generator=g) * 2
+    if regime == "one_hot_column":
+        A[1, 7, 131] = 120.0                                # exp(120) overflows fp32: one column of one sample
+    elif regime == "all_large":
+        A = A * 40.0
+    else:
+        A = A - 200.0                                       # every exp underflows: the sums are 0
+    A = A.bfloat16()
+    dout = torch.randn(B, Cx, N, generator=g).bfloat16()
+    out_ref, dX_ref, dA_ref = psa_ref.psa_attention_with_grads(X.float(), A.float(), dout.float())
+    lse_ref = torch.logsumexp(A.double(), dim=1)
+    Xd, Ad = X.to(cuda).requires_grad_(True), A.to(cuda).requires_grad_(True)
+    out = psa_attention(Xd, Ad)
+    out.backward(dout.to(cuda))
+    assert torch.isfinite(out.float()).all()
+    for got, ref, name in ((out, out_ref, "out"), (Xd.grad, dX_ref, "dX"), (Ad.grad, dA_ref, "dA")):
+        scale = ref.abs().max().item()
+        err = (got.detach().float().cpu().double() - ref).abs().max().item()
+        assert err <= 2e-2 * scale, (regime, name, err, scale)
+    _, lse = K.provider().psa_fwd(X.to(cuda), A.to(cuda))
+    assert (lse.double().cpu() - lse_ref).abs().max().item() <= 1e-5 * lse_ref.abs().max().item() + 1e-5
+
+
+def test_psa_bf16_lse_of_the_optimistic_forward(cuda):
+    """In-range logits (the ordinary case): lse = log of the column sums the contraction collected equals
+    torch.logsumexp to fp32 accuracy, and two calls are bit-identical."""
+    from torchseg_amd import kernels as K
+    g = torch.Generator().manual_seed(6)
+    X = torch.relu(torch.randn(2, 512, 520, generator=g)).bfloat16().to(cuda)
+    A = (torch.randn(2, 520, 456, generator=g) * 3).bfloat16().to(cuda)
+    kp = K.provider()
+    out, lse = kp.psa_fwd(X, A)
+    out2, lse2 = kp.psa_fwd(X, A)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    ref = torch.logsumexp(A.double().cpu(), dim=1)
+    assert (lse.double().cpu() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 2e-6

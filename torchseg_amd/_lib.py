@@ -148,7 +148,8 @@ _PROTOS = {
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
     "tsg_conv2d_f32_exact_fwd": (_i, [_p, _p, _p, _i64] + [_i] * 12 + [_p, _p, _p, _p]),
     "tsg_conv2d_f32_exact_dgrad": (_i, [_p, _p, _p, _i64] + [_i] * 12 + [_p, _p, _p, _p]),
-    "tsg_conv2d_f32_exact_wgrad": (_i, [_p, _p, _p, _i64] + [_i] * 12 + [_p, _p, _p, _p]),
+    "tsg_conv2d_f32_exact_wgrad_ws_bytes": (_sz, [_i64] + [_i] * 12),
+    "tsg_conv2d_f32_exact_wgrad": (_i, [_p, _p, _p, _i64] + [_i] * 12 + [_p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

@@ -39,6 +39,11 @@ _OWN_C64 = _os.environ.get("TSG_CONV_C64", "1") != "0"
 # (csrc/conv3g.hip: 3.8 non-MFMA instructions per MFMA against conv64's 8.9, statistics epilogue) and keeps conv64 for the
 # stride-2 spatial-path layers only (A/B of VERDICT r3 item 6)
 _OWN_C64_S1 = _os.environ.get("TSG_CONV_C64_S1", "1") != "0"
+# TSG_CONV_C64_STATS=1|0 (default 1, round 4): the BatchNorm statistics of a conv64 output in that kernel's epilogue
+# (conv64_fwd_k<STATS = true>, built and parity-tested since round 2 but never requested by the autograd nodes): the
+# SyncBatchNorm behind each of the six 64 -> 64 layers (layer1 x 4 at 16 x 64 x 256^2, SpatialPath x 2) skips its own
+# pass over 134 / 34 MB
+_C64_STATS = _os.environ.get("TSG_CONV_C64_STATS", "1") != "0"
 # TSG_WEIGHT_SHADOW=0|1 (default 0): bf16 / rotated filters from torchseg_amd.shadow (one refresh launch per step instead
 # of ~45 cast / rotate launches).  Measured neutral on one MI355X (1032.5 vs 1035.5 img/s: the 4-us launches it removes sit
 # back to back in the queue and cost the GPU almost nothing), so it stays opt-in for hosts that are launch-bound.
@@ -57,12 +62,15 @@ def _skip_addend(dskip, like_shape):
 
 class _ConvWrwFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, wb, stride, wrt=None, skip=False):
+    def forward(ctx, x, weight, wb, stride, wrt=None, skip=False, with_stats=False):
         # x bf16 channels_last, wb = weight rounded to bf16 (what autocast feeds the convolution)
         ctx.own = _OWN_C64 and K.provider().conv3x3_c64_supported(x, wb, stride, 1, 1, 1) \
             and wb.is_contiguous(memory_format=torch.channels_last)
         ctx.in_hw = (x.shape[2], x.shape[3])
-        if ctx.own:
+        partial = None
+        if ctx.own and with_stats:
+            y, partial = K.provider().conv3x3_c64_fwd(x, wb, with_stats=True, stride=stride)
+        elif ctx.own:
             y = K.provider().conv3x3_c64_fwd(x, wb, stride=stride)     # 64 -> 64: our kernels (csrc/conv64.hip)
         else:
             y = F.conv2d(x, wb, None, stride, 1)
@@ -73,15 +81,23 @@ class _ConvWrwFn(torch.autograd.Function):
         ctx.need_dx = x.requires_grad
         ctx.dgrad_fwd = _DGRAD_FWD and stride == 1 and (_DGRAD_ANY or weight.shape[0] == weight.shape[1])
         ctx.set_materialize_grads(False)
-        # skip: x is returned as a second output for the block's skip connection, so that the gradient of that path
+        ctx.has_stats = bool(with_stats)
+        if with_stats:                                     # second output: the statistics partial of y (or an empty tensor)
+            if partial is None:
+                partial = x.new_empty(0, dtype=torch.float32)
+            ctx.mark_non_differentiable(partial)
+        # skip: x is returned as a further output for the block's skip connection, so that the gradient of that path
         # arrives HERE (dskip) and is added in the epilogue of the data-gradient kernel instead of by autograd's own pass
-        return (y, x) if skip else y
+        outs = (y,) + ((partial,) if with_stats else ()) + ((x,) if skip else ())
+        return outs if len(outs) > 1 else y
 
     @staticmethod
-    def backward(ctx, dy, dskip=None):
+    def backward(ctx, dy, *rest):
         x, wb = ctx.saved_tensors
+        rest = rest[1:] if ctx.has_stats else rest         # drop the (non-differentiable) partial's slot
+        dskip = rest[0] if rest else None
         if dy is None:                                     # only the skip path was used
-            return dskip, None, None, None, None, None
+            return dskip, None, None, None, None, None, None
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -106,7 +122,7 @@ class _ConvWrwFn(torch.autograd.Function):
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
         dw = K.provider().conv3x3_wrw(x, dy, stride=ctx.stride)
-        return dx, dw.to(ctx.wdtype), None, None, None, None
+        return dx, dw.to(ctx.wdtype), None, None, None, None, None
 
 
 # TSG_CONV_GEN=1|0 (default 1): forward and data gradient of every other stride-1 3x3 layer (C_in % 16 == 0, C_out % 64
@@ -210,9 +226,16 @@ class WrwConv2d(nn.Conv2d):
                         wb, wrt = self.weight.detach().to(torch.bfloat16), None
                     own64 = _OWN_C64 and _OWN_C64_S1 and self.stride == (1, 1) and self.in_channels == 64 \
                         and self.out_channels == 64
-                    if fuse and own64:
-                        return _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, True)
-                    return ret(_ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt))
+                    c64 = _OWN_C64 and self.in_channels == 64 and self.out_channels == 64
+                    stats = _C64_STATS and c64 and self.training
+                    out = _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, bool(fuse and own64), stats)
+                    if not stats:
+                        return out if (fuse and own64) else ret(out)
+                    y, partial = out[0], out[1]
+                    if partial.numel():
+                        from .stemconv import attach_bn_partial
+                        attach_bn_partial(y, partial)      # the SyncBatchNorm behind it skips its statistics pass
+                    return ret(y, out[2] if (fuse and own64) else None)
         return ret(super().forward(x))
 
 
@@ -254,6 +277,8 @@ class _BnReluConvFn(torch.autograd.Function):
             out = kp.conv3x3_gen_fwd(x, kp.conv3x3_gen_prep_filter(weight, 0, x), weight.shape[0], with_stats=out_stats,
                                      in_ab=fp)
             y, partial = out if out_stats else (out, None)
+        elif out_stats:
+            y, partial = kp.conv3x3_c64_fwd(x, wb, with_stats=True, stride=stride, in_ab=fp)
         else:
             y = kp.conv3x3_c64_fwd(x, wb, stride=stride, in_ab=fp)
         if partial is None:
@@ -300,7 +325,7 @@ class _StemBnReluConvFn(torch.autograd.Function):
     stem's weight gradient (tsg_stem_conv_wrw_bn), its only consumer, so neither relu(bn(xc)) nor d(xc) is ever stored."""
 
     @staticmethod
-    def forward(ctx, img, w_stem, gamma, beta, bn, use_batch_stats, group, weight, wb, stride, wrt):
+    def forward(ctx, img, w_stem, gamma, beta, bn, use_batch_stats, group, weight, wb, stride, wrt, out_stats=False):
         from . import syncbn as S
         kp = K.provider()
         if use_batch_stats:
@@ -317,14 +342,18 @@ class _StemBnReluConvFn(torch.autograd.Function):
         else:
             invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
             fp = kp.bn_affine(bn.running_mean.float(), invstd, g32, b32)
-        y = kp.conv3x3_c64_fwd(xc, wb, stride=stride, in_ab=fp)
+        if out_stats:
+            y, partial = kp.conv3x3_c64_fwd(xc, wb, with_stats=True, stride=stride, in_ab=fp)
+        else:
+            y, partial = kp.conv3x3_c64_fwd(xc, wb, stride=stride, in_ab=fp), img.new_empty(0, dtype=torch.float32)
         ctx.save_for_backward(img, xc, wb, gamma, beta, invstd, fp, count_dev)
         ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype, w_stem.dtype)
         ctx.wrt = wrt
-        return y
+        ctx.mark_non_differentiable(partial)
+        return y, partial
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         from . import syncbn as S
         kp = K.provider()
         img, xc, wb, gamma, beta, invstd, fp, count_dev = ctx.saved_tensors
@@ -344,7 +373,7 @@ class _StemBnReluConvFn(torch.autograd.Function):
         else:
             dgamma = dgamma.to(gamma.dtype)
             dbeta = dbeta.to(beta.dtype) if beta is not None else None
-        return None, dw_stem.to(sdtype), dgamma, dbeta, None, None, None, dw.to(wdtype), None, None, None
+        return None, dw_stem.to(sdtype), dgamma, dbeta, None, None, None, dw.to(wdtype), None, None, None, None
 
 
 # TSG_STEM_BN_WRW=1|0 (default 1): stem -> BN -> ReLU -> 64 -> 64 3x3 as one autograd node (see _StemBnReluConvFn)
@@ -376,8 +405,12 @@ def stem_bn_relu_conv(stem, bn, relu, img, conv):
             wb, wrt = bank.get(conv.weight, want_rot=True)
         else:
             wb, wrt = conv.weight.detach().to(torch.bfloat16), None
-        return _StemBnReluConvFn.apply(xb, w_stem, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, conv.weight,
-                                       wb, conv.stride[0], wrt)
+        y, partial = _StemBnReluConvFn.apply(xb, w_stem, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group,
+                                             conv.weight, wb, conv.stride[0], wrt, bool(_C64_STATS and conv.training))
+        if partial.numel():
+            from .stemconv import attach_bn_partial
+            attach_bn_partial(y, partial)
+        return y
 
 
 # TSG_BN_ON_LOAD=1|0 (default 1): BatchNorm + ReLU in front of a 64 -> 64 3x3 convolution applied while that convolution
@@ -419,8 +452,9 @@ def bn_relu_conv(bn, relu, x, conv):
                     wb, wrt = bank.get(conv.weight, want_rot=True)
                 else:
                     wb, wrt = conv.weight.detach().to(torch.bfloat16), None
+                out_stats = ((gen and _GEN_STATS) or (c64 and _C64_STATS)) and conv.training
                 y, partial = _BnReluConvFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group, hint,
-                                                 conv.weight, wb, conv.stride[0], wrt, gen, gen and _GEN_STATS and conv.training)
+                                                 conv.weight, wb, conv.stride[0], wrt, gen, bool(out_stats))
             if partial.numel():
                 from .stemconv import attach_bn_partial
                 attach_bn_partial(y, partial)

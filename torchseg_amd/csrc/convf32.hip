@@ -2,14 +2,15 @@
 //
 // north_star asks for fp32 loss / logits within 1e-4 of the reference's CPU path (the `nn.Conv2d` calls of
 // furnace/base_model/resnet.py:24-29,96-97, furnace/seg_opr/seg_oprs.py:27-31 evaluated by torch's CPU convolution).
-// Measured in round 4 (tools/diag_fp64_truth.py, BiSeNet-R18 at 2 x 512^2 / 2 x 1024^2): the CPU path is 3-7e-5 from the
-// float64 evaluation of the same network, while EVERY GPU path that runs its convolutions on the vendor library in fp32 —
-// stock PyTorch-ROCm modules included — is 3-6e-4 away: the library's fp32 kernels do not accumulate like an fp32 FMA
-// chain.  The fp32 compute mode of this package exists for parity, not speed, so its convolutions run here instead:
-// a direct (implicit-GEMM-tiled) convolution whose products are exact (fp32 x fp32 in fp64) and whose accumulation is
-// fp64, rounded to fp32 once at the store: the result is the correctly rounded exact convolution for all practical
-// purposes, closer to the truth than the CPU reference itself.  Any kernel size / stride / padding / dilation, any
-// memory layout (element strides), groups = 1.  Speed is a non-goal (fp64 FMAs, ~10-20 TFLOP/s).
+// Measured in round 4 (tools/diag_fp64_truth.py, BiSeNet-R18 at 2 x 1024^2, max |logit difference| per head): the CPU path
+// is 6.9-8.3e-5 from the float64 evaluation of the same network.  Rounds 1-3 sat 1.1-1.6e-3 away; the cause was NOT the
+// convolutions but the fp32 sum / square-sum formulation of the BatchNorm statistics (csrc/bn.hip, RedAcc).  With that
+// fixed, the vendor library's fp32 convolutions leave the logits 4.8-6.3e-5 from the truth, these kernels 1.3-1.9e-5: a
+// direct (implicit-GEMM-tiled) convolution whose products are exact (fp32 x fp32 in fp64) and whose accumulation is
+// fp64, rounded to fp32 once at the store — the correctly rounded exact convolution, four times closer to the truth than
+// the CPU reference itself.  The fp32 compute mode of this package exists for parity, not speed, so its convolutions
+// run here.  Any kernel size / stride / padding / dilation, any memory layout (element strides), groups = 1.  Speed is
+// a non-goal (fp64 FMAs).
 //
 // Tiling: 256 threads own 64 output channels x 64 output pixels; K = (kh, kw, ci) walked tap by tap in chunks of 16
 // input channels staged through LDS; a thread accumulates a 4 x 4 block in 16 doubles.  Fixed summation order:
@@ -122,29 +123,34 @@ __global__ __launch_bounds__(256) void convf32_k(const float* __restrict__ x, co
 }
 
 // dw[o, c, kh, kw] = sum_{b, oh, ow} dy[b, o, oh, ow] x[b, c, oh sh - ph + kh dh, ow sw - pw + kw dw]
-// block = (64 o) x (64 c) of ONE tap; the pixels are walked in chunks of 16 by every block (no split: deterministic).
+// block = (64 o) x (64 c) of ONE tap and ONE pixel slice (blockIdx.z = tap * nslice + slice); the slice's pixels are walked
+// in chunks of 16.  nslice == 1: the block stores dw itself; otherwise it stores its fp64 partial [slice][o][c][tap] and
+// convf32_wrw_fold adds the slices in index order (deterministic either way).
 __global__ __launch_bounds__(256) void convf32_wrw_k(const float* __restrict__ x, const float* __restrict__ dy,
-                                                     float* __restrict__ dw, CfGeom g) {
+                                                     float* __restrict__ dw, CfGeom g, int nslice, int64_t per_slice,
+                                                     double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float As[CF_KC][CF_TM];     // dy[pixel k][o]
   __shared__ __attribute__((aligned(16))) float Bs[CF_KC][CF_TN];     // x[pixel k @ tap][c]
   const int tid = threadIdx.x, tm = tid >> 4, tn = tid & 15;
   const int o0 = blockIdx.y * CF_TM, c0 = blockIdx.x * CF_TN;
-  const int tap = blockIdx.z, kh = tap / g.KW, kw = tap % g.KW;
+  const int tap = blockIdx.z / nslice, slice = blockIdx.z % nslice, kh = tap / g.KW, kw = tap % g.KW;
   const int sc = tid & 63, sk4 = tid >> 6;
+  const int64_t pbeg = (int64_t)slice * per_slice;
+  const int64_t pend = pbeg + per_slice < g.P ? pbeg + per_slice : g.P;
   double acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
   const int64_t hw = (int64_t)g.OH * g.OW;
-  for (int64_t pb = 0; pb < g.P; pb += CF_KC) {
+  for (int64_t pb = pbeg; pb < pend; pb += CF_KC) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = sk4 * 4 + j;
       const int64_t p = pb + k;
       float a = 0.f, b = 0.f;
-      if (p < g.P) {
+      if (p < pend) {
         const int bi = (int)(p / hw), r = (int)(p % hw), oh = r / g.OW, ow = r % g.OW;
         if (o0 + sc < g.Cout)
           a = dy[(int64_t)bi * g.ys[0] + (int64_t)(o0 + sc) * g.ys[1] + (int64_t)oh * g.ys[2] + (int64_t)ow * g.ys[3]];
@@ -175,9 +181,26 @@ __global__ __launch_bounds__(256) void convf32_wrw_k(const float* __restrict__ x
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + tn * 4 + j;
-      if (c < g.Cin) dw[(int64_t)o * g.ws[0] + (int64_t)c * g.ws[1] + (int64_t)kh * g.ws[2] + (int64_t)kw * g.ws[3]] = (float)acc[i][j];
+      if (c >= g.Cin) continue;
+      if (nslice == 1)
+        dw[(int64_t)o * g.ws[0] + (int64_t)c * g.ws[1] + (int64_t)kh * g.ws[2] + (int64_t)kw * g.ws[3]] = (float)acc[i][j];
+      else
+        part[(((int64_t)slice * g.Cout + o) * g.Cin + c) * (g.KH * g.KW) + tap] = acc[i][j];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void convf32_wrw_fold(const double* __restrict__ part, float* __restrict__ dw, CfGeom g,
+                                                        int nslice) {
+  const int64_t n = (int64_t)g.Cout * g.Cin * g.KH * g.KW;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double t = 0.0;
+  for (int s = 0; s < nslice; ++s) t += part[(int64_t)s * n + i];
+  const int tap = (int)(i % (g.KH * g.KW));
+  const int64_t oc = i / (g.KH * g.KW);
+  const int c = (int)(oc % g.Cin), o = (int)(oc / g.Cin);
+  dw[(int64_t)o * g.ws[0] + (int64_t)c * g.ws[1] + (int64_t)(tap / g.KW) * g.ws[2] + (int64_t)(tap % g.KW) * g.ws[3]] = (float)t;
 }
 
 }  // namespace tsg
@@ -231,17 +254,47 @@ int tsg_conv2d_f32_exact_dgrad(const float* dy, const float* w, float* dx, int64
   return 0;
 }
 
+// pixel slices of the weight gradient: enough blocks to fill the chip (~1024), at least 2048 pixels per slice, at most 64
+static int cf_wrw_slices(const CfGeom& g) {
+  const int64_t base = (int64_t)((g.Cin + CF_TN - 1) / CF_TN) * ((g.Cout + CF_TM - 1) / CF_TM) * g.KH * g.KW;
+  int64_t ns = (1024 + base - 1) / base;
+  const int64_t by_px = g.P / 2048;
+  if (ns > by_px) ns = by_px;
+  if (ns > 64) ns = 64;
+  return (int)(ns < 1 ? 1 : ns);
+}
+
+size_t tsg_conv2d_f32_exact_wgrad_ws_bytes(int64_t B, int Cin, int H, int W, int Cout, int KH, int KW, int sh, int sw, int ph,
+                                           int pw, int dh, int dw) {
+  CfGeom g;
+  const int64_t one[4] = {1, 1, 1, 1};
+  if (cf_geom(&g, B, Cin, H, W, Cout, KH, KW, sh, sw, ph, pw, dh, dw, one, one, one)) return 0;
+  const int ns = cf_wrw_slices(g);
+  return ns == 1 ? 0 : (size_t)ns * Cout * Cin * KH * KW * sizeof(double);
+}
+
 int tsg_conv2d_f32_exact_wgrad(const float* x, const float* dy, float* dw_out, int64_t B, int Cin, int H, int W, int Cout,
                                int KH, int KW, int sh, int sw, int ph, int pw, int dh, int dw, const int64_t* x_strides,
-                               const int64_t* w_strides, const int64_t* dy_strides, void* stream) {
+                               const int64_t* w_strides, const int64_t* dy_strides, void* ws, size_t ws_bytes,
+                               void* stream) {
   if (!x || !dy || !dw_out) return TSG_E_NULL;
   CfGeom g;
   int e = cf_geom(&g, B, Cin, H, W, Cout, KH, KW, sh, sw, ph, pw, dh, dw, x_strides, w_strides, dy_strides);
   if (e) return e;
-  if ((int64_t)KH * KW > 65535) return TSG_E_SHAPE;
-  hipLaunchKernelGGL(convf32_wrw_k, dim3((unsigned)((Cin + CF_TN - 1) / CF_TN), (unsigned)((Cout + CF_TM - 1) / CF_TM), (unsigned)(KH * KW)),
-                     dim3(256), 0, (hipStream_t)stream, x, dy, dw_out, g);
+  const int ns = cf_wrw_slices(g);
+  if ((int64_t)KH * KW * ns > 65535) return TSG_E_SHAPE;
+  const size_t need = ns == 1 ? 0 : (size_t)ns * Cout * Cin * KH * KW * sizeof(double);
+  if (need && (!ws || ws_bytes < need)) return ws ? TSG_E_WS : TSG_E_NULL;
+  const int64_t per_slice = ((g.P + ns - 1) / ns + CF_KC - 1) / CF_KC * CF_KC;
+  hipLaunchKernelGGL(convf32_wrw_k, dim3((unsigned)((Cin + CF_TN - 1) / CF_TN), (unsigned)((Cout + CF_TM - 1) / CF_TM), (unsigned)(KH * KW * ns)),
+                     dim3(256), 0, (hipStream_t)stream, x, dy, dw_out, g, ns, per_slice, (double*)ws);
   TSG_CHECK_LAUNCH();
+  if (ns > 1) {
+    const int64_t n = (int64_t)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(convf32_wrw_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)ws, dw_out, g, ns);
+    TSG_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -38,7 +38,8 @@ constexpr int GT = 256;                     // threads per gemm block (4 waves)
 template <typename T>
 __global__ __launch_bounds__(256) void psa_colstat1(const T* __restrict__ A, int64_t K, int64_t N,
                                                     int rows_per_chunk, float* __restrict__ pm,
-                                                    float* __restrict__ pl) {
+                                                    float* __restrict__ pl, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int chunk = blockIdx.y, nchunk = gridDim.y;
   const int64_t b = blockIdx.z;
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(256) void psa_colstat1(const T* __restrict__ A, int
 }
 
 __global__ __launch_bounds__(256) void psa_colstat2(const float* __restrict__ pm, const float* __restrict__ pl,
-                                                    int nchunk, int64_t N, float* __restrict__ lse) {
+                                                    int nchunk, int64_t N, float* __restrict__ lse,
+                                                    const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t b = blockIdx.y;
   if (j >= N) return;
@@ -80,7 +83,8 @@ template <> struct ColVec<float, 4> : Vec<float> {};
 template <typename T, int V, int GR>
 __global__ __launch_bounds__(128) void psa_colstat1_vec(const T* __restrict__ A, int64_t K, int64_t N,
                                                         int rows_per_chunk, float* __restrict__ pm,
-                                                        float* __restrict__ pl) {
+                                                        float* __restrict__ pl, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int64_t j = ((int64_t)blockIdx.x * 128 + threadIdx.x) * V;
   const int chunk = blockIdx.y, nchunk = gridDim.y;
   const int64_t b = blockIdx.z;
@@ -118,7 +122,9 @@ __global__ __launch_bounds__(128) void psa_colstat1_vec(const T* __restrict__ A,
 // Stage 2 for many chunks: block = 64 columns x 4 chunk groups; the per-thread loads are independent, the four
 // group results meet in LDS (fixed order).
 __global__ __launch_bounds__(256) void psa_colstat2_wide(const float* __restrict__ pm, const float* __restrict__ pl,
-                                                         int nchunk, int64_t N, float* __restrict__ lse) {
+                                                         int nchunk, int64_t N, float* __restrict__ lse,
+                                                         const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   __shared__ float sm[4][64], sl[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 64 + col;
@@ -443,7 +449,13 @@ static int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t st) {
 //         (cols * 2 + 64) B are odd multiples of 64 B: the 4 rows x 64 B a half-wave touches fall on distinct banks.
 // B transforms (the fused softmax):  EXPB 1: B is a TR tile of A, element -> exp(a - lse[n])   (forward)
 //                                    EXPB 2: B is an NT tile of A, element -> exp(a - lse[k])   (dX)
-// Epilogues (through LDS, 16-B global accesses): EPI 0 store bf16; EPI 1 dA = exp(Araw[m][n] - lse[n]) * (acc - delta[n]).
+//                                    EXPB 3 (round 4, "optimistic" forward): B is a TR tile of A, element -> exp(a), and the
+//                                    staging threads keep the COLUMN SUMS of the (unrounded) exponentials: no column
+//                                    statistics pass in front of the contraction
+// Epilogues (through LDS, 16-B global accesses): EPI 0 store bf16; EPI 1 dA = exp(Araw[m][n] - lse[n]) * (acc - delta[n]);
+//   EPI 2 (with EXPB 3): out = acc / colsum[n], lse[n] = log(colsum[n]) written by the tm = 0 tiles, and *flag |= 1 when a
+//   column sum left [1e-20, 1e20] (logits beyond ~+-46: exp without the max subtraction is no longer safe) — the host
+//   then has the guarded three-kernel path (column statistics + EXPB 1) recompute the call.
 //   forward  out[c][j] = sum_i X[c][i] P[i][j]       A = X    NT   B = A     TR  EXPB 1
 //   dX       dX[c][i]  = sum_j dOut[c][j] P[i][j]    A = dOut NT   B = A     NT  EXPB 2
 //   dA       dP[i][j]  = sum_c X[c][i] dOut[c][j]    A = X    TR   B = dOut  TR  EPI 1
@@ -492,6 +504,9 @@ struct MmArgs {
   const bf16_t* Af; int64_t sAf;    // AF: the NT A operand in MFMA fragment order (psa_frag_k), batch stride in elements
   int MB, KS;                       // AF: 32-row blocks of A, 16-wide k steps (4 per K tile, zero padded)
   int64_t batch;
+  float* lse_out;                   // EPI 2: log of the column sums (batch stride sL)
+  int* flag;                        // EPI 2: set when a column sum is out of the safe range
+  const int* run_if;                // when given: the kernel returns at once unless *run_if != 0 (guarded fallback)
 };
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -502,7 +517,8 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // registers.  The ablations (profiles/r03_psa_ablations.txt) showed psa_mm bound by its register -> LDS write path
 // (768 B per MFMA at 128 x 64 tiles): without the A tile only the exponentiated B tile is left on it (8 KB per K tile).
 __global__ __launch_bounds__(256) void psa_frag_k(const bf16_t* __restrict__ X, int64_t M, int64_t K, int MB, int KS,
-                                                  bf16_t* __restrict__ Xf) {
+                                                  bf16_t* __restrict__ Xf, int* __restrict__ clear_flag) {
+  if (clear_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear_flag = 0;   // EPI 2's flag, fresh per call
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 16-byte vector per thread
   const int64_t per_b = (int64_t)MB * KS * 64;
   const int64_t b = blockIdx.y;
@@ -534,6 +550,10 @@ void psa_mm(MmArgs g) {
   static_assert(!AF || (!A_TR && SPLIT && PF == 2), "AF: NT A operand, MFMA / staging wave split, two register sets");
   static_assert((!AF || UT) && (!UT || (SPLIT && PF >= 2)), "UT: staging waves of their own, at least two register sets");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  static_assert((EXPB == 3) == (EPI == 2), "the optimistic forward is EXPB 3 with EPI 2");
+  static_assert(EPI != 2 || (BN == 64 && B_TR && (size_t)BM * (BN + 4) * 4 + 33 * 64 * 4 <= MmGeom<BM, BN>::LDS),
+                "EPI 2: 64-column tiles, column-sum image behind the epilogue image");
+  if (g.run_if && *g.run_if == 0) return;                // guarded fallback launch: nothing to redo
   const bool producer = SPLIT && threadIdx.x >= MM_T;    // wave-uniform
   const bool stages = !SPLIT || producer, computes = !SPLIT || !producer;
   const int tid = threadIdx.x & (MM_T - 1), lane = tid & 63, wave = tid >> 6;
@@ -555,7 +575,7 @@ void psa_mm(MmArgs g) {
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const bf16_t* Ag = g.A + b * g.sA;
   const bf16_t* Bg = g.B + b * g.sB;
-  const float* lse = (EXPB || EPI == 1) ? g.lse + b * g.sL : nullptr;
+  const float* lse = (EXPB == 1 || EXPB == 2 || EPI == 1) ? g.lse + b * g.sL : nullptr;
 
   // ---- staging maps: 16-byte chunks.  A tile = BM * 8 chunks (ACH per thread), B tile = BN * 8 chunks (BCH per thread)
   //   NT image [rows][8 chunks]: chunk id c -> row c >> 3, k-chunk c & 7
@@ -597,6 +617,9 @@ void psa_mm(MmArgs g) {
       kb[q] = kc; pb[q] = Bg + (vb[q] ? n0 + nr : g.N - 1) * g.K; ob[q] = nr * MM_NT_ROW + kc;
     }
   }
+  float csum[8];                                        // EXPB 3: sum over k of exp(a) for the thread's 8 columns
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   float bl[EXPB == 1 ? G::BCH : 1][8];                  // EXPB 1: lse * log2e of the thread's B columns (fixed per block)
   if (EXPB == 1) {
 #pragma unroll
@@ -662,6 +685,17 @@ void psa_mm(MmArgs g) {
       uint4 v = qb[q];
       const bool in = vb[q] && k0 + kb[q] < Kd;            // the K tail (and the padding) must be exact zeros, not exp(-lse)
       if (ablate & 4) {
+      } else if (EXPB == 3) {
+        // exp(a) itself; the thread's chunks all lie in the same 8 columns (256 % CPR == 0), so one register row of sums
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = exp2_fast(__uint_as_float(w[i] << 16) * kLog2e);
+          const float hi = exp2_fast(__uint_as_float(w[i] & 0xffff0000u) * kLog2e);
+          if (in) { csum[2 * i] += lo; csum[2 * i + 1] += hi; }
+          w[i] = pack2_bf16(lo, hi);
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
       } else if (EXPB == 1) {
         v = expchunk(v, bl[EXPB == 1 ? q : 0]);
       } else if (EXPB == 2 && UT) {                        // lse of the chunk's 8 k positions came with the tile (TSG_UT_FETCH)
@@ -860,6 +894,11 @@ void psa_mm(MmArgs g) {
   // [BM][BN + 4], then every thread owns 8 consecutive columns of a row: 16-byte global accesses
   __syncthreads();
   float* ep = reinterpret_cast<float*>(lds);
+  float* cs = ep + BM * G::EPI_ROW;                       // EPI 2: [32 staging rows][64 columns] partial column sums
+  if (EPI == 2 && stages) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[(tid / G::CPR) * 64 + (tid % G::CPR) * 8 + e] = csum[e];
+  }
   if (computes) {
 #pragma unroll
     for (int i = 0; i < G::MI; ++i)
@@ -882,6 +921,22 @@ void psa_mm(MmArgs g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dl[e] = g.delta[b * g.sD + n + e]; l2[e] = lse[n + e] * kLog2e; }
   }
+  if (EPI == 2) {
+    // column sums: the 32 staging rows in a fixed order, one column per thread of wave 0 (the tile of the other M half
+    // gets the same values in the same order); reciprocals shared through LDS so that no thread carries them in registers
+    float* cinv = cs + (MM_T / G::CPR) * 64;
+    if (threadIdx.x < 64) {
+      float tot = 0.f;
+      for (int q = 0; q < MM_T / G::CPR; ++q) tot += cs[q * 64 + threadIdx.x];
+      cinv[threadIdx.x] = 1.f / tot;
+      const int64_t nc = n0 + threadIdx.x;
+      if (tm == 0 && nc < g.N) {
+        g.lse_out[b * g.sL + nc] = logf(tot);
+        if (!(tot >= 1e-20f && tot <= 1e20f)) atomicOr(g.flag, 1);
+      }
+    }
+    __syncthreads();
+  }
 #pragma unroll 4
   for (int q = 0; q < BM / RPP; ++q) {
     if (SPLIT && (q & 1) != (producer ? 1 : 0)) continue;
@@ -902,6 +957,11 @@ void psa_mm(MmArgs g) {
         v[2 * e] = p0 * (v[2 * e] - dl[2 * e]);
         v[2 * e + 1] = p1 * (v[2 * e + 1] - dl[2 * e + 1]);
       }
+    }
+    if (EPI == 2) {
+      const float* cinv = cs + (MM_T / G::CPR) * 64 + cchunk * 8;
+      const float4 i0 = *reinterpret_cast<const float4*>(cinv), i1 = *reinterpret_cast<const float4*>(cinv + 4);
+      v[0] *= i0.x; v[1] *= i0.y; v[2] *= i0.z; v[3] *= i0.w; v[4] *= i1.x; v[5] *= i1.y; v[6] *= i1.z; v[7] *= i1.w;
     }
     uint32_t o[4];
 #pragma unroll
@@ -952,7 +1012,11 @@ static int mm_cfg() {
 // AF configurations apply to the products whose A operand is NT and for which the caller prepared the fragment image
 template <bool A_TR, bool B_TR, int EXPB, int EPI>
 static int launch_mm_af(MmArgs g, hipStream_t st, int cfg) {
-  if constexpr (!A_TR) {
+  if constexpr (!A_TR && EPI == 2) {
+    // the optimistic forward exists for the 256 x 64 tile only: at 128 x 64 (two blocks per CU, 128 VGPRs) its column sums
+    // spill, and a kernel with untracked loads must not spill (tests/test_isa_guards_cpu.py)
+    return launch_mm_cfg<256, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
+  } else if constexpr (!A_TR) {
     switch (cfg) {
       case 71280642: return launch_mm_cfg<128, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
       default:       return launch_mm_cfg<256, 64, 2, A_TR, B_TR, EXPB, EPI, true, true>(g, st);
@@ -1004,6 +1068,7 @@ struct PsaWs {
   float* delta_part;                 // [B, kDeltaChunks, N]
   float* dP;                         // fp32 path bwd: [B, K, N]
   bf16_t* Af;                        // bf16 path: the NT A operand (X fwd, dOut bwd) in MFMA fragment order
+  int* flag;                         // bf16 forward: "a column sum left the safe range" (optimistic contraction, EPI 2)
   size_t total;
 };
 
@@ -1014,12 +1079,12 @@ static inline int af_ks(int64_t K) { return 4 * (int)((K + MM_BK - 1) / MM_BK); 
 static inline size_t af_elems(int64_t B, int64_t M, int64_t K) { return (size_t)B * af_mb(M) * af_ks(K) * 512; }
 
 // lay the NT A operand out in fragment order when the configured tile wants it (TSG_PSA_CFG=af...)
-static int af_prepare(MmArgs& m, bf16_t* Af, hipStream_t st) {
+static int af_prepare(MmArgs& m, bf16_t* Af, hipStream_t st, int* clear_flag = nullptr) {
   if (mm_cfg() / 10000000 != 7 || !Af) return 0;
   m.MB = af_mb(m.M); m.KS = af_ks(m.K);
   const int64_t per_b = (int64_t)m.MB * m.KS * 64;
   hipLaunchKernelGGL(psa_frag_k, dim3((unsigned)((per_b + 255) / 256), (unsigned)m.batch), dim3(256), 0, st, m.A,
-                     m.M, m.K, m.MB, m.KS, Af);
+                     m.M, m.K, m.MB, m.KS, Af, clear_flag);
   TSG_CHECK_LAUNCH();
   m.Af = Af; m.sAf = per_b * 8;
   return 0;
@@ -1033,6 +1098,7 @@ static PsaWs psa_carve(void* base, int64_t B, int64_t Cx, int64_t K, int64_t N, 
   w.pm = (float*)take((size_t)B * kChunks * N * 4);
   w.pl = (float*)take((size_t)B * kChunks * N * 4);
   w.lse_tmp = (float*)take((size_t)B * N * 4);
+  w.flag = (int*)take(256);
   // the bf16 path (psa_mm) fuses the softmax into the contractions and needs no operand images at all
   w.P_hi = f32 ? (bf16_t*)take((size_t)B * K * N * 2) : nullptr;
   w.P_lo = f32 ? (bf16_t*)take((size_t)B * K * N * 2) : nullptr;
@@ -1060,7 +1126,8 @@ static int egrid(int64_t n) {
 }
 
 template <typename T>
-static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float* lse, hipStream_t st) {
+static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float* lse, hipStream_t st,
+                   const int* run_if = nullptr) {
   constexpr int V = sizeof(T) == 2 ? 8 : 4;
   if (N % V == 0 && aligned16(A)) {
     static const int want = [] { const char* e = getenv("TSG_PSA_COLCHUNKS"); const int v = e ? atoi(e) : kChunks;
@@ -1069,20 +1136,20 @@ static int colstat(const T* A, int64_t B, int64_t K, int64_t N, PsaWs& w, float*
     const int nch = (int)((K + rpc - 1) / rpc);                        // chunks that actually hold rows
     const int64_t nv = N / V;
     hipLaunchKernelGGL((psa_colstat1_vec<T, V, 15>), dim3((unsigned)((nv + 127) / 128), (unsigned)nch, (unsigned)B),
-                       dim3(128), 0, st, A, K, N, rpc, w.pm, w.pl);
+                       dim3(128), 0, st, A, K, N, rpc, w.pm, w.pl, run_if);
     TSG_CHECK_LAUNCH();
     hipLaunchKernelGGL(psa_colstat2_wide, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(256), 0, st, w.pm, w.pl,
-                       nch, N, lse);
+                       nch, N, lse, run_if);
     TSG_CHECK_LAUNCH();
     return 0;
   }
   const int nch = 30;
   const int rpc = (int)((K + nch - 1) / nch);
   hipLaunchKernelGGL((psa_colstat1<T>), dim3((unsigned)((N + 255) / 256), nch, (unsigned)B), dim3(256), 0, st,
-                     A, K, N, rpc, w.pm, w.pl);
+                     A, K, N, rpc, w.pm, w.pl, run_if);
   TSG_CHECK_LAUNCH();
   hipLaunchKernelGGL(psa_colstat2, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st, w.pm, w.pl,
-                     nch, N, lse);
+                     nch, N, lse, run_if);
   TSG_CHECK_LAUNCH();
   return 0;
 }
@@ -1130,10 +1197,28 @@ int tsg_psa_fwd(const void* X, const void* A, void* out, float* lse, int dtype, 
     if ((e = launch_gemm<float, 0>(g, B, st))) return e;
   } else {
     if (Cx % 8 != 0 || N % 8 != 0) return TSG_E_SHAPE;
-    if ((e = colstat<bf16_t>((const bf16_t*)A, B, K, N, w, lse, st))) return e;
     MmArgs m = {};
     m.A = (const bf16_t*)X; m.B = (const bf16_t*)A; m.C = (bf16_t*)out;
     m.M = Cx; m.N = N; m.K = K; m.sA = Cx * K; m.sB = K * N; m.sC = Cx * N; m.lse = lse; m.sL = N; m.batch = B;
+    // TSG_PSA_OPTIMISTIC=1|0 (default 1; fragment-order tiles only).  Round 3's forward spent 35 % of its time on the
+    // column statistics (psa_colstat1_vec + psa_colstat2_wide: a full pass over A before the contraction could start).
+    // The optimistic form contracts X with exp(A) directly, sums the columns of exp(A) on the way (in the staging waves,
+    // which hold fixed columns) and normalises in the epilogue: one pass over A.  exp without the max subtraction is only
+    // safe while the column sums stay in [1e-20, 1e20] (|logit| up to ~46); a tile that sees anything else raises a device
+    // flag, and the three launches of the classic path that follow — each returns at once unless the flag is set —
+    // recompute the whole call exactly as round 3 did.  No host synchronisation either way.
+    static const bool optimistic = [] { const char* o = getenv("TSG_PSA_OPTIMISTIC"); return !(o && o[0] == '0'); }();
+    if (optimistic && mm_cfg() / 10000000 == 7 && mm_cfg() != 71280642 && w.Af) {
+      if ((e = af_prepare(m, w.Af, st, w.flag))) return e;             // psa_frag_k also clears the flag
+      MmArgs o = m;
+      o.lse = nullptr; o.lse_out = lse; o.flag = w.flag;
+      if ((e = launch_mm_af<false, true, 3, 2>(o, st, mm_cfg()))) return e;
+      if ((e = colstat<bf16_t>((const bf16_t*)A, B, K, N, w, lse, st, w.flag))) return e;
+      m.run_if = w.flag;
+      if ((e = launch_mm<false, true, 1, 0>(m, st))) return e;
+      return 0;
+    }
+    if ((e = colstat<bf16_t>((const bf16_t*)A, B, K, N, w, lse, st))) return e;
     if ((e = af_prepare(m, w.Af, st))) return e;
     if ((e = launch_mm<false, true, 1, 0>(m, st))) return e;
   }

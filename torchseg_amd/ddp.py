@@ -392,8 +392,8 @@ class DistributedDataParallel(nn.Module):
                 from .pool import install_adaptive_pool
                 install_adaptive_pool(self.module)
             if self.compute_dtype == torch.float32:
-                # fp32 = the parity mode: convolutions on the reference-accuracy kernels (exactconv.py; the vendor
-                # library's fp32 kernels sit 3-6e-4 from the float64 truth, the reference's CPU path 5e-5)
+                # fp32 = the parity mode: convolutions on the reference-accuracy kernels (exactconv.py: logits 1.3-1.9e-5
+                # from the float64 truth, the reference's CPU path 7-8e-5, the vendor library's fp32 kernels 5-6e-5)
                 from . import exactconv
                 exactconv.install(self.module)
 

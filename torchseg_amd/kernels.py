@@ -606,10 +606,12 @@ class HipKernels:
         B, Cin, H, W = x.shape
         Cout, _, KH, KW = w_like.shape
         dw = torch.empty_like(w_like)
-        L.check(self.lib.tsg_conv2d_f32_exact_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, KH, KW,
-                                                    stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+        geo = (Cin, H, W, Cout, KH, KW, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1])
+        wsb = self.lib.tsg_conv2d_f32_exact_wgrad_ws_bytes(B, *geo)
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_conv2d_f32_exact_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, *geo,
                                                     self._strides4(x), self._strides4(dw), self._strides4(dy),
-                                                    L.stream_ptr(x)), "tsg_conv2d_f32_exact_wgrad")
+                                                    ws.data_ptr(), wsb, L.stream_ptr(x)), "tsg_conv2d_f32_exact_wgrad")
         return dw
 
     def sgd_step(self, param, grad, buf, lr, momentum, weight_decay, grad_scale, first):
