@@ -664,6 +664,22 @@ int tsg_conv2d_f32_exact_wgrad(const float* x, const float* dy, float* dw_out, i
                                const int64_t* w_strides, const int64_t* dy_strides, void* ws, size_t ws_bytes,
                                void* stream);
 
+/* ------------------------------------------------------------------------
+ * Classifier convolution of a segmentation head (csrc/clshead.hip) — replaces the cuDNN calls behind
+ * `nn.Conv2d(C_in, n_classes, kernel_size=1)` + bias of bisenet network.py:151-161 (BiSeNetHead.conv_1x1; the same layer
+ * ends the 19-class heads of dfn network.py) and of its backward.  x / dx: channels_last bf16 [B, HW, C_in]; w: fp32
+ * [n_classes, C_in] (rounded to bf16 inside, as autocast would); bias fp32 or NULL; z / dz: PLANAR bf16 [B, n_classes, HW] —
+ * the layout tsg_ohem_up_fwd / tsg_ohem_fwd read, so no layout copy sits between the head and its criterion.
+ * n_classes <= 32, C_in in {32, 64, 128, 256}, HW % 16 == 0.  fp32 accumulation; the weight / bias gradient is folded
+ * from per-block partials in fp64 in a fixed order (deterministic).  ws: tsg_cls_head_wgrad_ws_bytes. */
+int tsg_cls_head_supported(int dtype, int Cin, int n_classes, int64_t HW);
+int tsg_cls_head_fwd(const void* x, const float* w, const float* bias, void* z, int64_t B, int64_t HW, int Cin, int n_classes,
+                     void* stream);
+int tsg_cls_head_dgrad(const void* dz, const float* w, void* dx, int64_t B, int64_t HW, int Cin, int n_classes, void* stream);
+size_t tsg_cls_head_wgrad_ws_bytes(int64_t B, int Cin, int n_classes);
+int tsg_cls_head_wgrad(const void* dz, const void* x, float* dw, float* dbias, int64_t B, int64_t HW, int Cin, int n_classes,
+                       void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,3 +181,21 @@ def test_wrw_buffer_fetch_addresses_equal_pointer_fetch():
                     assert 0 <= ptr and ptr + 8 <= B * Hin * Win * Cin
                     checked += 1
     assert checked > 10000
+
+
+def test_every_python_source_compiles():
+    """The DDP wrapper imports most of the package only on a GPU: a syntax error in such a module would first show on the
+    GPU box.  Byte-compile everything here."""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 0
+    for base in ("torchseg_amd", "tools", "tests", "oracle"):
+        for d, _, files in os.walk(os.path.join(root, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    py_compile.compile(os.path.join(d, f), doraise=True)
+                    n += 1
+    for f in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(os.path.join(root, f), doraise=True)
+    assert n > 60

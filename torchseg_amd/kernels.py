@@ -571,6 +571,42 @@ class HipKernels:
                                      ws.data_ptr(), wsb, L.stream_ptr(X)), "tsg_psa_bwd")
         return dX, dA
 
+    # ---- classifier convolution of a head (csrc/clshead.hip) ---------------------
+    def cls_head_supported(self, x, weight):
+        return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dim() == 4 and weight.shape[2:] == (1, 1)
+                and weight.dtype == torch.float32 and x.shape[1] == weight.shape[1]
+                and bool(self.lib.tsg_cls_head_supported(L.BF16, x.shape[1], weight.shape[0], x.shape[2] * x.shape[3])))
+
+    def cls_head_fwd(self, x, weight, bias):
+        """x bf16 channels_last [B,C,H,W], weight fp32 [N,C,1,1] -> z bf16 NCHW-contiguous [B,N,H,W] (planar logits)"""
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("cls_head_fwd expects a channels_last activation")
+        _require_contiguous(weight, bias)
+        B, Cc, H, W = x.shape
+        N = weight.shape[0]
+        z = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x.device)
+        L.check(self.lib.tsg_cls_head_fwd(x.data_ptr(), weight.data_ptr(), L.ptr(bias), z.data_ptr(), B, H * W, Cc, N,
+                                          L.stream_ptr(x)), "tsg_cls_head_fwd")
+        return z
+
+    def cls_head_bwd(self, dz, x, weight, need_dx=True, need_db=True):
+        """dz bf16 NCHW-contiguous [B,N,H,W] -> (dx bf16 channels_last like x | None, dw fp32 like weight, dbias fp32 [N] | None)"""
+        _require_contiguous(dz, weight)
+        B, Cc, H, W = x.shape
+        N = weight.shape[0]
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(x)
+            L.check(self.lib.tsg_cls_head_dgrad(dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, H * W, Cc, N,
+                                                L.stream_ptr(dz)), "tsg_cls_head_dgrad")
+        dw = torch.empty_like(weight)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if need_db else None
+        wsb = self.lib.tsg_cls_head_wgrad_ws_bytes(B, Cc, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_cls_head_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), L.ptr(db), B, H * W, Cc, N,
+                                            ws.data_ptr(), wsb, L.stream_ptr(dz)), "tsg_cls_head_wgrad")
+        return dx, dw, db
+
     # ---- reference-accuracy fp32 convolution (parity path; csrc/convf32.hip) ------
     @staticmethod
     def _strides4(t):
