@@ -9,7 +9,7 @@ TAG=${1:-r04}; FAM=${2:-}
 O=gpurun_out/${TAG}_evidence; mkdir -p $O
 export TMPDIR=/tmp
 HEAD=$(cat .git_head 2>/dev/null || echo unknown)
-( time timeout 600 python bench.py ) > $O/bench_default.log 2>&1; tail -n 1 $O/bench_default.log | cut -c1-400
+( time timeout 600 python bench.py ) > $O/bench_default.log 2>&1; grep "^{" $O/bench_default.log | tail -n 1 | cut -c1-300
 bash tools/prof_bench.sh > $O/prof_bench.out 2>&1; cp gpurun_out/prof/kernel_stats_compact.csv $O/kernel_stats.csv; grep "kernels total" $O/prof_bench.out
 bash tools/pmc_traffic.sh > $O/pmc_traffic.out 2>&1; cp gpurun_out/pmc/summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc/traffic_by_kernel.json $O/traffic_by_kernel.json
 out=$PWD/gpurun_out/pmc_busy; rm -rf $out; mkdir -p $out
@@ -20,7 +20,7 @@ python tools/make_traffic_json.py $O/traffic_by_kernel.json $O/traffic.json "$TA
 if [ -n "$FAM" ]; then
 for c in pspnet dfn psanet; do
   ( time timeout 900 python bench.py --config $c --steps 20 --warmup 10 ) > $O/bench_$c.log 2>&1
-  tail -n 1 $O/bench_$c.log > $O/bench_$c.json; grep -o '"value": [0-9.]*' $O/bench_$c.log | head -2
+  grep "^{" $O/bench_$c.log | tail -n 1 > $O/bench_$c.json; grep -o '"value": [0-9.]*' $O/bench_$c.log | head -2
 done
 fi
 ls -la $O
