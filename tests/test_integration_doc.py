@@ -58,7 +58,7 @@ def _namespace():
 
 def test_section3_blocks_execute_and_bind_the_library():
     ns = _namespace()                                      # ctypes.CDLL of the built .so + the function definitions
-    for fn in ("ohem_forward", "make_comm", "allreduce_stats", "destroy_comm"):
+    for fn in ("ohem_forward", "make_comm", "allreduce_stats", "destroy_comm", "cls_head_forward"):
         assert callable(ns[fn])
     assert ns["lib"].tsg_comm_unique_id_bytes() == 128
 
@@ -86,6 +86,13 @@ def test_section3_stubs_run_on_the_gpu(cuda):
     loss, _ = ns["ohem_forward"](pred.cuda(), target.cuda(), 255, 0.7, 2 * 32 * 48 // 16)
     ref = ohem_cross_entropy(pred, target, ignore_label=255, thresh=0.7, min_kept=2 * 32 * 48 // 16)
     assert abs(loss.item() - float(ref)) < 1e-4
+    # the classifier-head stub against torch's own 1x1 convolution on the bf16-rounded operands
+    x = torch.randn(2, 64, 16, 24, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(19, 64, 1, 1, generator=g) * 0.1).cuda()
+    b = torch.randn(19, generator=g).cuda()
+    z = ns["cls_head_forward"](x, w, b)
+    want = torch.nn.functional.conv2d(x.float(), w.bfloat16().float(), b)
+    assert z.is_contiguous() and (z.float() - want).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
     # the communicator stub on a 1-rank group, id carried by a TCPStore as the text says
     store = dist.TCPStore("127.0.0.1", _free_port(), 1, True)
     comm = ns["make_comm"](lib, store, 0, 1, 0)
