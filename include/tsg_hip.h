@@ -680,6 +680,18 @@ size_t tsg_cls_head_wgrad_ws_bytes(int64_t B, int Cin, int n_classes);
 int tsg_cls_head_wgrad(const void* dz, const void* x, float* dw, float* dbias, int64_t B, int64_t HW, int Cin, int n_classes,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * DFN's border labels — replaces, on the GPU, lines 24-29 of model/dfn/cityscapes.dfn.R101_v1c/dataloader.py
+ * (TrainPre.__call__: cv2.Canny(no255_gt, 5, 5, apertureSize=7) -> cv2.dilate(7 x 7) -> 255 becomes 1 ->
+ * random_crop_pad_to_shape(..., 255)) for one sample: gt uint8 [H][W] on the device, geom = {H, W, SH, SW, flip, crop_y,
+ * crop_x} as for tsg_augment_crop, out [CH][CW] int64 / uint8 with values {0, 1, pad_label}.  aperture must be 7 and
+ * threshold1 == threshold2 (the reference's only use).  Arithmetic of torchseg_amd/shims_optional/cv2 (OpenCV's documented
+ * Canny); parity with OpenCV's own rounding is unpinned (no cv2 in the build image). */
+size_t tsg_edge_labels_ws_bytes(int SH, int SW);
+int tsg_edge_labels(const void* gt, const int32_t* geom, const double* inv_scale, int CH, int CW, int ignore_label,
+                    int threshold1, int threshold2, int aperture, int dilate_size, int pad_label, void* out, int out_type,
+                    void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

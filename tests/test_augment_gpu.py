@@ -84,3 +84,37 @@ def test_synthetic_loader_yields_the_reference_dict(cuda):
     assert mb["data"].shape == (3, 3, 64, 64) and mb["data"].dtype == torch.float32 and mb["data"].is_cuda
     assert mb["label"].shape == (3, 64, 64) and mb["label"].dtype == torch.int64
     assert len(list(it)) == 3
+
+
+# DFN's border labels (dfn dataloader.py:24-29): bit-exact against oracle/edge_ref.py
+def _segments(h, w, seed):
+    """Label images with structure: blocky segments with some ignored pixels (a Canny of pure noise is all edges)."""
+    rng = np.random.RandomState(seed)
+    bh, bw = max(h // 6, 1), max(w // 7, 1)
+    gt = rng.randint(0, 19, size=((h + bh - 1) // bh, (w + bw - 1) // bw)).astype(np.uint8)
+    gt = np.repeat(np.repeat(gt, bh, 0), bw, 1)[:h, :w].copy()
+    gt[rng.rand(h, w) < 0.02] = 255
+    yy, xx = np.mgrid[0:h, 0:w]
+    gt[(yy - h // 2) ** 2 + (xx - w // 3) ** 2 < (min(h, w) // 5) ** 2] = 7          # a disc: every gradient direction
+    return gt
+
+
+@pytest.mark.parametrize("case", CASES[:7] + [((256, 512), (192, 192), dict(flip=True, scale=1.75, crop_y=100, crop_x=300))])
+@pytest.mark.parametrize("label_dtype", [torch.int64, torch.uint8])
+def test_dfn_edge_labels_match_oracle(cuda, case, label_dtype):
+    from oracle import edge_ref
+    from torchseg_amd.data import GpuTrainPreDFN
+    (H, W), crop, p = case
+    img, _ = _sample(H, W, H + W)
+    gt = _segments(H, W, H * 3 + W)
+    p = dict(p, sh=int(H * p["scale"]), sw=int(W * p["scale"]))
+    want = edge_ref.dfn_edge_label(gt, p, crop)
+    pre = GpuTrainPreDFN(MEAN, STD, crop, label_dtype=label_dtype)
+    data, label, aux = pre([torch.from_numpy(img).to(cuda)], [torch.from_numpy(gt).to(cuda)], params=[p])
+    assert aux.dtype == label_dtype and tuple(aux.shape) == (1,) + tuple(crop)
+    got = aux[0].cpu().numpy().astype(np.int64)
+    assert set(np.unique(got)) <= {0, 1, 255}
+    assert np.array_equal(got, want), (int((got != want).sum()), got.size)
+    assert 0 < (want == 1).mean() < 1                      # the case has edges and non-edges
+    _, want_gt = R.train_pre(img, gt, p, MEAN, STD, crop)
+    assert np.array_equal(label[0].cpu().numpy().astype(np.int64), want_gt)

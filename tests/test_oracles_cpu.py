@@ -150,3 +150,32 @@ def test_augment_oracle_geometry_matches_torch_resampling():
     a = np.arange(5 * 7).reshape(5, 7)
     p = R.pad_to_shape(a, (8, 10), 255)
     assert p.shape == (8, 10) and p[1, 1] == a[0, 0] and p[0, 0] == 255 and p[-2, -2] == 255 and p[5, 7] == a[4, 6]
+
+
+def test_edge_oracle_equals_the_cv2_stand_in_and_the_kernel_sector_rule():
+    """oracle/edge_ref.py (DFN border labels, dfn dataloader.py:24-29) against the cv2 stand-in the unchanged dataloader
+    runs on here (Canny + dilate bit-equal), and the integer / double sector rule of csrc/augment.hip's edge_sobel_k
+    against the oracle's arctan2 quantisation on every gradient pair a label image can produce nearby."""
+    import importlib.util
+    import os
+    import numpy as np
+    from oracle import edge_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cv2_standin", os.path.join(root, "torchseg_amd", "shims_optional", "cv2", "__init__.py"))
+    cv2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cv2)
+    rng = np.random.RandomState(0)
+    for (h, w) in [(40, 56), (33, 71), (8, 8)]:
+        gt = np.repeat(np.repeat(rng.randint(0, 19, size=(h // 8 + 1, w // 8 + 1)).astype(np.uint8), 8, 0), 8, 1)[:h, :w].copy()
+        a, b = cv2.Canny(gt, 5, 5, apertureSize=7), edge_ref.canny(gt, 5, 5, aperture=7)
+        assert np.array_equal(a, b)
+        assert np.array_equal(cv2.dilate(a, np.ones((7, 7), np.uint8)), edge_ref.dilate(b, 7))
+    # the kernel's sector rule: q = 0 if |gy| < tan(22.5) |gx| (or both zero), 2 if |gy| > tan(67.5) |gx|, else 1 / 3 by sign
+    gx, gy = np.meshgrid(np.arange(-600, 601, 7), np.arange(-600, 601, 5))
+    gx, gy = gx.astype(np.float64).ravel(), gy.astype(np.float64).ravel()
+    ang = (np.rad2deg(np.arctan2(gy, gx)) + 180.0) % 180.0
+    want = ((ang + 22.5) // 45).astype(int) % 4
+    a, b = np.abs(gx), np.abs(gy)
+    t1, t2 = 0.41421356237309503, 2.414213562373095
+    got = np.where((b < t1 * a) | ((a == 0) & (b == 0)), 0, np.where(b > t2 * a, 2, np.where((gx < 0) == (gy < 0), 1, 3)))
+    assert np.array_equal(got, want)

@@ -146,6 +146,8 @@ _PROTOS = {
     "tsg_xgmi_small_allreduce": (_i, [_p, _p, _i64, _p]),
     "tsg_sgd_step_dev": (_i, [_p, _p, _p, _i64, _p, _f, _f, _f, _f, _p]),
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
+    "tsg_edge_labels_ws_bytes": (_sz, [_i, _i]),
+    "tsg_edge_labels": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     "tsg_cls_head_supported": (_i, [_i, _i, _i, _i64]),
     "tsg_cls_head_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _p]),
     "tsg_cls_head_dgrad": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _p]),

@@ -146,3 +146,146 @@ int tsg_augment_crop(const void* const* imgs, const void* const* gts, const int3
 }
 
 }  // extern "C"
+
+namespace tsg {
+
+// =====================================================================================================================
+// DFN's border labels on the GPU (VERDICT r3 "missing" item 2) — restates, on the mirrored / scaled
+// label image, the lines of model/dfn/cityscapes.dfn.R101_v1c/dataloader.py:24-29:
+//     no255_gt = gt with 255 -> 0;  cgt = cv2.Canny(no255_gt, 5, 5, apertureSize=7);  cgt = cv2.dilate(cgt, 7 x 7 ones);
+//     cgt[cgt == 255] = 1;  p_cgt = random_crop_pad_to_shape(cgt, crop_pos, crop_size, 255)
+// cv2 is not in this image: the arithmetic is the one of torchseg_amd/shims_optional/cv2 (OpenCV's documented Canny:
+// separable Sobel of aperture 7 with reflect-101 borders, L1 magnitude, non-maximum suppression along the gradient
+// direction quantised to 4 sectors with `mag > n1 && mag >= n2`, hysteresis — which degenerates to `mag > threshold` when
+// both thresholds are equal, the reference's only use).  Labels are small integers, so gx / gy / |gx| + |gy| are exact in
+// int32; the sector comes from comparing |gy| with |gx| tan(22.5 deg) / tan(67.5 deg) in double, which decides exactly what
+// the stand-in's arctan2 decides (the sector borders have irrational tangents: integer gradients never sit on one).
+// Parity with OpenCV's own Canny is UNPINNED, like the rest of row f3.
+//   k1 scaled label S (nearest, mirrored, 255 -> 0)   k2 Sobel -> magnitude + sector   k3 NMS + threshold -> edge map
+//   k4 7 x 7 dilation, crop, centred padding -> aux label.   Workspace: 7 bytes per scaled pixel.
+struct EdgeGeom { int H, W, SH, SW, flip, crop_y, crop_x, top, left, ch, cw, CH, CW; double fy, fx; int thr, rad, pad_label; };
+
+__global__ __launch_bounds__(256) void edge_scale_k(const uint8_t* __restrict__ gt, uint8_t* __restrict__ S, EdgeGeom g,
+                                                    int ignore_label) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= g.SW) return;
+  int ny = (int)floor((double)y * g.fy); if (ny > g.H - 1) ny = g.H - 1;
+  int nx = (int)floor((double)x * g.fx); if (nx > g.W - 1) nx = g.W - 1;
+  if (g.flip) nx = g.W - 1 - nx;
+  const uint8_t v = gt[(int64_t)ny * g.W + nx];
+  S[(int64_t)y * g.SW + x] = v == (uint8_t)ignore_label ? (uint8_t)0 : v;
+}
+
+__device__ __forceinline__ int edge_reflect(int i, int n) {          // BORDER_REFLECT_101 (numpy "reflect")
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void edge_sobel_k(const uint8_t* __restrict__ S, int32_t* __restrict__ mag,
+                                                    uint8_t* __restrict__ sec, EdgeGeom g) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= g.SW) return;
+  const int sm[7] = {1, 6, 15, 20, 15, 6, 1}, df[7] = {1, 4, 5, 0, -5, -4, -1};
+  int cx[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) cx[j] = edge_reflect(x + j - 3, g.SW);
+  int gx = 0, gy = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const uint8_t* row = S + (int64_t)edge_reflect(y + i - 3, g.SH) * g.SW;
+    int rs = 0, rd = 0;                                              // row filtered with the smoothing / the difference taps
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const int v = row[cx[j]]; rs += sm[j] * v; rd += df[j] * v; }
+    gx += sm[i] * rd;                                                // sep(ky = smooth, kx = diff)
+    gy += df[i] * rs;                                                // sep(ky = diff, kx = smooth)
+  }
+  const int a = gx < 0 ? -gx : gx, b = gy < 0 ? -gy : gy;
+  int q;
+  const double t1 = 0.41421356237309503, t2 = 2.414213562373095;    // tan(22.5 deg), tan(67.5 deg)
+  if ((double)b < t1 * (double)a || (a == 0 && b == 0)) q = 0;
+  else if ((double)b > t2 * (double)a) q = 2;
+  else q = ((gx < 0) == (gy < 0)) ? 1 : 3;
+  mag[(int64_t)y * g.SW + x] = a + b;
+  sec[(int64_t)y * g.SW + x] = (uint8_t)q;
+}
+
+__global__ __launch_bounds__(256) void edge_nms_k(const int32_t* __restrict__ mag, const uint8_t* __restrict__ sec,
+                                                  uint8_t* __restrict__ E, EdgeGeom g) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= g.SW) return;
+  const int64_t i = (int64_t)y * g.SW + x;
+  const int m = mag[i], q = sec[i];
+  const int dy = q == 0 ? 0 : 1, dx = q == 0 ? 1 : (q == 1 ? 1 : (q == 2 ? 0 : -1));
+  auto at = [&](int yy, int xx) { return (yy < 0 || yy >= g.SH || xx < 0 || xx >= g.SW) ? 0 : mag[(int64_t)yy * g.SW + xx]; };
+  const int n1 = at(y + dy, x + dx), n2 = at(y - dy, x - dx);
+  E[i] = (m > n1 && m >= n2 && m > g.thr) ? 1 : 0;
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void edge_dilate_crop_k(const uint8_t* __restrict__ E, LT* __restrict__ out, EdgeGeom g) {
+  const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+  if (ox >= g.CW) return;
+  const int iy = oy - g.top, ix = ox - g.left;
+  LT v = (LT)g.pad_label;
+  if (iy >= 0 && iy < g.ch && ix >= 0 && ix < g.cw) {
+    const int sy = g.crop_y + iy, sx = g.crop_x + ix, lo = g.rad / 2, hi = g.rad - 1 - lo;
+    int any = 0;
+    for (int yy = sy - lo; yy <= sy + hi; ++yy) {
+      if (yy < 0 || yy >= g.SH) continue;
+      for (int xx = sx - lo; xx <= sx + hi; ++xx)
+        if (xx >= 0 && xx < g.SW) any |= E[(int64_t)yy * g.SW + xx];
+    }
+    v = (LT)any;
+  }
+  out[(int64_t)oy * g.CW + ox] = v;
+}
+
+}  // namespace tsg
+
+extern "C" {
+
+size_t tsg_edge_labels_ws_bytes(int SH, int SW) {
+  if (SH < 1 || SW < 1) return 0;
+  const size_t n = (size_t)SH * SW;
+  return ((n + 15) / 16 * 16) * 3 + n * 4 + 64;
+}
+
+int tsg_edge_labels(const void* gt, const int32_t* geom, const double* inv_scale, int CH, int CW, int ignore_label,
+                    int threshold1, int threshold2, int aperture, int dilate_size, int pad_label, void* out, int out_type,
+                    void* ws, size_t ws_bytes, void* stream) {
+  using namespace tsg;
+  if (!gt || !geom || !out || !ws) return TSG_E_NULL;
+  if (out_type != TSG_I64 && out_type != TSG_U8) return TSG_E_DTYPE;
+  if (aperture != 7 || threshold1 != threshold2 || dilate_size < 1 || dilate_size > 31 || CH < 1 || CW < 1) return TSG_E_SHAPE;
+  EdgeGeom g;
+  g.H = geom[0]; g.W = geom[1]; g.SH = geom[2]; g.SW = geom[3]; g.flip = geom[4] != 0; g.crop_y = geom[5]; g.crop_x = geom[6];
+  if (g.H < 1 || g.W < 1 || g.SH < 1 || g.SW < 1 || g.crop_y < 0 || g.crop_x < 0 || g.crop_y >= g.SH || g.crop_x >= g.SW)
+    return TSG_E_SHAPE;
+  if (ws_bytes < tsg_edge_labels_ws_bytes(g.SH, g.SW)) return TSG_E_WS;
+  g.CH = CH; g.CW = CW;
+  g.ch = g.SH - g.crop_y < CH ? g.SH - g.crop_y : CH;
+  g.cw = g.SW - g.crop_x < CW ? g.SW - g.crop_x : CW;
+  g.top = (CH - g.ch) / 2; g.left = (CW - g.cw) / 2;
+  const double isy = inv_scale ? inv_scale[0] : (double)g.SH / (double)g.H;
+  const double isx = inv_scale ? inv_scale[1] : (double)g.SW / (double)g.W;
+  if (!(isy > 0.0) || !(isx > 0.0)) return TSG_E_SHAPE;
+  g.fy = 1.0 / isy; g.fx = 1.0 / isx;
+  g.thr = threshold1; g.rad = dilate_size; g.pad_label = pad_label;
+  const size_t n = (size_t)g.SH * g.SW, na = (n + 15) / 16 * 16;
+  uint8_t* S = (uint8_t*)ws;
+  uint8_t* sec = S + na;
+  uint8_t* E = sec + na;
+  int32_t* mag = (int32_t*)(E + na);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gs((unsigned)((g.SW + 255) / 256), (unsigned)g.SH), gc((unsigned)((CW + 255) / 256), (unsigned)CH);
+  hipLaunchKernelGGL(edge_scale_k, gs, dim3(256), 0, st, (const uint8_t*)gt, S, g, ignore_label);
+  hipLaunchKernelGGL(edge_sobel_k, gs, dim3(256), 0, st, (const uint8_t*)S, mag, sec, g);
+  hipLaunchKernelGGL(edge_nms_k, gs, dim3(256), 0, st, (const int32_t*)mag, (const uint8_t*)sec, E, g);
+  if (out_type == TSG_I64) hipLaunchKernelGGL((edge_dilate_crop_k<int64_t>), gc, dim3(256), 0, st, (const uint8_t*)E, (int64_t*)out, g);
+  else hipLaunchKernelGGL((edge_dilate_crop_k<uint8_t>), gc, dim3(256), 0, st, (const uint8_t*)E, (uint8_t*)out, g);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -54,6 +54,25 @@ class GpuTrainPre(object):
         return data, label
 
 
+class GpuTrainPreDFN(GpuTrainPre):
+    """DFN's TrainPre (model/dfn/cityscapes.dfn.R101_v1c/dataloader.py:16-47): the BiSeNet pipeline plus the border label —
+    Canny(aperture 7, thresholds 5 / 5) of the mirrored / scaled label image with 255 -> 0, 7 x 7 dilation, cropped and
+    padded with 255 like the label (`extra_dict = {'aux_label': p_cgt}`).  Returns (data, label, aux_label); everything
+    stays on the GPU (round 3 left the edge label on the host)."""
+
+    edge_radius = 7                                                          # dataloader.py:20
+
+    def __call__(self, imgs, gts, params=None):
+        if params is None:
+            params = [self.draw(im.shape[:2]) for im in imgs]
+        data, label = super().__call__(imgs, gts, params)
+        geom = np.array([[im.shape[0], im.shape[1], p["sh"], p["sw"], int(p["flip"]), p["crop_y"], p["crop_x"]]
+                         for im, p in zip(imgs, params)], dtype=np.int32)
+        aux = K.provider().edge_labels(gts, geom, self.crop_size, ignore_label=255, threshold=5, aperture=7,
+                                       dilate_size=self.edge_radius, pad_label=255, label_dtype=self.label_dtype)
+        return data, label, aux
+
+
 class SyntheticSegLoader(object):
     """Endless loader of synthetic Cityscapes-shaped samples kept in HBM as uint8, augmented on the GPU per batch."""
 

@@ -869,6 +869,27 @@ class HipKernels:
                                               L.stream_ptr(out)), "tsg_augment_crop")
         return out, lab
 
+    def edge_labels(self, gts, geom, crop_hw, ignore_label=255, threshold=5, aperture=7, dilate_size=7, pad_label=255,
+                    label_dtype=torch.int64):
+        """DFN's border labels (dfn dataloader.py:24-29) for n samples: gts[i] uint8 [H,W] on the GPU, geom int32 [n,7] as
+        for augment_crop -> [n, CH, CW] with values {0, 1, pad_label}."""
+        import numpy as np
+        n = len(gts)
+        CH, CW = int(crop_hw[0]), int(crop_hw[1])
+        dev = gts[0].device
+        geom = np.ascontiguousarray(geom, dtype=np.int32).reshape(n, 7)
+        out = torch.empty((n, CH, CW), dtype=label_dtype, device=dev)
+        for i in range(n):
+            if gts[i].dtype != torch.uint8 or not gts[i].is_contiguous() or not gts[i].is_cuda:
+                raise L.TsgError("edge_labels takes contiguous uint8 tensors on the GPU")
+            wsb = self.lib.tsg_edge_labels_ws_bytes(int(geom[i, 2]), int(geom[i, 3]))
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            L.check(self.lib.tsg_edge_labels(gts[i].data_ptr(), geom[i].ctypes.data, None, CH, CW, int(ignore_label),
+                                             int(threshold), int(threshold), int(aperture), int(dilate_size), int(pad_label),
+                                             out[i].data_ptr(), _label_code(out), ws.data_ptr(), wsb, L.stream_ptr(out)),
+                    "tsg_edge_labels")
+        return out
+
     def resize_bilinear_hp(self, x, OH, OW, out=None, accumulate=False):
         """x [..., IH, IW] f32 / bf16 contiguous -> fp32 [..., OH, OW], half-pixel centres (cv2 INTER_LINEAR on float data)"""
         _require_contiguous(x)

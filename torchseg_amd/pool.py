@@ -12,6 +12,11 @@ import torch.nn as nn
 from . import kernels as K
 
 
+import os as _os
+# TSG_GAP_BWD_EXPAND=1|0 (default 1): the gradient of the global average pool as a broadcast view (see _GapFn.backward)
+_GAP_BWD_EXPAND = _os.environ.get("TSG_GAP_BWD_EXPAND", "1") != "0"
+
+
 class _GapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -30,6 +35,15 @@ class _GapFn(torch.autograd.Function):
         kp = K.provider()
         (x,) = ctx.saved_tensors
         layout, N, C, HW = ctx.cfg
+        if _GAP_BWD_EXPAND:
+            # d x[n, c, h, w] = dout[n, c] / HW for every pixel: hand autograd the BROADCAST VIEW instead of a
+            # materialised tensor.  The pooled map always has a second consumer here (the squeeze-excite branches of
+            # seg_oprs.py:192-238 gate the map they pool), so the engine's gradient accumulation reads the other gradient
+            # + C values per sample instead of two full tensors, and gap_bwd's write of the full map disappears
+            # (round 4: 4 launches + a third of 9 adds' traffic per BiSeNet step).  A consumer that needs a dense tensor
+            # materialises it exactly as before.
+            g = (dout.reshape(N, C).float() * (1.0 / HW)).to(x.dtype)
+            return g.view(N, C, 1, 1).expand(N, C, x.shape[2], x.shape[3])
         dout = dout.reshape(N, C).to(x.dtype).contiguous()
         return kp.gap_bwd(dout, x, layout, N, C, HW)
 
