@@ -339,6 +339,9 @@ int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int 
  *     zero padding stays zero.  addend (may be NULL; not together with partial): [B,H,W,Cout] bf16,
  *     y = bf16(bf16(conv) + addend) — used for the data gradient of a residual block's first convolution, where the
  *     gradient of the skip connection (resnet.py:48-52) is added in the epilogue instead of by a separate pass.
+ *   tsg_conv3x3_gen_variant: which of the two kernels the forward call runs for a problem (0: 8-row pixel tiles; 1: the
+ *     16-row tiles with all staging by LDS-DMA, taken when they fill the GPU and in_ab is not given) — informational, for
+ *     tests and benchmarks; results and the partial's row count do not depend on it beyond fp32 summation order.
  * ---------------------------------------------------------------------- */
 int tsg_conv3x3_gen_supported(int dtype, int Cin, int Cout, int kh, int kw, int stride, int pad, int dilation,
                               int groups);
@@ -346,6 +349,7 @@ int64_t tsg_conv3x3_gen_filter_elems(int Cin, int Cout);
 int tsg_conv3x3_gen_tile(int64_t B, int64_t H, int64_t W, int Cin, int Cout);
 int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int I, int mode, int BN, void* stream);
 int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN);
+int tsg_conv3x3_gen_variant(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, int with_in_ab);
 int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, const void* addend,
                         int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream);
 

@@ -219,6 +219,10 @@ def test_bench_geometry_forward_stats_dgrad_addend(cuda, geom):
     from torchseg_amd import kernels as K
     kp = K.provider()
     B, Cin, Cout, S = geom
+    # which kernel the step runs at this geometry: the 16-row / LDS-DMA kernel wherever its tiles fill 2 x 256 block slots
+    assert kp.conv3x3_gen_variant(B, S, S, Cin, Cout) == (0 if S == 32 else 1)
+    assert kp.conv3x3_gen_variant(B, S, S, Cout, Cin) == (0 if S == 32 else 1)      # the data gradient
+    assert kp.conv3x3_gen_variant(B, S, S, Cin, Cout, with_in_ab=True) == 0
     g = torch.Generator(device=cuda).manual_seed(Cin + Cout + S)
     x = torch.randn(B, Cin, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g, device=cuda) * (2.0 / (9 * Cin)) ** 0.5).contiguous(memory_format=torch.channels_last)
@@ -247,3 +251,77 @@ def test_bench_geometry_forward_stats_dgrad_addend(cuda, geom):
     _vs_library(dx, lib)
     dxa = kp.conv3x3_gen_fwd(dy, wf1, Cin, addend=skip)
     assert torch.equal(dxa, dx + skip)                      # bf16(bf16(conv) + addend): what the eager add computes
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# conv3h_fwd_k (16-row tiles, both operands by LDS-DMA, zero padding = out-of-range buffer offsets) forced onto small and
+# ragged problems: TSG_CONV3G_V2=2.  Partial tiles in both directions, one tile column / several, fewer tiles than block
+# slots (idle blocks must write zero partial rows), one oc tile / several, two chunks / many.
+V2_SHAPES = [(2, 128, 128, 8, 32), (2, 64, 128, 19, 70), (1, 128, 256, 16, 64), (3, 256, 64, 9, 33), (1, 512, 512, 8, 32),
+             (1, 32, 192, 1, 1), (2, 128, 128, 24, 96), (1, 32, 64, 37, 45), (2, 96, 64, 33, 31), (1, 192, 64, 17, 65)]
+
+
+@pytest.fixture
+def sixteen_row_kernel(monkeypatch):
+    from torchseg_amd import kernels as K
+    monkeypatch.setenv("TSG_CONV3G_BN", "64")
+    monkeypatch.setenv("TSG_CONV3G_V2", "2")
+    K.provider()._npart.clear()
+    yield
+    K.provider()._npart.clear()
+
+
+@pytest.mark.parametrize("shape", V2_SHAPES)
+def test_sixteen_row_kernel_forward_stats_dgrad_addend_vs_oracle(cuda, shape, sixteen_row_kernel):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    assert kp.conv3x3_gen_variant(B, H, W, Cin, Cout) == 1
+    x, w, xb, wd = _operands(cuda, *shape, seed=sum(shape) + 1)
+    wf = kp.conv3x3_gen_prep_filter(wd, 0, xb)
+    y, partial = kp.conv3x3_gen_fwd(xb, wf, Cout, with_stats=True)
+    y_ref = conv_ref.conv2d_ref(conv_ref.bf16_round(x), conv_ref.bf16_round(w), stride=1, pad=1)
+    _check(y, y_ref)
+    y2, p2 = kp.conv3x3_gen_fwd(xb, wf, Cout, with_stats=True)
+    assert torch.equal(y, y2) and torch.equal(partial, p2) and torch.equal(y, kp.conv3x3_gen_fwd(xb, wf, Cout))
+    yf = y.double().cpu()
+    ref = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    np.testing.assert_allclose(partial.double().sum(0).cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-3)
+    # data gradient = the same kernel on dy with the mode-1 filter; with the skip connection's gradient as addend
+    if Cin % 64:
+        return                                              # (its output channels are this convolution's inputs)
+    assert kp.conv3x3_gen_variant(B, H, W, Cout, Cin) == 1
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    wf1 = kp.conv3x3_gen_prep_filter(wd, 1, dyb)
+    dx = kp.conv3x3_gen_fwd(dyb, wf1, Cin)
+    xr = conv_ref.bf16_round(x).double().requires_grad_(True)
+    F.conv2d(xr, conv_ref.bf16_round(w).double(), None, 1, 1).backward(conv_ref.bf16_round(dy).double())
+    _check(dx, xr.grad)
+    skip = torch.randn(B, Cin, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(kp.conv3x3_gen_fwd(dyb, wf1, Cin, addend=skip), dx + skip)
+
+
+def test_sixteen_row_kernel_against_the_eight_row_kernel(cuda, monkeypatch):
+    """The two kernels walk the nine taps of a chunk in different orders (kernel-row-major / column-shift-major), so their
+    fp32 accumulations differ in the last bits: y equal to a bf16 ulp at a few rounding boundaries."""
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    shape = (4, 128, 128, 40, 70)
+    x, w, xb, wd = _operands(cuda, *shape, seed=21)
+    monkeypatch.setenv("TSG_CONV3G_BN", "64")
+    out = {}
+    for v2 in ("0", "2"):
+        monkeypatch.setenv("TSG_CONV3G_V2", v2)
+        kp._npart.clear()
+        assert kp.conv3x3_gen_variant(4, 40, 70, 128, 128) == (1 if v2 == "2" else 0)
+        out[v2] = kp.conv3x3_gen_fwd(xb, kp.conv3x3_gen_prep_filter(wd, 0, xb), 128, with_stats=True)
+    kp._npart.clear()
+    _vs_library(out["2"][0], out["0"][0])
+    assert (out["2"][0] != out["0"][0]).float().mean().item() < 0.05     # a rounding boundary now and then, not a different result
+    for v2 in ("0", "2"):                                    # each partial belongs to its own y (which differ in those few roundings)
+        yf = out[v2][0].double()
+        ref = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).cpu()
+        np.testing.assert_allclose(out[v2][1].double().sum(0).cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-3)
+    assert out["0"][1].shape == out["2"][1].shape            # same rows whichever kernel runs

@@ -29,6 +29,7 @@
 // x, y: NHWC bf16.  wf: the prepared filter.  fp32 accumulation, one rounding to bf16 at the store.
 #include "tsg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace tsg {
 
@@ -308,6 +309,223 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3g_fwd_k(const bf16_t* __restr
   }
 }
 
+// ---- second structure for the large maps (>= 512 block tiles of 64 oc x 16 x 32 pixels): conv3h_fwd_k ----------------
+// Counters of the kernel above on the 128-channel / 128^2 layers (profiles/r03_conv3g_sq_counters.txt): MFMA pipe busy 0.52,
+// the waves wait for instruction issue 43 % of their cycles.  The ISA of its K loop shows why: per chunk of 36 MFMAs a wave
+// runs ~75 address / bounds / branch instructions for its three patch loads and five DMA pieces, then waits for 16 fragment
+// reads with nothing to issue, then 3 ds_write_b128 behind exec branches, then the barrier: roughly 700 cycles of overhead
+// against 1,152 cycles of MFMA, and two waves per SIMD do not interleave well enough to hide that.  This kernel halves the
+// overhead per MFMA and removes the per-chunk VALU work:
+//   * a wave owns 64 oc x 4 rows x 32 pixels = 8 accumulators: 72 MFMAs (2,304 cycles) per chunk and barrier, 36 fragment
+//     reads instead of 60 for the same MFMAs (the six patch rows of one column shift serve three kernel rows);
+//   * BOTH operands arrive by LDS-DMA (buffer_load_dwordx4 ... lds): the filter slab as before, the (16+2) x (32+2) x 16
+//     patch as 20 pieces of 1 KB whose per-lane source offsets are computed ONCE per tile; out-of-image pixels carry an
+//     offset beyond the buffer's num_records, for which the load returns zeros (the padding), so a chunk's staging is ten
+//     DMA instructions per wave with an SGPR chunk offset: no registers, no ds_write, no branches;
+//   * the patch is stored unpadded (32 B per pixel) so that 2 x (filter + patch) = 76 KB and two blocks still share a CU;
+//     the B-fragment reads are then 2-way bank conflicted (8 LDS cycles instead of 4), which the LDS pipe has to spare
+//     (it is ~35 % busy with them);
+//   * the DMA pieces of chunk c+1 are issued between the first MFMA groups of chunk c, the fragment reads of MFMA group
+//     s+1 before group s: after the eight reads that open a chunk every instruction sits in an MFMA shadow;
+//   * STATS: the channel sums of a tile are folded across lanes (same 16-byte part) and waves through a 2 KB corner of
+//     LDS into ONE register per thread instead of sixteen.
+// Same prepared filter (BN = 64 layout), same partial[slot][2][C_out] contract and slot count as conv3g_fwd_k.
+constexpr int H3_TH = 16, H3_PH = H3_TH + 2;             // output rows per tile, patch rows
+constexpr int H3_NPX = H3_PH * G3_PW;                    // 612 patch pixels
+constexpr int H3_PPIECES = 20;                           // 1 KB DMA pieces of a patch chunk (612 x 32 B = 19,584 B)
+constexpr int H3_PBYTES = H3_PPIECES * 1024;
+constexpr int H3_FBYTES = 9 * 64 * G3_KC * 2;            // 18,432
+constexpr int H3_FPIECES = H3_FBYTES / 1024;             // 18
+constexpr int H3_OS = 72;                                // epilogue staging: bf16 per pixel row
+constexpr int H3_RED = 2 * H3_FBYTES + 2 * H3_PBYTES;               // float [4 waves][2][64] behind the staging buffers
+constexpr size_t H3_LDS = H3_RED + 2048;                           // 79,872 B: two blocks per CU (<= 81,920 each)
+static_assert(512 * H3_OS * 2 <= H3_RED, "the output tile is staged in the filter and patch buffers");
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void conv3h_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                        bf16_t* __restrict__ y, G3Geom g, float* __restrict__ partial,
+                                                        const bf16_t* __restrict__ addend) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char h3_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int oct = jb % g.noct, slot = (jb / g.noct) * 8 + xcd;
+  bf16_t* outs = reinterpret_cast<bf16_t*>(h3_smem);
+  float* red = reinterpret_cast<float*>(h3_smem + H3_RED);
+
+  // the block's filter slabs [chunk][tap][ocb][lane][8] as one buffer; piece q of chunk c at byte (c 18 + q) 1024
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(wf + (int64_t)oct * g.nchunks * (H3_FBYTES / 2)), 0, g.nchunks * H3_FBYTES, 0x00020000);
+  const unsigned char* fa = h3_smem + lane * 16;                                           // A fragment (tap, ocb) at + (tap 2 + ocb) 1024
+  const unsigned char* pb = h3_smem + 2 * H3_FBYTES + ((4 * wave) * G3_PW + p) * 32 + half * 16;   // B (row, shift) at + (row 34 + shift) 32
+
+  float stacc = 0.f;                                     // STATS: thread (c = tid & 63, which = tid >> 6 & 1) of the first 128
+  bool red_full = false;
+
+  for (int tile = slot; tile < g.ntiles; tile += g.nslots) {
+    const int ow0 = (tile % g.tiles_w) * G3_TW, oh0 = ((tile / g.tiles_w) % g.tiles_h) * H3_TH;
+    const int bimg = tile / (g.tiles_w * g.tiles_h);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (int64_t)bimg * g.H * g.W * g.Cin), 0, g.H * g.W * g.Cin * 2, 0x00020000);
+    int voff[5];                                          // patch piece wave + 4 u: this lane's 16 bytes
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int v = (wave + 4 * u) * 64 + lane, q = v >> 1;
+      const int ih = oh0 - 1 + q / G3_PW, iw = ow0 - 1 + q % G3_PW;
+      const bool ok = q < H3_NPX && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+      voff[u] = ok ? (ih * g.W + iw) * g.Cin * 2 + (v & 1) * 16 : (int)0x80000000;
+    }
+    auto dma_patch = [&](int u, int chunk, int buf) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(h3_smem + 2 * H3_FBYTES + buf * H3_PBYTES + (wave + 4 * u) * 1024),
+                                               16, voff[u], chunk * (G3_KC * 2), 0, 0);
+    };
+    auto dma_filter = [&](int u, int chunk, int buf) {
+      const int q = wave + 4 * u;
+      if (u < 4 || q < H3_FPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(h3_smem + buf * H3_FBYTES + q * 1024), 16, lane * 16,
+                                                 (chunk * H3_FPIECES + q) * 1024, 0, 0);
+    };
+
+    g3_f32x16 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    __syncthreads();                                     // the previous tile's epilogue is done with LDS
+    if (STATS && red_full && tid < 128) {                // fold the previous tile's four wave sums (order fixed)
+      const int c = tid & 63, which = tid >> 6;
+      stacc += (red[(0 * 2 + which) * 64 + c] + red[(1 * 2 + which) * 64 + c]) +
+               (red[(2 * 2 + which) * 64 + c] + red[(3 * 2 + which) * 64 + c]);
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) dma_patch(u, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) dma_filter(u, 0, 0);
+    __syncthreads();                                     // (waits for the DMA: vmcnt(0) in front of the barrier)
+
+    auto chunk_body = [&](auto BUFC, int c) {
+      constexpr int buf = decltype(BUFC)::value;
+      const bool more = c + 1 < g.nchunks;
+      const unsigned char* fab = fa + buf * H3_FBYTES;
+      const unsigned char* pbb = pb + buf * H3_PBYTES;
+      g3_bf16x8 bq[2][6], af[2][2];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) bq[0][r] = *reinterpret_cast<const g3_bf16x8*>(pbb + (r * G3_PW) * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) af[0][j] = *reinterpret_cast<const g3_bf16x8*>(fab + j * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {                      // MFMA group s: column shift kw = s / 3, kernel row kh = s % 3
+        const int kw = s / 3, kh = s % 3;
+        if (s + 1 < 9) {
+          const int t1 = ((s + 1) % 3) * 3 + (s + 1) / 3;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) af[(s + 1) & 1][j] = *reinterpret_cast<const g3_bf16x8*>(fab + (t1 * 2 + j) * 1024);
+        }
+        if (kw + 1 < 3) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            bq[(kw + 1) & 1][2 * kh + e] = *reinterpret_cast<const g3_bf16x8*>(pbb + ((2 * kh + e) * G3_PW + kw + 1) * 32);
+        }
+        if (more) {                                      // chunk c + 1: the patch (HBM / L2) first, the filter (L2) behind it
+          if (s == 0) { dma_patch(0, c + 1, buf ^ 1); dma_patch(1, c + 1, buf ^ 1); }
+          if (s == 1) { dma_patch(2, c + 1, buf ^ 1); dma_patch(3, c + 1, buf ^ 1); }
+          if (s == 2) { dma_patch(4, c + 1, buf ^ 1); dma_filter(0, c + 1, buf ^ 1); }
+          if (s == 3) { dma_filter(1, c + 1, buf ^ 1); dma_filter(2, c + 1, buf ^ 1); }
+          if (s == 4) { dma_filter(3, c + 1, buf ^ 1); dma_filter(4, c + 1, buf ^ 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][j], bq[kw & 1][i + kh], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+    for (int c = 0; c < g.nchunks; c += 2) {             // nchunks is even (host check): buffer indices are immediates
+      chunk_body(std::integral_constant<int, 0>{}, c);
+      chunk_body(std::integral_constant<int, 1>{}, c + 1);
+    }
+
+    // ---- epilogue: acc[j][i][r] is oc = j 32 + (r & 3) + 8 (r >> 2) + 4 half, pixel (row 4 wave + i, column p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2 v;
+          v.x = pack2_bf16(acc[j][i][4 * gq + 0], acc[j][i][4 * gq + 1]);
+          v.y = pack2_bf16(acc[j][i][4 * gq + 2], acc[j][i][4 * gq + 3]);
+          *reinterpret_cast<uint2*>(outs + ((4 * wave + i) * G3_TW + p) * H3_OS + j * 32 + 8 * gq + 4 * half) = v;
+        }
+    __syncthreads();
+    const int64_t img_off = (int64_t)bimg * g.H * g.W * g.Cout + oct * 64;
+    bf16_t* yimg = y + img_off;
+    float st1[8], st2[8];
+    if (STATS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
+    }
+    const int part = tid & 7;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int px = (tid >> 3) + 32 * k;
+      const int oh = oh0 + (px >> 5), ow = ow0 + (px & 31);
+      if (oh < g.H && ow < g.W) {
+        uint4 o = *reinterpret_cast<const uint4*>(outs + px * H3_OS + part * 8);
+        const int64_t off = ((int64_t)oh * g.W + ow) * g.Cout + part * 8;
+        if (addend) o = g3_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + img_off + off));
+        *reinterpret_cast<uint4*>(yimg + off) = o;
+        if (STATS) {
+          const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+            st1[2 * e] += lo; st2[2 * e] = fmaf(lo, lo, st2[2 * e]);
+            st1[2 * e + 1] += hi; st2[2 * e + 1] = fmaf(hi, hi, st2[2 * e + 1]);
+          }
+        }
+      }
+    }
+    if (STATS) {                                         // lanes with the same part: xor 8, 16, 32; lanes 0-7 write the wave's sums
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+          st1[e] += __shfl_xor(st1[e], m);
+          st2[e] += __shfl_xor(st2[e], m);
+        }
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[(wave * 2 + 0) * 64 + part * 8 + e] = st1[e];
+          red[(wave * 2 + 1) * 64 + part * 8 + e] = st2[e];
+        }
+      }
+      red_full = true;
+    }
+  }
+
+  if (STATS) {
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;
+      if (red_full)
+        stacc += (red[(0 * 2 + which) * 64 + c] + red[(1 * 2 + which) * 64 + c]) +
+                 (red[(2 * 2 + which) * 64 + c] + red[(3 * 2 + which) * 64 + c]);
+      partial[((int64_t)slot * 2 + which) * g.Cout + oct * 64 + c] = stacc;
+    }
+  }
+}
+
 // ---- filter preparation: fp32 / bf16 master weight [O][3][3][I] (channels_last filter) -> bf16 in fragment order
 //   out[oc tile][chunk][tap][ocb][lane][e] = W'[oc = tile BN + ocb 32 + (lane & 31)][tap][ci = chunk 16 + (lane >> 5) 8 + e]
 // mode 0: W' = w (forward: C_out' = O, C_in' = I).
@@ -391,6 +609,24 @@ static int g3_geom(G3Geom* g, int64_t B, int64_t H, int64_t W, int Cin, int Cout
   return 0;
 }
 
+// conv3h_fwd_k (16-row tiles, 8 accumulators per wave) takes the problem when its tiles fill the two-blocks-per-CU grid:
+// >= 512 block tiles (BiSeNet-R18 at the bench shape: every 128^2 layer, the 64^2 layers with >= 256 output channels).
+// Not with normalise-on-load (the patch bypasses the registers) and not with 128-wide filter layouts.  The slot count
+// equals conv3g_fwd_k's for the same problem, so the statistics partial has the same rows whichever kernel runs.
+// TSG_CONV3G_V2=0 keeps every problem on conv3g_fwd_k, =2 sends every problem it can run to conv3h_fwd_k (tests).
+static bool g3_v2_geom(G3Geom* g, int BN) {
+  const char* e = getenv("TSG_CONV3G_V2");               // 0: never, 1 (default): where it fills the grid, 2: wherever it can run
+  const int on = e ? atoi(e) : 1;
+  if (!on || BN != 64 || g3_nw(64) != 4 || (g->nchunks & 1)) return false;
+  const int64_t th = (g->H + H3_TH - 1) / H3_TH;
+  const int64_t nt = (int64_t)g->B * th * g->tiles_w;
+  if ((int64_t)g->H * g->W * g->Cin * 2 > 0x7fffffffLL || (int64_t)g->nchunks * H3_FBYTES > 0x7fffffffLL) return false;
+  if (on != 2 && (nt < g->nslots || nt * g->noct < 512)) return false;
+  g->tiles_h = (int)th;
+  g->ntiles = (int)nt;
+  return true;
+}
+
 }  // namespace tsg
 
 using namespace tsg;
@@ -434,6 +670,15 @@ int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int 
   return 0;
 }
 
+/* which kernel tsg_conv3x3_gen_fwd runs for this problem: 0 = conv3g_fwd_k (8-row tiles), 1 = conv3h_fwd_k (16-row tiles,
+ * all staging by LDS-DMA; never with in_ab).  Negative = error code. */
+int tsg_conv3x3_gen_variant(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, int with_in_ab) {
+  G3Geom g;
+  int e = g3_geom(&g, B, H, W, Cin, Cout, BN);
+  if (e) return e;
+  return (!with_in_ab && g3_v2_geom(&g, BN)) ? 1 : 0;
+}
+
 /* rows of the statistics partial the forward writes when `partial` is given: partial[rows][2][Cout] */
 int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN) {
   G3Geom g;
@@ -467,7 +712,19 @@ int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, 
   } while (0)
 #define G3_PICK(BNN, NWW)                                                                                           \
   do { if (g3_glds()) G3_PICK2(BNN, NWW, true); else G3_PICK2(BNN, NWW, false); } while (0)
-  if (BN == 128) G3_PICK(128, 8);
+  if (!in_ab && g3_v2_geom(&g, BN)) {
+    if (partial) {
+      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3h_fwd_k<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)H3_LDS));
+      hipLaunchKernelGGL((conv3h_fwd_k<true>), dim3(grid), dim3(256), H3_LDS, st, (const bf16_t*)x, (const bf16_t*)wf,
+                         (bf16_t*)y, g, partial, (const bf16_t*)addend);
+    } else {
+      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3h_fwd_k<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)H3_LDS));
+      hipLaunchKernelGGL((conv3h_fwd_k<false>), dim3(grid), dim3(256), H3_LDS, st, (const bf16_t*)x, (const bf16_t*)wf,
+                         (bf16_t*)y, g, partial, (const bf16_t*)addend);
+    }
+  } else if (BN == 128) G3_PICK(128, 8);
   else if (g3_nw(64) == 8) G3_PICK(64, 8);
   else G3_PICK(64, 4);
 #undef G3_PICK

@@ -715,6 +715,13 @@ class HipKernels:
         return self._count(("g3_tile", B, H, W, Cin, Cout), lambda: self.lib.tsg_conv3x3_gen_tile(B, H, W, Cin, Cout),
                            "tsg_conv3x3_gen_tile")
 
+    def conv3x3_gen_variant(self, B, H, W, Cin, Cout, with_in_ab=False):
+        """0: 8-row pixel tiles (conv3g_fwd_k), 1: 16-row tiles with all staging by LDS-DMA (conv3h_fwd_k)"""
+        v = self.lib.tsg_conv3x3_gen_variant(B, H, W, Cin, Cout, self.conv3x3_gen_tile(B, H, W, Cin, Cout), int(bool(with_in_ab)))
+        if v < 0:
+            L.check(v, "tsg_conv3x3_gen_variant")
+        return v
+
     def conv3x3_gen_prep_filter(self, weight, mode, like):
         """weight [O,I,3,3] channels_last (fp32 master or bf16) -> (wf, BN): the bf16 filter in MFMA fragment order for
         the convolution that will read `like` ([B,C,H,W]): mode 0 for conv(x, w), mode 1 for the data gradient
