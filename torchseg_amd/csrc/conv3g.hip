@@ -455,24 +455,24 @@ __global__ __launch_bounds__(256, 2) void conv3h_fwd_k(const bf16_t* __restrict_
 
     // ---- epilogue: acc[j][i][r] is oc = j 32 + (r & 3) + 8 (r >> 2) + 4 half, pixel (row 4 wave + i, column p)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 4; ++i) {
+      // STATS: pixels of a partial tile that lie outside the image are staged as zeros (they are not stored, and the
+      // statistics below read the staged tile)
+      const bool inside = !STATS || (oh0 + 4 * wave + i < g.H && ow0 + p < g.W);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           uint2 v;
           v.x = pack2_bf16(acc[j][i][4 * gq + 0], acc[j][i][4 * gq + 1]);
           v.y = pack2_bf16(acc[j][i][4 * gq + 2], acc[j][i][4 * gq + 3]);
+          if (!inside) v = make_uint2(0u, 0u);
           *reinterpret_cast<uint2*>(outs + ((4 * wave + i) * G3_TW + p) * H3_OS + j * 32 + 8 * gq + 4 * half) = v;
         }
+    }
     __syncthreads();
     const int64_t img_off = (int64_t)bimg * g.H * g.W * g.Cout + oct * 64;
     bf16_t* yimg = y + img_off;
-    float st1[8], st2[8];
-    if (STATS) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
-    }
     const int part = tid & 7;
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {
@@ -483,32 +483,49 @@ __global__ __launch_bounds__(256, 2) void conv3h_fwd_k(const bf16_t* __restrict_
         const int64_t off = ((int64_t)oh * g.W + ow) * g.Cout + part * 8;
         if (addend) o = g3_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + img_off + off));
         *reinterpret_cast<uint4*>(yimg + off) = o;
-        if (STATS) {
-          const uint32_t w[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-            st1[2 * e] += lo; st2[2 * e] = fmaf(lo, lo, st2[2 * e]);
-            st1[2 * e + 1] += hi; st2[2 * e + 1] = fmaf(hi, hi, st2[2 * e + 1]);
-          }
-        }
       }
     }
-    if (STATS) {                                         // lanes with the same part: xor 8, 16, 32; lanes 0-7 write the wave's sums
+    if (STATS) {
+      // Channel sums of the staged (bf16-rounded) tile ON THE MATRIX CORES: the wave's 128 pixels are the K dimension.  A
+      // transposing read (the weight-gradient kernel's recipe, csrc/conv3wrw.hip) hands lane (c, half) the channel
+      // cb 32 + c at 8 pixels; that register is both the A fragment Y^T[c][pixel] and the B fragment Y[pixel][c], so
+      //   ones x Y  -> every row of D1 holds sum_px y[px][c]            (row 0: lanes 0-31, register 0)
+      //   Y^T x Y   -> the diagonal of D2 holds sum_px y[px][c]^2       (exact products of bf16, fp32 accumulation)
+      // 32 MFMAs + 32 LDS reads per wave and tile; the VALU version (unpack, add, fma per element and 48 cross-lane
+      // shuffles) cost ~15 us of an 85-us launch (profiles/r04_conv3h.txt).
+      typedef short h3_v4i16 __attribute__((ext_vector_type(4)));
+      typedef h3_v4i16 __attribute__((address_space(3))) h3_lds_v4i16;
+      const int sub = (lane >> 4) & 1, i16 = lane & 15;
+      const bf16_t* fr = outs + (128 * wave + 8 * half + (i16 >> 2)) * H3_OS + 16 * sub + 4 * (i16 & 3);
+      g3_f32x16 d1[2], d2[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int m = 8; m < 64; m <<= 1) {
-          st1[e] += __shfl_xor(st1[e], m);
-          st2[e] += __shfl_xor(st2[e], m);
+        for (int r = 0; r < 16; ++r) { d1[cb][r] = 0.f; d2[cb][r] = 0.f; }
+      union { uint32_t u[4]; g3_bf16x8 v; } ones;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ones.u[e] = 0x3f803f80u;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          union { h3_v4i16 q[2]; g3_bf16x8 v; } f;
+          f.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h3_lds_v4i16*)(fr + (ks * 16 + 0) * H3_OS + cb * 32));
+          f.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h3_lds_v4i16*)(fr + (ks * 16 + 4) * H3_OS + cb * 32));
+          d1[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones.v, f.v, d1[cb], 0, 0, 0);
+          d2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, f.v, d2[cb], 0, 0, 0);
         }
-      }
-      if (lane < 8) {
+      // D row (r & 3) + 8 (r >> 2) + 4 half, column lane & 31: channel c's diagonal element sits in the lane with
+      // half == (c >> 2 & 1), register (c & 3) + 4 (c >> 3)
+      const int c = lane & 31, rc = (c & 3) + 4 * (c >> 3);
+      const bool mine = half == ((c >> 2) & 1);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          red[(wave * 2 + 0) * 64 + part * 8 + e] = st1[e];
-          red[(wave * 2 + 1) * 64 + part * 8 + e] = st2[e];
-        }
+      for (int cb = 0; cb < 2; ++cb) {
+        float sq = d2[cb][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) sq = rc == r ? d2[cb][r] : sq;
+        if (half == 0) red[(wave * 2 + 0) * 64 + cb * 32 + c] = d1[cb][0];
+        if (mine) red[(wave * 2 + 1) * 64 + cb * 32 + c] = sq;
       }
       red_full = true;
     }
