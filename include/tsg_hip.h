@@ -685,6 +685,18 @@ int tsg_cls_head_wgrad(const void* dz, const void* x, float* dw, float* dbias, i
                        void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * 1x1 convolution of a globally pooled map (csrc/vecconv.hip) — replaces the cuDNN calls behind the bias-free
+ * `ConvBnRelu(C_in, C_out, 1, 1, 0)` layers that follow `nn.AdaptiveAvgPool2d(1)`: furnace/seg_opr/seg_oprs.py:199-205
+ * (AttentionRefinement.channel_attention), :222-231 (FeatureFusion.channel_attention), bisenet network.py:34-39
+ * (global_context), and of their backward.  x / dx: bf16 [B, C_in]; y / dy: bf16 [B, C_out]; w: fp32 [C_out, C_in]
+ * (rounded to bf16 inside, as autocast would), dw: fp32 [C_out, C_in] (not rounded).  B <= 32; C_in, C_out multiples
+ * of 16.  fp32 accumulation, fixed summation order.  dx may be NULL (input needs no gradient). */
+int tsg_conv1x1_vec_supported(int B, int Cin, int Cout);
+int tsg_conv1x1_vec_fwd(const void* x, const float* w, void* y, int B, int Cin, int Cout, void* stream);
+int tsg_conv1x1_vec_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int B, int Cin, int Cout,
+                        void* stream);
+
+/* ------------------------------------------------------------------------
  * DFN's border labels — replaces, on the GPU, lines 24-29 of model/dfn/cityscapes.dfn.R101_v1c/dataloader.py
  * (TrainPre.__call__: cv2.Canny(no255_gt, 5, 5, apertureSize=7) -> cv2.dilate(7 x 7) -> 255 becomes 1 ->
  * random_crop_pad_to_shape(..., 255)) for one sample: gt uint8 [H][W] on the device, geom = {H, W, SH, SW, flip, crop_y,

@@ -149,6 +149,9 @@ _PROTOS = {
     "tsg_sgd_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
     "tsg_edge_labels_ws_bytes": (_sz, [_i, _i]),
     "tsg_edge_labels": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
+    "tsg_conv1x1_vec_supported": (_i, [_i, _i, _i]),
+    "tsg_conv1x1_vec_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "tsg_conv1x1_vec_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tsg_cls_head_supported": (_i, [_i, _i, _i, _i64]),
     "tsg_cls_head_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _p]),
     "tsg_cls_head_dgrad": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _p]),

@@ -57,6 +57,8 @@ upsample overrides.  Controlled by env so train.py needs no edit:
                         TSG_CONV_WRW_IMPL=tr|v1 picks the kernel variant, default tr)
   TSG_CLS_HEAD=1|0      (default 1 on GPU: the 1x1 classifier convolution of a head (<= 32 classes) on tsg_cls_head_*:
                         planar logits for the criterion kernels, no layout copies, no separate bias passes; clshead.py)
+  TSG_VEC_CONV=1|0      (default 1 on GPU: bias-free 1x1 convolutions applied to pooled [B, C, 1, 1] maps (channel attention,
+                        global context) on tsg_conv1x1_vec_*: one launch forward, one backward, fp32 master weight; vecconv.py)
   TSG_FP32_EXACT=1|0    (default 1: with TSG_DTYPE=fp32 every convolution runs on tsg_conv2d_f32_exact_* — exact products,
                         fp64 accumulation — instead of the vendor library's fp32 kernels: the parity mode, exactconv.py)
 """
@@ -396,6 +398,9 @@ class DistributedDataParallel(nn.Module):
             if _env_flag("TSG_CLS_HEAD", True):
                 from .clshead import install_cls_head
                 install_cls_head(self.module)                        # 1x1 classifier convolutions -> planar logits
+            if _env_flag("TSG_VEC_CONV", True):
+                from .vecconv import install_pooled_conv
+                install_pooled_conv(self.module)                     # 1x1 convolutions of pooled [B, C, 1, 1] maps
             if self.compute_dtype == torch.float32:
                 # fp32 = the parity mode: convolutions on the reference-accuracy kernels (exactconv.py: logits 1.3-1.9e-5
                 # from the float64 truth, the reference's CPU path 7-8e-5, the vendor library's fp32 kernels 5-6e-5)

@@ -572,6 +572,36 @@ class HipKernels:
         return dX, dA
 
     # ---- classifier convolution of a head (csrc/clshead.hip) ---------------------
+    # ---- 1x1 convolution of a globally pooled map (csrc/vecconv.hip)
+    def conv1x1_vec_supported(self, x, weight):
+        return (x.dim() == 4 and x.shape[2] == 1 and x.shape[3] == 1 and x.dtype == torch.bfloat16 and weight.dim() == 4
+                and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (1, 1) and weight.shape[1] == x.shape[1]
+                and bool(self.lib.tsg_conv1x1_vec_supported(x.shape[0], x.shape[1], weight.shape[0])))
+
+    def conv1x1_vec_fwd(self, x, weight):
+        """x [B,Cin,1,1] bf16, weight fp32 [Cout,Cin,1,1] -> y [B,Cout,1,1] bf16"""
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = weight.shape[0]
+        x = x.reshape(B, Cin).contiguous()
+        w = weight.reshape(Cout, Cin).contiguous()
+        y = torch.empty((B, Cout, 1, 1), dtype=torch.bfloat16, device=x.device)
+        L.check(self.lib.tsg_conv1x1_vec_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, L.stream_ptr(x)),
+                "tsg_conv1x1_vec_fwd")
+        return y
+
+    def conv1x1_vec_bwd(self, dy, x, weight, need_dx=True):
+        """dy [B,Cout,1,1] bf16, x [B,Cin,1,1] bf16, weight fp32 -> (dx bf16 [B,Cin,1,1] or None, dw fp32 like weight)"""
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = weight.shape[0]
+        dy = dy.reshape(B, Cout).contiguous()
+        x = x.reshape(B, Cin).contiguous()
+        w = weight.reshape(Cout, Cin).contiguous()
+        dx = torch.empty((B, Cin, 1, 1), dtype=torch.bfloat16, device=x.device) if need_dx else None
+        dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+        L.check(self.lib.tsg_conv1x1_vec_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), L.ptr(dx), dw.data_ptr(), B, Cin, Cout,
+                                             L.stream_ptr(x)), "tsg_conv1x1_vec_bwd")
+        return dx, dw
+
     def cls_head_supported(self, x, weight):
         return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dim() == 4 and weight.shape[2:] == (1, 1)
                 and weight.dtype == torch.float32 and x.shape[1] == weight.shape[1]
