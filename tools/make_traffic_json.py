@@ -14,7 +14,7 @@ FAMILIES = [("bn_stats", r"bn_reduce_(nhwc|nchw)<[^,]+, \d+, 0,"), ("bn_bwd_redu
             ("stem_conv_fwd", r"stem_fwd_k<false>"), ("stem_conv_fwd_stats", r"stem_fwd_k<true>"), ("stem_conv_wrw", r"stem_wrw_k<false>"), ("stem_conv_wrw_bn", r"stem_wrw_k<true>"),
             ("sgd_multi_step", r"sgd_multi_k"),
             ("conv3x3_wrw", r"conv3_wrw_(gen_k<|tr_k|k\()"), ("conv3x3_c64_fwd", r"conv64_fwd(_s2)?_k<"),
-            ("conv3x3_gen_fwd", r"conv3g_fwd_k<"),
+            ("conv3x3_gen_fwd", r"conv3[gh]_fwd_k<"),
             ("conv3x3_c64_s2_dgrad", r"conv64_dgrad_s2_k<"), ("ohem_up_fwd", r"ohem_up_fwd_k<"), ("ohem_up_bwd", r"ohem_up_bwd_k<"),
             ("bn_relu_pool_fwd", r"bn_relu_pool_fwd_k<"), ("bn_relu_pool_bwd_reduce", r"bn_relu_pool_bwd_reduce_k<"),
             ("bn_relu_pool_bwd_apply", r"bn_relu_pool_bwd_apply_k<")]

@@ -578,12 +578,19 @@ class HipKernels:
                 and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (1, 1) and weight.shape[1] == x.shape[1]
                 and bool(self.lib.tsg_conv1x1_vec_supported(x.shape[0], x.shape[1], weight.shape[0])))
 
+    @staticmethod
+    def _rows(t):
+        """[N, C, 1, 1] as N rows of C contiguous elements: the tensor itself when its memory already is that (contiguous or
+        channels_last strides, or a broadcast-free view), otherwise a copy"""
+        if t.stride(1) == 1 and t.stride(0) == t.shape[1]:
+            return t
+        return t.reshape(t.shape[0], t.shape[1]).contiguous()
+
     def conv1x1_vec_fwd(self, x, weight):
         """x [B,Cin,1,1] bf16, weight fp32 [Cout,Cin,1,1] -> y [B,Cout,1,1] bf16"""
         B, Cin = x.shape[0], x.shape[1]
         Cout = weight.shape[0]
-        x = x.reshape(B, Cin).contiguous()
-        w = weight.reshape(Cout, Cin).contiguous()
+        x, w = self._rows(x), self._rows(weight)
         y = torch.empty((B, Cout, 1, 1), dtype=torch.bfloat16, device=x.device)
         L.check(self.lib.tsg_conv1x1_vec_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, L.stream_ptr(x)),
                 "tsg_conv1x1_vec_fwd")
@@ -593,9 +600,7 @@ class HipKernels:
         """dy [B,Cout,1,1] bf16, x [B,Cin,1,1] bf16, weight fp32 -> (dx bf16 [B,Cin,1,1] or None, dw fp32 like weight)"""
         B, Cin = x.shape[0], x.shape[1]
         Cout = weight.shape[0]
-        dy = dy.reshape(B, Cout).contiguous()
-        x = x.reshape(B, Cin).contiguous()
-        w = weight.reshape(Cout, Cin).contiguous()
+        dy, x, w = self._rows(dy), self._rows(x), self._rows(weight)
         dx = torch.empty((B, Cin, 1, 1), dtype=torch.bfloat16, device=x.device) if need_dx else None
         dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
         L.check(self.lib.tsg_conv1x1_vec_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), L.ptr(dx), dw.data_ptr(), B, Cin, Cout,
