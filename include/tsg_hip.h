@@ -350,6 +350,15 @@ int tsg_conv3x3_gen_tile(int64_t B, int64_t H, int64_t W, int Cin, int Cout);
 int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int I, int mode, int BN, void* stream);
 int tsg_conv3x3_gen_stats_partials(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN);
 int tsg_conv3x3_gen_variant(int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, int with_in_ab);
+/* Data gradient of the 3x3 / STRIDE 2 / padding 1 convolutions C_in -> C_out (ResNet's first block of layer2-4,
+ * furnace/base_model/resnet.py:24-29,36-53): the cuDNN backward-data call of the reference plus, with `addend`, the
+ * gradient accumulation of the shortcut branch (resnet.py:48-52).  dy [B,OH,OW,C_out] -> dx [B,H,W,C_in], bf16
+ * channels_last, OH = (H - 1) / 2 + 1; wf = tsg_conv3x3_gen_prep_filter(w, ..., mode 1, BN 32); addend (may be NULL)
+ * [B,H,W,C_in] bf16: dx = bf16(bf16(dgrad) + addend).  C_in, C_out multiples of 32.  Computed by output parity (1 / 2 / 2 /
+ * 4 taps), no zero-stuffed operand; fp32 accumulation. */
+int tsg_conv3x3_s2_dgrad_supported(int dtype, int Cin, int Cout);
+int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* addend, int64_t B, int64_t H, int64_t W,
+                         int Cin, int Cout, void* stream);
 int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, const void* addend,
                         int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream);
 

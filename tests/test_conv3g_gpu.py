@@ -325,3 +325,97 @@ def test_sixteen_row_kernel_against_the_eight_row_kernel(cuda, monkeypatch):
         ref = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).cpu()
         np.testing.assert_allclose(out[v2][1].double().sum(0).cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-3)
     assert out["0"][1].shape == out["2"][1].shape            # same rows whichever kernel runs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tsg_conv3x3_s2_dgrad: the data gradient of the stride-2 3x3 convolutions by output parity (conv3s2d_k).  Oracle: autograd
+# of F.conv2d(stride 2) in fp64 on the bf16-rounded operands.  Even and odd input sizes (OH = (H - 1) / 2 + 1), partial
+# tiles, one / several dx-channel tiles, one chunk of 32 dy channels / many, the addend; the three layers of the bench
+# step against the vendor library's backward-data on the whole batch.
+S2_SHAPES = [(2, 64, 128, 16, 64), (1, 32, 32, 7, 9), (2, 128, 256, 18, 66), (1, 64, 96, 33, 31), (3, 32, 64, 1, 1),
+             (1, 256, 512, 16, 64), (2, 96, 32, 20, 130)]
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES)
+def test_stride2_data_gradient_vs_oracle(cuda, shape):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    assert kp.conv3x3_s2_dgrad_supported(Cin, Cout)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
+    dy = torch.randn(B, Cout, OH, OW, generator=g)
+    skip = torch.randn(B, Cin, H, W, generator=g)
+    wd = w.to(cuda).contiguous(memory_format=torch.channels_last)
+    dyb = dy.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dx = kp.conv3x3_s2_dgrad(dyb, wd, (H, W))
+    assert tuple(dx.shape) == (B, Cin, H, W) and dx.is_contiguous(memory_format=torch.channels_last)
+    xr = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, conv_ref.bf16_round(w).double(), None, 2, 1).backward(conv_ref.bf16_round(dy).double())
+    _check(dx, xr.grad)
+    # the bf16 copy of the master weight gives the same result (what the autograd node passes)
+    assert torch.equal(dx, kp.conv3x3_s2_dgrad(dyb, wd.bfloat16().contiguous(memory_format=torch.channels_last), (H, W)))
+    sb = skip.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(kp.conv3x3_s2_dgrad(dyb, wd, (H, W), addend=sb), dx + sb)
+
+
+@pytest.mark.parametrize("geom", [(16, 64, 128, 256), (16, 128, 256, 128), (16, 256, 512, 64)])
+def test_stride2_data_gradient_bench_geometry_vs_library(cuda, geom):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, S = geom
+    g = torch.Generator(device=cuda).manual_seed(Cin + S)
+    x = torch.randn(B, Cin, S, S, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g, device=cuda) * (2.0 / (9 * Cout)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, Cout, S // 2, S // 2, generator=g, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dx = kp.conv3x3_s2_dgrad(dy, w, (S, S))
+    lib = torch.ops.aten.convolution_backward(dy, x, w.bfloat16(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                              [True, False, False])[0]
+    _vs_library(dx, lib)
+    assert torch.equal(dx, kp.conv3x3_s2_dgrad(dy, w, (S, S)))
+
+
+def test_shortcut_gradient_joins_the_stride2_data_gradient(cuda, monkeypatch):
+    """BasicBlock with a 1x1 / stride-2 shortcut (resnet.py:139-146): conv1's node returns the input alias the shortcut
+    branch reads, so the branch's gradient is the addend of tsg_conv3x3_s2_dgrad.  Against the same block with the vendor
+    library's data gradient + autograd's accumulation (TSG_CONV_S2_DGRAD off): outputs bit-equal (the forward is the same),
+    every gradient equal to bf16 rounding."""
+    import copy, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torchseg_amd", "furnace"))
+    from base_model.resnet import BasicBlock, _shortcut
+    from torchseg_amd import convwrw
+    from torchseg_amd.convwrw import install_conv_wrw
+    from torchseg_amd.syncbn import SyncBatchNorm
+    torch.manual_seed(9)
+    proto = BasicBlock(64, 128, 2, norm_layer=SyncBatchNorm, downsample=_shortcut(64, 128, 2, SyncBatchNorm, 1e-5, 0.1))
+    g = torch.Generator().manual_seed(10)
+    x0 = torch.randn(2, 64, 24, 40, generator=g)
+    dy0 = torch.randn(2, 128, 12, 20, generator=g)
+    res = {}
+    for own in (True, False):
+        blk = copy.deepcopy(proto).to(cuda).to(memory_format=torch.channels_last)
+        install_conv_wrw(blk)
+        blk.train()
+        kp = convwrw.K.provider()
+        calls = []
+        orig = kp.conv3x3_s2_dgrad
+
+        def spy(*a, **k):
+            calls.append(k.get("addend") is not None)
+            return orig(*a, **k)
+        kp.conv3x3_s2_dgrad = spy
+        monkeypatch.setattr(convwrw, "_OWN_S2_DGRAD", own)
+        try:
+            xin = x0.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            x = xin * 1.0
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = blk(x)
+            out.backward(dy0.to(cuda).to(out.dtype).contiguous(memory_format=torch.channels_last))
+        finally:
+            del kp.conv3x3_s2_dgrad
+        assert calls == ([True] if own else []), calls
+        res[own] = [out.detach().float().cpu(), xin.grad.float().cpu()] + [p.grad.float().cpu() for p in blk.parameters()]
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert (a - b).abs().max().item() <= 2.0 ** -6 * b.abs().max().item() + 1e-6

@@ -75,6 +75,9 @@ class _ConvWrwFn(torch.autograd.Function):
         else:
             y = F.conv2d(x, wb, None, stride, 1)
         ctx.stride = stride
+        # stride 2, not 64 -> 64: the data gradient by output parity on tsg_conv3x3_s2_dgrad (csrc/conv3g.hip)
+        ctx.s2_gen = (_OWN_S2_DGRAD and not ctx.own and stride == 2 and wb.is_contiguous(memory_format=torch.channels_last)
+                      and K.provider().conv3x3_s2_dgrad_supported(wb.shape[1], wb.shape[0]))
         ctx.wrt = wrt                                  # not a graph tensor: a shadow owned by torchseg_amd.shadow
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
@@ -104,8 +107,12 @@ class _ConvWrwFn(torch.autograd.Function):
         dx = None
         rot = (lambda: ctx.wrt) if ctx.wrt is not None else (lambda: K.provider().conv3x3_weight_rot180_t(wb))
         if ctx.need_dx:
-            add = _skip_addend(dskip, x.shape) if (ctx.own and ctx.stride == 1) else None
-            if ctx.own and ctx.stride == 2:
+            add = _skip_addend(dskip, x.shape) if ((ctx.own and ctx.stride == 1) or ctx.s2_gen) else None
+            if ctx.s2_gen:
+                dx = K.provider().conv3x3_s2_dgrad(dy, wb, ctx.in_hw, addend=add)
+                if add is not None:
+                    dskip = None
+            elif ctx.own and ctx.stride == 2:
                 dx = K.provider().conv3x3_c64_s2_dgrad(dy, rot(), ctx.in_hw)
             elif ctx.own:
                 dx = K.provider().conv3x3_c64_fwd(dy, rot(), addend=add)
@@ -123,6 +130,11 @@ class _ConvWrwFn(torch.autograd.Function):
                 dx = dx + dskip.to(dx.dtype)
         dw = K.provider().conv3x3_wrw(x, dy, stride=ctx.stride)
         return dx, dw.to(ctx.wdtype), None, None, None, None, None
+
+
+# TSG_CONV_S2_DGRAD=1|0 (default 1): data gradient of the stride-2 3x3 layers other than 64 -> 64 (ResNet layer2-4's first
+# convolution) on tsg_conv3x3_s2_dgrad, with the shortcut branch's gradient as its epilogue addend (conv_with_skip)
+_OWN_S2_DGRAD = _os.environ.get("TSG_CONV_S2_DGRAD", "1") != "0"
 
 
 # TSG_CONV_GEN=1|0 (default 1): forward and data gradient of every other stride-1 3x3 layer (C_in % 16 == 0, C_out % 64
@@ -227,6 +239,10 @@ class WrwConv2d(nn.Conv2d):
                     own64 = _OWN_C64 and _OWN_C64_S1 and self.stride == (1, 1) and self.in_channels == 64 \
                         and self.out_channels == 64
                     c64 = _OWN_C64 and self.in_channels == 64 and self.out_channels == 64
+                    if not own64:                          # stride 2 on the parity kernel: its epilogue takes the shortcut's gradient
+                        own64 = (_OWN_S2_DGRAD and self.stride == (2, 2) and not c64
+                                 and self.weight.is_contiguous(memory_format=torch.channels_last)
+                                 and K.provider().conv3x3_s2_dgrad_supported(self.in_channels, self.out_channels))
                     stats = _C64_STATS and c64 and self.training
                     out = _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, bool(fuse and own64), stats)
                     if not stats:
@@ -240,12 +256,13 @@ class WrwConv2d(nn.Conv2d):
 
 
 def conv_with_skip(conv, x):
-    """`conv(x)` for the first convolution of a residual block whose skip connection is x itself.  Returns (y, x_skip):
+    """`conv(x)` for the first convolution of a residual block whose skip connection is x itself (stride 1) or starts from x
+    (stride 2: the 1x1 shortcut convolution, resnet.py:139-146).  Returns (y, x_skip):
     x_skip is x routed through the convolution's autograd node when our kernels compute its data gradient (then the
     block must use x_skip for `out += residual`: the skip path's gradient is added in that kernel's epilogue), else None
     (use x)."""
-    if _FUSE_SKIP and isinstance(conv, WrwConv2d) and conv.stride == (1, 1) and isinstance(x, torch.Tensor) and x.is_cuda \
-            and torch.is_grad_enabled():
+    if _FUSE_SKIP and isinstance(conv, WrwConv2d) and conv.stride in ((1, 1), (2, 2)) and isinstance(x, torch.Tensor) \
+            and x.is_cuda and torch.is_grad_enabled():
         return conv._forward(x, True)
     return conv(x), None
 

@@ -543,6 +543,155 @@ __global__ __launch_bounds__(256, 2) void conv3h_fwd_k(const bf16_t* __restrict_
   }
 }
 
+// ---- data gradient of the STRIDE-2 3x3 / padding 1 convolutions: conv3s2d_k ---------------------------------------------
+// ResNet's first block of layer2-4 (furnace/base_model/resnet.py:24-29 conv3x3(inplanes, planes, stride), :36-53) with 64 ->
+// 128, 128 -> 256, 256 -> 512 channels: the vendor library's backward-data kernels run them at 0.13-0.2 PF (141 / 92 / 95 us
+// at the bench shape, profiles/r04_eager_ops.txt) and autograd then adds the shortcut branch's gradient in a separate pass
+// over three tensors (60 / 33 / 17 us).  dx by OUTPUT PARITY: with ih = 2 a + pa, iw = 2 b + pb,
+//   dx[2a  ][2b  ] = dy[a][b] w11
+//   dx[2a  ][2b+1] = dy[a][b+1] w10 + dy[a][b] w12
+//   dx[2a+1][2b  ] = dy[a+1][b] w01 + dy[a][b] w21
+//   dx[2a+1][2b+1] = dy[a+1][b+1] w00 + dy[a+1][b] w02 + dy[a][b+1] w20 + dy[a][b] w22
+// (w_khkw = w[co][ci][kh][kw], summed over co): four small stride-1 correlations of the SAME dy patch, nine MFMA taps per
+// dy pixel in all, no zero-stuffed operand.  A block owns 8 x 32 dy pixels (-> 16 x 64 of dx) x 32 dx channels; a wave 2
+// dy rows = 4 parities x 2 rows = 8 accumulators; K = the convolution's output channels in chunks of 32 (two MFMA K
+// steps per barrier: 36 MFMAs per wave).  Staging as in conv3h_fwd_k: everything by LDS-DMA, the (8+1) x (32+1) dy patch
+// as two 16-channel planes of 32-byte pixels, out-of-image pixels by out-of-range buffer offsets; the filter is the
+// mode-1 prepared filter at tile width 32 ([ci tile][chunk][tap'][lane][8] with tap' = 8 - (3 kh + kw)).  `addend`
+// (the gradient that reaches x through the shortcut branch, resnet.py:48-52) joins in the epilogue.
+constexpr int D2_TH = 8, D2_PR = D2_TH + 1, D2_PC = G3_TW + 1;      // dy tile rows, patch rows / columns
+constexpr int D2_NPX = D2_PR * D2_PC;                    // 297 patch pixels
+constexpr int D2_PVEC = D2_NPX * 2;                      // 16-byte vectors of one 16-channel plane: 594
+constexpr int D2_PPIECES = (2 * D2_PVEC + 63) / 64;      // 19 pieces of 1 KB
+constexpr int D2_PBYTES = D2_PPIECES * 1024;             // 19,456
+constexpr int D2_FBYTES = 2 * 9 * 32 * G3_KC * 2;        // 18,432: two 16-channel slabs of a 32-wide tile
+constexpr int D2_FPIECES = D2_FBYTES / 1024;             // 18
+constexpr int D2_OS = 36;                                // epilogue staging: bf16 per dx pixel (32 + 4)
+constexpr size_t D2_LDS = 2 * (D2_FBYTES + D2_PBYTES);   // 75,776 B: two blocks per CU
+static_assert(16 * 64 * D2_OS * 2 <= D2_LDS, "the dx tile is staged in the filter and patch buffers");
+
+__global__ __launch_bounds__(256, 2) void conv3s2d_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wf,
+                                                      bf16_t* __restrict__ dx, G3Geom g, const bf16_t* __restrict__ addend) {
+  // g: B; H, W = dy's size; Cin = the convolution's OUTPUT channels (the K of this product); Cout = dx channels;
+  //    tiles over dy; nchunks = Cin / 32; noct = Cout / 32; prio carries dx's height | width << 16
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char d2_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int oct = jb % g.noct, slot = (jb / g.noct) * 8 + xcd;
+  const int XH = g.prio & 0xffff, XW = (g.prio >> 16) & 0xffff;
+  bf16_t* outs = reinterpret_cast<bf16_t*>(d2_smem);
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(wf + (int64_t)oct * g.nchunks * (D2_FBYTES / 2)), 0, g.nchunks * D2_FBYTES, 0x00020000);
+  const unsigned char* fa = d2_smem + lane * 16;                    // A (k step, tap') at + (ks 9 + tap') 1024
+  const unsigned char* pb = d2_smem + D2_FBYTES + ((2 * wave) * D2_PC + p) * 32 + half * 16;   // B (ks, row, shift) at + ks 594 16 + (row 33 + shift) 32
+
+  for (int tile = slot; tile < g.ntiles; tile += g.nslots) {
+    const int b0 = (tile % g.tiles_w) * G3_TW, a0 = ((tile / g.tiles_w) % g.tiles_h) * D2_TH;
+    const int bimg = tile / (g.tiles_w * g.tiles_h);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dy + (int64_t)bimg * g.H * g.W * g.Cin), 0, g.H * g.W * g.Cin * 2, 0x00020000);
+    int voff[5];                                          // patch piece wave + 4 u: this lane's 16 bytes
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int v = (wave + 4 * u) * 64 + lane;
+      const int ks = v >= D2_PVEC ? 1 : 0, vv = v - ks * D2_PVEC, q = vv >> 1;
+      const int a = a0 + q / D2_PC, b = b0 + q % D2_PC;
+      const bool ok = v < 2 * D2_PVEC && a < g.H && b < g.W;
+      voff[u] = ok ? (a * g.W + b) * g.Cin * 2 + ks * 32 + (vv & 1) * 16 : (int)0x80000000;
+    }
+    auto dma = [&](int u, int chunk, int buf) {          // patch piece u and filter piece u of this wave
+      const int q = wave + 4 * u;
+      if (u < 4 || q < D2_PPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(d2_smem + buf * (D2_FBYTES + D2_PBYTES) + D2_FBYTES + q * 1024),
+                                                 16, voff[u], chunk * 64, 0, 0);
+      if (u < 4 || q < D2_FPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d2_smem + buf * (D2_FBYTES + D2_PBYTES) + q * 1024), 16,
+                                                 lane * 16, (chunk * D2_FPIECES + q) * 1024, 0, 0);
+    };
+
+    g3_f32x16 acc[4][2];                                  // [2 pa + pb][dy row of the wave]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][r][e] = 0.f;
+
+    __syncthreads();                                     // the previous tile's epilogue is done with LDS
+#pragma unroll
+    for (int u = 0; u < 5; ++u) dma(u, 0, 0);
+    __syncthreads();
+
+    for (int c = 0; c < g.nchunks; ++c) {
+      const int buf = c & 1;
+      const bool more = c + 1 < g.nchunks;
+      const unsigned char* fab = fa + buf * (D2_FBYTES + D2_PBYTES);
+      const unsigned char* pbb = pb + buf * (D2_FBYTES + D2_PBYTES);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        g3_bf16x8 bq[3][2], af[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int dc = 0; dc < 2; ++dc)
+            bq[r][dc] = *reinterpret_cast<const g3_bf16x8*>(pbb + ks * (D2_PVEC * 16) + (r * D2_PC + dc) * 32);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) af[t] = *reinterpret_cast<const g3_bf16x8*>(fab + (ks * 9 + (8 - t)) * 1024);
+        if (more) {
+          if (ks == 0) { dma(0, c + 1, buf ^ 1); dma(1, c + 1, buf ^ 1); dma(2, c + 1, buf ^ 1); }
+          else { dma(3, c + 1, buf ^ 1); dma(4, c + 1, buf ^ 1); }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                     // tap (kh, kw) -> parity class and patch offset
+          const int kh = t / 3, kw = t % 3;
+          const int pa = kh == 1 ? 0 : 1, dr = kh == 0 ? 1 : 0;
+          const int pbp = kw == 1 ? 0 : 1, dc = kw == 0 ? 1 : 0;
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            acc[2 * pa + pbp][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bq[r + dr][dc], acc[2 * pa + pbp][r], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- epilogue: acc[2 pa + pb][r][e]: channel (e & 3) + 8 (e >> 2) + 4 half of dx pixel
+    //      (row 2 (2 wave + r) + pa, column 2 p + pb) of the 16 x 64 tile
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int row = 2 * (2 * wave + r) + (cls >> 1), col = 2 * p + (cls & 1);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2 v;
+          v.x = pack2_bf16(acc[cls][r][4 * gq + 0], acc[cls][r][4 * gq + 1]);
+          v.y = pack2_bf16(acc[cls][r][4 * gq + 2], acc[cls][r][4 * gq + 3]);
+          *reinterpret_cast<uint2*>(outs + (row * 64 + col) * D2_OS + 8 * gq + 4 * half) = v;
+        }
+      }
+    __syncthreads();
+    const int64_t img_off = (int64_t)bimg * XH * XW * g.Cout + oct * 32;
+    const int part = tid & 3;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int px = (tid >> 2) + 64 * k;                 // row k, column tid >> 2 of the tile
+      const int ih = 2 * a0 + (px >> 6), iw = 2 * b0 + (px & 63);
+      if (ih < XH && iw < XW) {
+        // (D2_OS = 36 elements: rows are 8-byte aligned only)
+        const uint2 lo = *reinterpret_cast<const uint2*>(outs + px * D2_OS + part * 8);
+        const uint2 hi = *reinterpret_cast<const uint2*>(outs + px * D2_OS + part * 8 + 4);
+        uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const int64_t off = ((int64_t)ih * XW + iw) * g.Cout + part * 8;
+        if (addend) o = g3_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + img_off + off));
+        *reinterpret_cast<uint4*>(dx + img_off + off) = o;
+      }
+    }
+  }
+}
+
 // ---- filter preparation: fp32 / bf16 master weight [O][3][3][I] (channels_last filter) -> bf16 in fragment order
 //   out[oc tile][chunk][tap][ocb][lane][e] = W'[oc = tile BN + ocb 32 + (lane & 31)][tap][ci = chunk 16 + (lane >> 5) 8 + e]
 // mode 0: W' = w (forward: C_out' = O, C_in' = I).
@@ -673,7 +822,7 @@ int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int 
   if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
   if (mode != 0 && mode != 1) return TSG_E_SHAPE;
   const int Co = mode ? I : O, Ci = mode ? O : I;
-  if (O <= 0 || I <= 0 || Ci % G3_KC || Co % 64 || (BN != 64 && BN != 128) || Co % BN) return TSG_E_SHAPE;
+  if (O <= 0 || I <= 0 || Ci % G3_KC || (BN != 32 && BN != 64 && BN != 128) || Co % BN) return TSG_E_SHAPE;   // 32: conv3s2d_k
   if (!aligned16(out)) return TSG_E_ALIGN;
   const int64_t nvec = (int64_t)9 * Ci * Co / 8;
   const unsigned grid = (unsigned)((nvec + 255) / 256);
@@ -683,6 +832,40 @@ int tsg_conv3x3_gen_prep_filter(const void* w, int dtype, void* out, int O, int 
   else
     hipLaunchKernelGGL((g3_prep_filter_k<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w,
                        (bf16_t*)out, O, I, BN, mode, nvec);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+/* data gradient of a 3x3 / stride 2 / padding 1 convolution C_in -> C_out: dy [B,OH,OW,C_out] -> dx [B,H,W,C_in], OH =
+ * (H - 1) / 2 + 1; wf = tsg_conv3x3_gen_prep_filter(w, mode 1, BN 32) */
+int tsg_conv3x3_s2_dgrad_supported(int dtype, int Cin, int Cout) {
+  return dtype == TSG_BF16 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0;
+}
+
+int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* addend, int64_t B, int64_t H, int64_t W,
+                         int Cin, int Cout, void* stream) {
+  if (!dy || !wf || !dx) return TSG_E_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || H > 0xffff || W > 0xffff) return TSG_E_SHAPE;
+  if (!aligned16(dy) || !aligned16(wf) || !aligned16(dx) || (addend && !aligned16(addend))) return TSG_E_ALIGN;
+  const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t th = (OH + D2_TH - 1) / D2_TH, tw = (OW + G3_TW - 1) / G3_TW;
+  if (B * th * tw > 0x7fffffffLL || OH * OW * (int64_t)Cout * 2 > 0x7fffffffLL || H * W * (int64_t)Cin > 0x7fffffffLL ||
+      (int64_t)9 * Cin * Cout * 2 > 0x7fffffffLL)
+    return TSG_E_SHAPE;
+  G3Geom g;
+  g.B = (int)B; g.H = (int)OH; g.W = (int)OW; g.Cin = Cout; g.Cout = Cin;      // the product's K = the convolution's C_out
+  g.tiles_h = (int)th; g.tiles_w = (int)tw; g.ntiles = (int)(B * th * tw);
+  g.nchunks = Cout / 32; g.noct = Cin / 32;
+  int64_t ns = 512 / g.noct;
+  if (ns > g.ntiles) ns = g.ntiles;
+  ns = (ns + 7) / 8 * 8;
+  if (ns < 8) ns = 8;
+  g.nslots = (int)ns;
+  g.prio = (int)H | ((int)W << 16);
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2d_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)D2_LDS));
+  hipLaunchKernelGGL(conv3s2d_k, dim3(g.nslots * g.noct), dim3(256), D2_LDS, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)wf, (bf16_t*)dx, g, (const bf16_t*)addend);
   TSG_CHECK_LAUNCH();
   return 0;
 }

@@ -54,10 +54,17 @@ class BasicBlock(_Block):
                 # the skip connection is x itself: route it through conv1's autograd node, whose data-gradient kernel
                 # then adds the skip path's gradient in its epilogue (no separate pass over three tensors)
                 c1, skip = conv_with_skip(self.conv1, x)
+                residual = skip if skip is not None else x
+            elif self.downsample is not None and self.stride == 2:
+                # the shortcut branch (1x1 / stride 2 convolution + BN) reads the alias: its gradient reaches conv1's
+                # node and joins the stride-2 data gradient in that kernel's epilogue
+                c1, skip = conv_with_skip(self.conv1, x)
+                residual = self._identity(skip if skip is not None else x)
             else:
                 c1 = self.conv1(x)
+                residual = self._identity(x)
             out = bn_relu_conv(self.bn1, self.relu, c1, self.conv2)
-            return norm_act(self.bn2, self.relu_inplace, out, residual=skip if skip is not None else self._identity(x))
+            return norm_act(self.bn2, self.relu_inplace, out, residual=residual)
         out = self.conv2(norm_act(self.bn1, self.relu, self.conv1(x)))
         return norm_act(self.bn2, self.relu_inplace, out, residual=self._identity(x))
 

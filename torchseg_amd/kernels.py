@@ -757,10 +757,11 @@ class HipKernels:
             L.check(v, "tsg_conv3x3_gen_variant")
         return v
 
-    def conv3x3_gen_prep_filter(self, weight, mode, like):
+    def conv3x3_gen_prep_filter(self, weight, mode, like, bn=None):
         """weight [O,I,3,3] channels_last (fp32 master or bf16) -> (wf, BN): the bf16 filter in MFMA fragment order for
         the convolution that will read `like` ([B,C,H,W]): mode 0 for conv(x, w), mode 1 for the data gradient
-        conv(dy, rot180(w)^T)"""
+        conv(dy, rot180(w)^T).  bn: the tile width to lay the filter out for (default: what tsg_conv3x3_gen_fwd will use;
+        32 for tsg_conv3x3_s2_dgrad)"""
         if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or not weight.is_contiguous(memory_format=torch.channels_last):
             raise ValueError("conv3x3_gen_prep_filter expects a channels_last [O, I, 3, 3] weight")
         O, I = weight.shape[0], weight.shape[1]
@@ -768,7 +769,8 @@ class HipKernels:
         B, C, H, W = like.shape
         if C != Cin:
             raise ValueError("conv3x3_gen_prep_filter: the input does not have the filter's channel count")
-        bn = self.conv3x3_gen_tile(B, H, W, Cin, Cout)
+        if bn is None:
+            bn = self.conv3x3_gen_tile(B, H, W, Cin, Cout)
         out = torch.empty(9 * O * I, dtype=torch.bfloat16, device=weight.device)
         L.check(self.lib.tsg_conv3x3_gen_prep_filter(weight.data_ptr(), L.dtype_code(weight), out.data_ptr(), O, I, int(mode),
                                                      bn, L.stream_ptr(weight)), "tsg_conv3x3_gen_prep_filter")
@@ -799,6 +801,28 @@ class HipKernels:
         L.check(self.lib.tsg_conv3x3_gen_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), L.ptr(partial), L.ptr(in_ab),
                                              L.ptr(addend), B, H, W, Cin, Cout, bn, L.stream_ptr(x)), "tsg_conv3x3_gen_fwd")
         return (y, partial) if with_stats else y
+
+    def conv3x3_s2_dgrad_supported(self, Cin, Cout):
+        return bool(self.lib.tsg_conv3x3_s2_dgrad_supported(L.BF16, Cin, Cout))
+
+    def conv3x3_s2_dgrad(self, dy, weight, in_hw, addend=None):
+        """dy [B,Cout,OH,OW] bf16 channels_last, weight [Cout,Cin,3,3] channels_last (fp32 master or bf16) of a 3x3 / stride 2
+        / padding 1 convolution whose input was [B,Cin,H,W] = in_hw -> dx bf16 channels_last (+ addend, same shape)"""
+        if not dy.is_contiguous(memory_format=torch.channels_last) or dy.dtype != torch.bfloat16:
+            raise ValueError("conv3x3_s2_dgrad expects a bf16 channels_last dy")
+        B, Cout = dy.shape[0], dy.shape[1]
+        Cin = weight.shape[1]
+        H, W = in_hw
+        if weight.shape[0] != Cout or (H - 1) // 2 + 1 != dy.shape[2] or (W - 1) // 2 + 1 != dy.shape[3]:
+            raise ValueError("conv3x3_s2_dgrad: dy does not belong to that weight / an input of that size")
+        if addend is not None and (tuple(addend.shape) != (B, Cin, H, W) or addend.dtype != torch.bfloat16
+                                   or not addend.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("conv3x3_s2_dgrad: addend must be a bf16 channels_last tensor of dx's shape")
+        wf, _ = self.conv3x3_gen_prep_filter(weight, 1, dy, bn=32)
+        dx = torch.empty((B, Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+        L.check(self.lib.tsg_conv3x3_s2_dgrad(dy.data_ptr(), wf.data_ptr(), dx.data_ptr(), L.ptr(addend), B, H, W, Cin, Cout,
+                                              L.stream_ptr(dy)), "tsg_conv3x3_s2_dgrad")
+        return dx
 
     def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw):
         """dy [B,64,OH,OW] bf16 channels_last, wt = conv3x3_weight_rot180_t(w) -> dx [B,64,H,W] of the stride-2 convolution"""
@@ -1065,6 +1089,7 @@ _ALGO_BYTES = {
     "conv3x3_c64_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "conv3x3_gen_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1][0]) + _nbytes(r[0] if isinstance(r, tuple) else r),
     "conv3x3_c64_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "conv3x3_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
 
@@ -1076,6 +1101,7 @@ _ALGO_FLOPS = {
     "conv3x3_c64_fwd": lambda a, r: 2 * 9 * 64 * r.numel(),
     "conv3x3_gen_fwd": lambda a, r: 2 * 9 * a[0].shape[1] * (r[0] if isinstance(r, tuple) else r).numel(),
     "conv3x3_c64_s2_dgrad": lambda a, r: 2 * 9 * 64 * a[0].numel(),
+    "conv3x3_s2_dgrad": lambda a, r: 2 * 9 * a[1].shape[1] * a[0].numel(),
     "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
     "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
     "stem_conv_wrw_bn": lambda a, r: 2 * 147 * a[1].numel(),
