@@ -35,6 +35,7 @@ namespace tsg {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float g3_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int g3_u32x4;
 
 constexpr int G3_TH = 8, G3_TW = 32;                     // output tile: 256 pixels
 constexpr int G3_PH = G3_TH + 2, G3_PW = G3_TW + 2;      // input patch
@@ -470,19 +471,45 @@ __global__ __launch_bounds__(256, 2) void conv3h_fwd_k(const bf16_t* __restrict_
           *reinterpret_cast<uint2*>(outs + ((4 * wave + i) * G3_TW + p) * H3_OS + j * 32 + 8 * gq + 4 * half) = v;
         }
     }
-    __syncthreads();
     const int64_t img_off = (int64_t)bimg * g.H * g.W * g.Cout + oct * 64;
     bf16_t* yimg = y + img_off;
     const int part = tid & 7;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int px = (tid >> 3) + 32 * k;
-      const int oh = oh0 + (px >> 5), ow = ow0 + (px & 31);
-      if (oh < g.H && ow < g.W) {
-        uint4 o = *reinterpret_cast<const uint4*>(outs + px * H3_OS + part * 8);
-        const int64_t off = ((int64_t)oh * g.W + ow) * g.Cout + part * 8;
-        if (addend) o = g3_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + img_off + off));
-        *reinterpret_cast<uint4*>(yimg + off) = o;
+    // the addend's vectors are requested one group of four rows ahead of the stores that use them (the first group before
+    // the barrier): their latency overlaps the staging instead of sitting in front of every store
+    const bool has_add = !STATS && addend != nullptr;
+    const int ow = ow0 + (tid >> 3);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(addend + (int64_t)bimg * g.H * g.W * g.Cout), 0, g.H * g.W * g.Cout * 2, 0x00020000);
+    const int av0 = ow < g.W ? (oh0 * g.W + ow) * g.Cout * 2 + oct * 128 + part * 16 : (int)0x80000000;
+    const int arow = g.W * g.Cout * 2;
+    g3_u32x4 adc[4], adn[4];
+    __builtin_amdgcn_sched_barrier(0);                   // (after the staging stores: the accumulators' registers are free)
+    if (has_add) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) adc[e] = __builtin_amdgcn_raw_buffer_load_b128(ra, av0, e * arow, 0);
+    }
+    __syncthreads();
+    {
+      bf16_t* yp = yimg + ((int64_t)oh0 * g.W + ow) * g.Cout + part * 8;       // row k of the tile: + k W C_out
+      const bf16_t* op = outs + (tid >> 3) * H3_OS + part * 8;
+      const int rows = ow < g.W ? min(16, g.H - oh0) : 0;
+#pragma unroll 1
+      for (int k4 = 0; k4 < 16; k4 += 4) {
+        if (has_add && k4 < 12) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) adn[e] = __builtin_amdgcn_raw_buffer_load_b128(ra, av0, (k4 + 4 + e) * arow, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (k4 + e < rows) {
+            uint4 o = *reinterpret_cast<const uint4*>(op + 32 * (k4 + e) * H3_OS);
+            if (has_add) o = g3_add_bf16x8(o, make_uint4(adc[e][0], adc[e][1], adc[e][2], adc[e][3]));
+            *reinterpret_cast<uint4*>(yp) = o;
+          }
+          yp += (int64_t)g.W * g.Cout;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adc[e] = adn[e];
       }
     }
     if (STATS) {
@@ -672,21 +699,47 @@ __global__ __launch_bounds__(256, 2) void conv3s2d_k(const bf16_t* __restrict__ 
           *reinterpret_cast<uint2*>(outs + (row * 64 + col) * D2_OS + 8 * gq + 4 * half) = v;
         }
       }
-    __syncthreads();
     const int64_t img_off = (int64_t)bimg * XH * XW * g.Cout + oct * 32;
     const int part = tid & 3;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int px = (tid >> 2) + 64 * k;                 // row k, column tid >> 2 of the tile
-      const int ih = 2 * a0 + (px >> 6), iw = 2 * b0 + (px & 63);
-      if (ih < XH && iw < XW) {
-        // (D2_OS = 36 elements: rows are 8-byte aligned only)
-        const uint2 lo = *reinterpret_cast<const uint2*>(outs + px * D2_OS + part * 8);
-        const uint2 hi = *reinterpret_cast<const uint2*>(outs + px * D2_OS + part * 8 + 4);
-        uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const int64_t off = ((int64_t)ih * XW + iw) * g.Cout + part * 8;
-        if (addend) o = g3_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + img_off + off));
-        *reinterpret_cast<uint4*>(dx + img_off + off) = o;
+    // the addend's 16 vectors of this thread are requested before the barrier: their latency (HBM: the tensor was written
+    // by another kernel) overlaps the staging instead of sitting in front of every store (129 -> us at 64 -> 128 @ 256^2)
+    const bool has_add = addend != nullptr;
+    const int iw = 2 * b0 + (tid >> 2);                   // row k, column tid >> 2 of the 16 x 64 tile
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(addend + (int64_t)bimg * XH * XW * g.Cout), 0, XH * XW * g.Cout * 2, 0x00020000);
+    const int av0 = iw < XW ? ((2 * a0) * XW + iw) * g.Cout * 2 + oct * 64 + part * 16 : (int)0x80000000;
+    const int arow = XW * g.Cout * 2;
+    g3_u32x4 adc[4], adn[4];
+    __builtin_amdgcn_sched_barrier(0);                   // (after the staging stores: the accumulators' registers are free)
+    if (has_add) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) adc[e] = __builtin_amdgcn_raw_buffer_load_b128(ra, av0, e * arow, 0);
+    }
+    __syncthreads();
+    {
+      bf16_t* xp = dx + img_off + ((int64_t)(2 * a0) * XW + iw) * g.Cout + part * 8;
+      const bf16_t* op = outs + (tid >> 2) * D2_OS + part * 8;
+      const int rows = iw < XW ? min(16, XH - 2 * a0) : 0;
+#pragma unroll 1
+      for (int k4 = 0; k4 < 16; k4 += 4) {
+        if (has_add && k4 < 12) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) adn[e] = __builtin_amdgcn_raw_buffer_load_b128(ra, av0, (k4 + 4 + e) * arow, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (k4 + e < rows) {
+            // (D2_OS = 36 elements: rows are 8-byte aligned only)
+            const uint2 lo = *reinterpret_cast<const uint2*>(op + 64 * (k4 + e) * D2_OS);
+            const uint2 hi = *reinterpret_cast<const uint2*>(op + 64 * (k4 + e) * D2_OS + 4);
+            uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            if (has_add) o = g3_add_bf16x8(o, make_uint4(adc[e][0], adc[e][1], adc[e][2], adc[e][3]));
+            *reinterpret_cast<uint4*>(xp) = o;
+          }
+          xp += (int64_t)XW * g.Cout;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adc[e] = adn[e];
       }
     }
   }
