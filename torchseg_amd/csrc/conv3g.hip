@@ -518,8 +518,9 @@ __global__ __launch_bounds__(256, 2) void conv3h_fwd_k(const bf16_t* __restrict_
       // cb 32 + c at 8 pixels; that register is both the A fragment Y^T[c][pixel] and the B fragment Y[pixel][c], so
       //   ones x Y  -> every row of D1 holds sum_px y[px][c]            (row 0: lanes 0-31, register 0)
       //   Y^T x Y   -> the diagonal of D2 holds sum_px y[px][c]^2       (exact products of bf16, fp32 accumulation)
-      // 32 MFMAs + 32 LDS reads per wave and tile; the VALU version (unpack, add, fma per element and 48 cross-lane
-      // shuffles) cost ~15 us of an 85-us launch (profiles/r04_conv3h.txt).
+      // 32 MFMAs + 32 LDS reads per wave and tile instead of unpack / add / fma per element and 48 cross-lane shuffles, and
+      // no statistics registers live across the K loop; time-neutral at the bench shapes (+3 ... +9 us per launch for the
+      // statistics either way, profiles/r04_conv3h.txt).
       typedef short h3_v4i16 __attribute__((ext_vector_type(4)));
       typedef h3_v4i16 __attribute__((address_space(3))) h3_lds_v4i16;
       const int sub = (lane >> 4) & 1, i16 = lane & 15;
@@ -701,8 +702,9 @@ __global__ __launch_bounds__(256, 2) void conv3s2d_k(const bf16_t* __restrict__ 
       }
     const int64_t img_off = (int64_t)bimg * XH * XW * g.Cout + oct * 32;
     const int part = tid & 3;
-    // the addend's 16 vectors of this thread are requested before the barrier: their latency (HBM: the tensor was written
-    // by another kernel) overlaps the staging instead of sitting in front of every store (129 -> us at 64 -> 128 @ 256^2)
+    // the addend's vectors are requested one group of four rows ahead of the stores that use them, the first group before
+    // the barrier: their latency (HBM: the tensor was written by another kernel) overlaps the staging instead of sitting in
+    // front of every store (64 -> 128 @ 256^2 with addend: 129 -> 110 us, profiles/r04_s2_dgrad.txt)
     const bool has_add = addend != nullptr;
     const int iw = 2 * b0 + (tid >> 2);                   // row k, column tid >> 2 of the 16 x 64 tile
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
