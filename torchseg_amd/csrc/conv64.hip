@@ -187,17 +187,29 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
         v.y = pack2_bf16(acc[i][4 * gq + 2], acc[i][4 * gq + 3]);
         *reinterpret_cast<uint2*>(outs + ((2 * wr + i) * C6_TW + p) * C6_PS + oc0) = v;
       }
-    __syncthreads();
     const int64_t tile_off = (((int64_t)tp.b * g.H + tp.oh0) * g.W + tp.ow0) * C6_C;
     bf16_t* yt = y + tile_off;
     const bool colok = tp.ow0 + spl < g.W;
+    // addend: y = bf16(bf16(conv) + addend): the skip connection's gradient joins the data gradient here.  Its four vectors
+    // are requested BEFORE the barrier, so their latency overlaps the staging instead of sitting in front of every store
+    // (16 x 64 x 256^2: 126-149 -> 120-143 us, profiles/r04_conv3h.txt; csrc/conv3g.hip's epilogues do the same)
+    uint4 ad[C6_TH];
+    __builtin_amdgcn_sched_barrier(0);                   // (after the staging stores: the accumulators' registers are free)
+    if (addend) {
+#pragma unroll
+      for (int qd = 0; qd < C6_TH; ++qd) {
+        ad[qd] = make_uint4(0u, 0u, 0u, 0u);
+        if (tp.oh0 + qd < g.H && colok)
+          ad[qd] = *reinterpret_cast<const uint4*>(addend + tile_off + ((int64_t)qd * g.W + spl) * C6_C + spart * 8);
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int qd = 0; qd < C6_TH; ++qd)
       if (tp.oh0 + qd < g.H && colok) {
         uint4 o = *reinterpret_cast<const uint4*>(outs + (qd * C6_TW + spl) * C6_PS + spart * 8);
         const int64_t off = ((int64_t)qd * g.W + spl) * C6_C + spart * 8;
-        // addend: y = bf16(bf16(conv) + addend): the skip connection's gradient joins the data gradient here
-        if (addend) o = c6_add_bf16x8(o, *reinterpret_cast<const uint4*>(addend + tile_off + off));
+        if (addend) o = c6_add_bf16x8(o, ad[qd]);
         *reinterpret_cast<uint4*>(yt + off) = o;
       }
     if (STATS) {
