@@ -25,7 +25,7 @@ def _check(cuda, B, H, W, seed=0, variant="tr"):
     return dw
 
 
-@pytest.mark.parametrize("variant", ["tr", "v1"])
+@pytest.mark.parametrize("variant", ["tr", "v1", "gen"])
 @pytest.mark.parametrize("shape", [(1, 8, 32), (2, 6, 40), (1, 3, 5), (3, 17, 70), (2, 64, 64)])
 def test_conv3x3_wrw_vs_oracle(cuda, shape, variant):
     _check(cuda, *shape, variant=variant)
@@ -33,7 +33,7 @@ def test_conv3x3_wrw_vs_oracle(cuda, shape, variant):
 
 def test_conv3x3_wrw_layer1_size_and_determinism(cuda):
     """ResNet-18 layer1 geometry at BASELINE config 2 (256 x 256 maps; B = 4 keeps the fp64 oracle to seconds)."""
-    for variant in ("tr", "v1"):
+    for variant in ("tr", "v1", "gen"):
         a = _check(cuda, 4, 256, 256, seed=5, variant=variant)
         b = _check(cuda, 4, 256, 256, seed=5, variant=variant)
         assert torch.equal(a, b), variant

@@ -54,7 +54,7 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
   TSG_ADAPTIVE_POOL=1|0 (default 1 on GPU: nn.AdaptiveAvgPool2d on channels_last maps -> tsg_adaptive_avgpool_nhwc_*)
   TSG_CONV_WRW=1|0      (default 1 on GPU: weight gradient of the 64->64 3x3/1 convolutions on tsg_conv3x3_wrw;
-                        TSG_CONV_WRW_IMPL=tr|v1 picks the kernel variant, default tr)
+                        TSG_CONV_WRW_IMPL=gen|tr|v1 picks the kernel of the 64 -> 64 layers, default gen)
   TSG_CLS_HEAD=1|0      (default 1 on GPU: the 1x1 classifier convolution of a head (<= 32 classes) on tsg_cls_head_*:
                         planar logits for the criterion kernels, no layout copies, no separate bias passes; clshead.py)
   TSG_VEC_CONV=1|0      (default 1 on GPU: bias-free 1x1 convolutions applied to pooled [B, C, 1, 1] maps (channel attention,

@@ -845,11 +845,12 @@ class HipKernels:
 
     def conv3x3_wrw(self, x, dy, variant=None, stride=1, in_ab=None):
         """x [B,Cin,Hin,Win], dy [B,Cout,OH,OW] bf16 channels_last (Cin, Cout multiples of 64; 3x3, padding 1, stride 1 or
-        2) -> dw fp32 [Cout,Cin,3,3] channels_last.  64 -> 64 / stride 1 takes the single-pair kernel (variant "tr", or
-        "v1" = the transposed-staging kernel, TSG_CONV_WRW_IMPL); everything else the pair-tiled kernel ("gen"; also
-        selectable for 64 -> 64 with variant="gen")."""
+        2) -> dw fp32 [Cout,Cin,3,3] channels_last.  The pair-tiled kernel ("gen") computes every shape; 64 -> 64 / stride 1 can
+        also take the single-pair kernels (variant "tr", or "v1" = the transposed-staging kernel; TSG_CONV_WRW_IMPL)."""
         if variant is None:
-            variant = os.environ.get("TSG_CONV_WRW_IMPL", "tr")
+            # 64 -> 64 / stride 1: the pair-tiled kernel (buffer-load fetch) is 4-7 % faster than the single-pair "tr" kernel
+            # at 16 x 64 x 256^2 (94-95 vs 99-101 us, profiles/r04_wrw_double_buffer_null.txt); TSG_CONV_WRW_IMPL=tr|v1 selects those
+            variant = os.environ.get("TSG_CONV_WRW_IMPL", "gen")
         if in_ab is not None:                 # normalise-on-load: x is the input of the BN + ReLU in front of the convolution
             if in_ab.dtype != torch.float32 or not in_ab.is_contiguous() or in_ab.shape[-1] != x.shape[1]:
                 raise ValueError("conv3x3_wrw: in_ab must be a contiguous fp32 [>=2, Cin] pack")
