@@ -841,7 +841,10 @@ static bool g3_v2_geom(G3Geom* g, int BN) {
   if (!on || BN != 64 || g3_nw(64) != 4 || (g->nchunks & 1)) return false;
   const int64_t th = (g->H + H3_TH - 1) / H3_TH;
   const int64_t nt = (int64_t)g->B * th * g->tiles_w;
-  if ((int64_t)g->H * g->W * g->Cin * 2 > 0x7fffffffLL || (int64_t)g->nchunks * H3_FBYTES > 0x7fffffffLL) return false;
+  // byte offsets into x, the addend and the filter are 32-bit buffer offsets
+  if ((int64_t)g->H * g->W * g->Cin * 2 > 0x7fffffffLL || (int64_t)g->H * g->W * g->Cout * 2 > 0x7fffffffLL ||
+      (int64_t)g->nchunks * H3_FBYTES > 0x7fffffffLL)
+    return false;
   if (on != 2 && (nt < g->nslots || nt * g->noct < 512)) return false;
   g->tiles_h = (int)th;
   g->ntiles = (int)nt;
@@ -904,9 +907,9 @@ int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* a
   if (!aligned16(dy) || !aligned16(wf) || !aligned16(dx) || (addend && !aligned16(addend))) return TSG_E_ALIGN;
   const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const int64_t th = (OH + D2_TH - 1) / D2_TH, tw = (OW + G3_TW - 1) / G3_TW;
-  if (B * th * tw > 0x7fffffffLL || OH * OW * (int64_t)Cout * 2 > 0x7fffffffLL || H * W * (int64_t)Cin > 0x7fffffffLL ||
+  if (B * th * tw > 0x7fffffffLL || OH * OW * (int64_t)Cout * 2 > 0x7fffffffLL || H * W * (int64_t)Cin * 2 > 0x7fffffffLL ||
       (int64_t)9 * Cin * Cout * 2 > 0x7fffffffLL)
-    return TSG_E_SHAPE;
+    return TSG_E_SHAPE;                                  // 32-bit buffer offsets (bytes) into dy, the addend and the filter
   G3Geom g;
   g.B = (int)B; g.H = (int)OH; g.W = (int)OW; g.Cin = Cout; g.Cout = Cin;      // the product's K = the convolution's C_out
   g.tiles_h = (int)th; g.tiles_w = (int)tw; g.ntiles = (int)(B * th * tw);
