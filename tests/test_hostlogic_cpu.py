@@ -199,3 +199,33 @@ def test_every_python_source_compiles():
     for f in ("bench.py", "__graft_entry__.py"):
         py_compile.compile(os.path.join(root, f), doraise=True)
     assert n > 60
+
+
+def test_pooled_conv_swap_and_kernel_choice_of_the_general_3x3():
+    """CPU: install_pooled_conv re-classes only bias-free 1x1 / stride-1 convolutions with channel counts the kernel takes and
+    passes CPU tensors to the stock forward; the host-side geometry queries of the library (no kernel launch) pick the
+    16-row LDS-DMA kernel exactly for the problems that fill 2 x 256 block slots, keep the statistics partial's row count
+    independent of that choice, and refuse what the kernels cannot index."""
+    from torchseg_amd.vecconv import PooledConv2d, install_pooled_conv
+    from torchseg_amd import _lib as L
+    net = nn.Sequential(nn.Conv2d(128, 64, 1, bias=False), nn.Conv2d(64, 19, 1, bias=False), nn.Conv2d(64, 64, 1, bias=True),
+                        nn.Conv2d(64, 64, 1, stride=2, bias=False), nn.Conv2d(64, 64, 3, padding=1, bias=False))
+    keys = list(net.state_dict().keys())
+    assert install_pooled_conv(net) == 1 and isinstance(net[0], PooledConv2d)
+    assert [type(m) for m in list(net)[1:]] == [nn.Conv2d] * 4 and list(net.state_dict().keys()) == keys
+    x = torch.randn(2, 128, 1, 1)
+    assert torch.equal(net[0](x), nn.functional.conv2d(x, net[0].weight))
+    lib = L.lib()
+    # (B, H, W, Cin, Cout) -> variant at tile width 64: BiSeNet-R18's 3x3 layers at the bench shape (tests/test_conv3g_gpu.py)
+    for geom, want in [((16, 128, 128, 128, 128), 1), ((16, 64, 64, 256, 256), 1), ((16, 128, 128, 128, 256), 1),
+                       ((16, 128, 128, 256, 64), 1), ((16, 64, 64, 128, 256), 1), ((16, 32, 32, 512, 512), 0),
+                       ((16, 64, 64, 256, 128), 0), ((16, 64, 64, 128, 128), 0), ((2, 128, 128, 48, 64), 0)]:
+        assert lib.tsg_conv3x3_gen_variant(*geom, 64, 0) == want, geom
+        assert lib.tsg_conv3x3_gen_variant(*geom, 64, 1) == 0                  # never with normalise-on-load
+        assert lib.tsg_conv3x3_gen_stats_partials(*geom, 64) > 0
+    assert lib.tsg_conv3x3_gen_variant(16, 128, 128, 100, 128, 64, 0) < 0      # C_in not a multiple of 16
+    assert lib.tsg_conv3x3_s2_dgrad_supported(L.BF16, 64, 128) == 1 and lib.tsg_conv3x3_s2_dgrad_supported(L.BF16, 48, 128) == 0
+    assert lib.tsg_conv3x3_s2_dgrad(None, None, None, None, 1, 8, 8, 64, 64, None) == -5      # TSG_E_NULL before any launch
+    assert lib.tsg_conv1x1_vec_supported(16, 512, 128) == 1 and lib.tsg_conv1x1_vec_supported(33, 512, 128) == 0
+    assert lib.tsg_conv1x1_vec_supported(16, 100, 128) == 0
+    assert lib.tsg_conv1x1_vec_fwd(None, None, None, 16, 64, 64, None) == -5
