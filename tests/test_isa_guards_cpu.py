@@ -92,3 +92,36 @@ def test_two_tiles_ahead_weight_gradient_does_not_spill(wrw_isa):
         asm = [a.strip() for a in re.findall(r";;#ASMSTART\n(.*?)\n\s*;;#ASMEND", body.split("s_endpgm")[0], flags=re.S)]
         assert sum(a.startswith("global_load_dwordx4") for a in asm) == 4 * 11     # prologue 2 sets + one per loop half
         assert "s_waitcnt vmcnt(11)" in asm and "s_waitcnt vmcnt(0)" in asm, name
+
+
+@pytest.fixture(scope="module")
+def g3_isa(tmp_path_factory):
+    return _isa(tmp_path_factory, "conv3g.hip")
+
+
+def test_lds_dma_convolution_kernels_keep_their_budget(g3_isa):
+    """conv3h_fwd_k (8 accumulators per wave) and conv3s2d_k (8 parity accumulators) run two blocks per CU, i.e. within 256
+    VGPRs; their epilogues hold prefetched addend rows while the accumulators die.  A spill would put scratch traffic into
+    the K loop (the first form of the addend prefetch did: 40 spilled registers).  Also: both operands of the K loop arrive
+    by LDS-DMA (`buffer_load_dwordx4 ... lds`), the loop has no `ds_write` of staged data, and the fragment reads are waited
+    for with counted `lgkmcnt` (not 0) in front of MFMA groups."""
+    meta = _kernel_meta(g3_isa)
+    want = {k: v for k, v in meta.items() if "conv3h_fwd_k" in k or "conv3s2d_k" in k}
+    assert len(want) == 3, sorted(meta)                  # conv3h with / without statistics, conv3s2d
+    for name, (spill, scratch) in want.items():
+        assert spill == 0 and scratch == 0, (name, spill, scratch)
+    bodies = re.split(r"\n(_ZN3tsg\d+conv3(?:h_fwd|s2d)_k\w+):", g3_isa)
+    checked = 0
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        body = body.split("s_endpgm")[0]
+        lines = [l.strip() for l in body.split("\n")]
+        mfma = [i for i, l in enumerate(lines) if l.startswith("v_mfma_f32_32x32x16_bf16")]
+        assert len(mfma) >= 36, (name, len(mfma))          # 72 (+ 32 statistics MFMAs) in conv3h, 2 x 18 in conv3s2d
+        loop = lines[mfma[0]:mfma[min(len(mfma), 72) - 1]]     # one chunk of the K loop (conv3h's statistics MFMAs come later)
+        dma = [l for l in loop if l.startswith("buffer_load_dwordx4") and l.endswith("lds")]
+        assert len(dma) >= 4, (name, len(dma))            # pieces of the next chunk are issued between the MFMA groups
+        assert not any(l.startswith("ds_write") for l in loop), name
+        counted = [l for l in loop if l.startswith("s_waitcnt lgkmcnt(") and l != "s_waitcnt lgkmcnt(0)"]
+        assert len(counted) >= 4, (name, counted)
+        checked += 1
+    assert checked == 3
