@@ -182,6 +182,12 @@ int tsg_adaptive_avgpool_nhwc_fwd(const void* x, void* out, int dtype, int64_t N
 int tsg_adaptive_avgpool_nhwc_bwd(const void* dout, void* dx, int dtype, int64_t N, int C, int H, int W, int OH, int OW,
                                   void* stream);
 
+/* Channel concatenation of two channels_last maps — `torch.cat([x1, x2], dim=1)` in FeatureFusion.forward
+ * (furnace/seg_opr/seg_oprs.py:233-235): out[m] = a[m] followed by b[m] for every row (pixel) m; row sizes in bytes,
+ * multiples of 16.  The backward of a concatenation is two views of the gradient (no kernel). */
+int tsg_cat2_rows(const void* a, const void* b, void* out, int64_t rows, int64_t row_bytes_a, int64_t row_bytes_b,
+                  void* stream);
+
 /* Channel gate y = x * s[n,c] (+ x when add_identity): the squeeze-excite
  * multiply of AttentionRefinement (`fm * fm_se`, seg_oprs.py:209-210) and
  * FeatureFusion (`fm + fm * fm_se`, seg_oprs.py:236-237).  s / ds are [N, C] in

@@ -131,3 +131,26 @@ def test_adaptive_avg_pool_channels_last(cuda, case, dtype):
     torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
     torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
     assert xd.grad.is_contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("shape", [(16, 128, 128, 32, 32), (2, 64, 256, 7, 9), (1, 8, 24, 5, 3), (3, 128, 128, 1, 2)])
+def test_channel_concatenation_equals_torch_cat_forward_and_backward(cuda, shape):
+    """cat_channels (tsg_cat2_rows) for FeatureFusion's torch.cat([x1, x2], dim=1) (seg_oprs.py:233-235): bit-equal output and
+    gradients, channels_last result; inputs it does not take (NCHW-contiguous, 1x1 maps) go to torch.cat."""
+    from torchseg_amd.pool import cat_channels
+    B, Ca, Cb, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    a0 = torch.randn(B, Ca, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    b0 = torch.randn(B, Cb, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, Ca + Cb, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    for fn in (lambda a, b: cat_channels(a, b), lambda a, b: torch.cat([a, b], dim=1)):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = fn(a, b)
+        y.backward(dy)
+        res.append((y.detach(), a.grad, b.grad))
+    assert res[0][0].is_contiguous(memory_format=torch.channels_last)
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(u, v)
+    n = torch.randn(2, 16, 4, 4, device=cuda)               # fp32 NCHW-contiguous: the stock path
+    assert torch.equal(cat_channels(n, n), torch.cat([n, n], 1))

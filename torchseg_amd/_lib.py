@@ -58,6 +58,7 @@ _PROTOS = {
     "tsg_adaptive_avgpool_nhwc_ws_bytes": (_sz, [_i, _i64, _i, _i, _i, _i, _i]),
     "tsg_adaptive_avgpool_nhwc_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "tsg_adaptive_avgpool_nhwc_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _i, _p]),
+    "tsg_cat2_rows": (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "tsg_chanscale_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p]),
     "tsg_chanscale_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p, _sz, _p]),
     "tsg_maxpool_nhwc_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

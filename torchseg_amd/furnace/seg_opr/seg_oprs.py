@@ -10,7 +10,7 @@ nn.BatchNorm2d for the CPU plumbing config) takes the plain module sequence.
 import torch
 import torch.nn as nn
 
-from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool, channel_scale
+from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool, cat_channels, channel_scale
 from torchseg_amd.syncbn import SyncBatchNorm as _FusedBN
 
 
@@ -221,5 +221,5 @@ class FeatureFusion(nn.Module):
             nn.Sigmoid())
 
     def forward(self, x1, x2):
-        fm = self.conv_1x1(torch.cat([x1, x2], dim=1))
+        fm = self.conv_1x1(cat_channels(x1, x2))           # torch.cat([x1, x2], dim=1) on HIP channels_last maps
         return channel_scale(fm, self.channel_attention(fm), add_identity=True)

@@ -230,6 +230,16 @@ class HipKernels:
                                                        OW, L.stream_ptr(dout)), "tsg_adaptive_avgpool_nhwc_bwd")
         return dx
 
+    def cat_channels(self, a, b):
+        """a [B,Ca,H,W], b [B,Cb,H,W], same dtype, channels_last -> [B,Ca+Cb,H,W] channels_last"""
+        B, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        out = torch.empty((B, Ca + Cb, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+        es = a.element_size()
+        L.check(self.lib.tsg_cat2_rows(a.data_ptr(), b.data_ptr(), out.data_ptr(), B * H * W, Ca * es, Cb * es, L.stream_ptr(a)),
+                "tsg_cat2_rows")
+        return out
+
     def chanscale_fwd(self, x, s, layout, N, Cc, HW, add_identity):
         y = torch.empty_like(x)
         L.check(self.lib.tsg_chanscale_fwd(x.data_ptr(), s.data_ptr(), y.data_ptr(), L.dtype_code(x), layout,

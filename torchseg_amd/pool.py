@@ -15,6 +15,8 @@ from . import kernels as K
 import os as _os
 # TSG_GAP_BWD_EXPAND=1|0 (default 1): the gradient of the global average pool as a broadcast view (see _GapFn.backward)
 _GAP_BWD_EXPAND = _os.environ.get("TSG_GAP_BWD_EXPAND", "1") != "0"
+# TSG_CAT=1|0 (default 1): FeatureFusion's channel concatenation on tsg_cat2_rows (cat_channels)
+_CAT = _os.environ.get("TSG_CAT", "1") != "0"
 
 
 class _GapFn(torch.autograd.Function):
@@ -144,6 +146,29 @@ def channel_scale(x, s, add_identity=False):
     if x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16):
         return _ChanScaleFn.apply(x, s, add_identity)
     return x + x * s if add_identity else x * s
+
+
+class _Cat2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = a.shape[1]
+        return K.provider().cat_channels(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.ca], g[:, ctx.ca:]                # views, as the framework's cat backward
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1) (seg_oprs.py:233-235) for two channels_last HIP maps of one dtype whose rows are multiples
+    of 16 bytes: one streaming kernel; anything else takes torch.cat."""
+    if (_CAT and a.is_cuda and b.is_cuda and a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype
+            and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:]
+            and (a.shape[1] * a.element_size()) % 16 == 0 and (b.shape[1] * b.element_size()) % 16 == 0
+            and a.shape[2] * a.shape[3] > 1
+            and a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last)):
+        return _Cat2Fn.apply(a, b)
+    return torch.cat([a, b], dim=1)
 
 
 class _MaxPoolFn(torch.autograd.Function):
