@@ -57,6 +57,9 @@ upsample overrides.  Controlled by env so train.py needs no edit:
                         TSG_CONV_WRW_IMPL=gen|tr|v1 picks the kernel of the 64 -> 64 layers, default gen)
   TSG_CLS_HEAD=1|0      (default 1 on GPU: the 1x1 classifier convolution of a head (<= 32 classes) on tsg_cls_head_*:
                         planar logits for the criterion kernels, no layout copies, no separate bias passes; clshead.py)
+  TSG_CONV_S2_DGRAD=1|0 (default 1 on GPU: data gradient of the stride-2 3x3 layers other than 64 -> 64 on tsg_conv3x3_s2_dgrad, the
+                        shortcut branch's gradient as its epilogue addend; convwrw.py)
+  TSG_CAT=1|0           (default 1 on GPU: FeatureFusion's torch.cat([x1, x2], 1) on tsg_cat2_rows; pool.py)
   TSG_VEC_CONV=1|0      (default 1 on GPU: bias-free 1x1 convolutions applied to pooled [B, C, 1, 1] maps (channel attention,
                         global context) on tsg_conv1x1_vec_*: one launch forward, one backward, fp32 master weight; vecconv.py)
   TSG_FP32_EXACT=1|0    (default 1: with TSG_DTYPE=fp32 every convolution runs on tsg_conv2d_f32_exact_* — exact products,
