@@ -88,3 +88,82 @@ def test_matrix_core_statistics_layout():
         half, r = (c >> 2) & 1, (c & 3) + 4 * (c >> 3)
         row = (r & 3) + 8 * (r >> 2) + 4 * half
         assert row == c, (c, half, r, row)                  # lane (c, half) register r is D[c][c]
+
+
+def _mfma_32x32x16(a_frag, b_frag, acc):
+    """v_mfma_f32_32x32x16 by its register layout: a_frag / b_frag [64 lanes][8]: lane l holds row (A) / column (B) l & 31 at
+    k = 8 (l >> 5) + e; acc [64 lanes][16]: lane l holds column l & 31 at rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)."""
+    A = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+    for l in range(64):
+        A[l & 31, 8 * (l >> 5): 8 * (l >> 5) + 8] = a_frag[l]
+        Bm[8 * (l >> 5): 8 * (l >> 5) + 8, l & 31] = b_frag[l]
+    D = A @ Bm
+    for l in range(64):
+        for r in range(16):
+            acc[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return acc
+
+
+def test_pooled_1x1_kernels_by_their_lane_arithmetic():
+    """vec1x1_fwd_k / vec1x1_bwd_k (csrc/vecconv.hip) restated lane by lane: forward M = batch, N = output channel, K = input
+    channel; weight gradient M = output channel, N = input channel, K = batch; data gradient M = batch, N = input channel,
+    K = output channel — each against the plain matrix products."""
+    rng = np.random.default_rng(3)
+    B, Cin, Cout = 5, 48, 80
+    x, w, dy = rng.standard_normal((B, Cin)), rng.standard_normal((Cout, Cin)), rng.standard_normal((B, Cout))
+    # ---- forward: block = 32 output channels
+    y = np.zeros((B, Cout))
+    for blk in range((Cout + 31) // 32):
+        acc = np.zeros((64, 16))
+        for k0 in range(0, Cin, 16):
+            a = np.zeros((64, 8)); b = np.zeros((64, 8))
+            for l in range(64):
+                n, half = l & 31, l >> 5
+                o = blk * 32 + n
+                if n < B: a[l] = x[n, k0 + 8 * half: k0 + 8 * half + 8]
+                if o < Cout: b[l] = w[o, k0 + 8 * half: k0 + 8 * half + 8]
+            _mfma_32x32x16(a, b, acc)
+        for l in range(64):
+            o = blk * 32 + (l & 31)
+            for r in range(16):
+                bb = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                if bb < B and o < Cout: y[bb, o] = acc[l, r]
+    assert np.allclose(y, x @ w.T)
+    # ---- weight gradient: 32 x 32 tiles, K = batch (one step of 16, rows >= B zero)
+    dw = np.zeros((Cout, Cin))
+    cit = (Cin + 31) // 32
+    for blk in range(((Cout + 31) // 32) * cit):
+        ot, ct = blk // cit, blk % cit
+        a = np.zeros((64, 8)); b = np.zeros((64, 8))
+        for l in range(64):
+            n, half = l & 31, l >> 5
+            o, ci = ot * 32 + n, ct * 32 + n
+            for e in range(8):
+                bb = 8 * half + e
+                if bb < B and o < Cout: a[l, e] = dy[bb, o]
+                if bb < B and ci < Cin: b[l, e] = x[bb, ci]
+        acc = _mfma_32x32x16(a, b, np.zeros((64, 16)))
+        for l in range(64):
+            ci = ct * 32 + (l & 31)
+            for r in range(16):
+                oo = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                if oo < Cout and ci < Cin: dw[oo, ci] = acc[l, r]
+    assert np.allclose(dw, dy.T @ x)
+    # ---- data gradient: 32 input channels per block, K = output channels
+    dx = np.zeros((B, Cin))
+    for blk in range(cit):
+        acc = np.zeros((64, 16))
+        for k0 in range(0, Cout, 16):
+            a = np.zeros((64, 8)); b = np.zeros((64, 8))
+            for l in range(64):
+                n, half = l & 31, l >> 5
+                ci = blk * 32 + n
+                if n < B: a[l] = dy[n, k0 + 8 * half: k0 + 8 * half + 8]
+                if ci < Cin: b[l] = w[k0 + 8 * half: k0 + 8 * half + 8, ci]
+            _mfma_32x32x16(a, b, acc)
+        for l in range(64):
+            ci = blk * 32 + (l & 31)
+            for r in range(16):
+                bb = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                if bb < B and ci < Cin: dx[bb, ci] = acc[l, r]
+    assert np.allclose(dx, dy @ w)
