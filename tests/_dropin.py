@@ -9,22 +9,32 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import stage_reference as _sr  # noqa: E402
 
 
 def have_reference():
     return os.path.isdir(os.path.join(REF, "model"))
 
 
+def have_staged_reference():
+    """The reference checkout, or the archive of its experiment files the build container packed for the GPU box
+    (oracle/_ref/reference_models.tar.gz, tools/stage_reference.py)."""
+    return _sr.available()
+
+
 def stage(tmp_path, family, exp, files=("config.py", "network.py")):
-    base = os.path.join(str(tmp_path), "TorchSeg")
-    exp_dir = os.path.join(base, "model", family, exp)
-    os.makedirs(exp_dir, exist_ok=True)
-    for f in files:
-        shutil.copy(os.path.join(REF, "model", family, exp, f), exp_dir)   # test-time copy only, never committed
-    link = os.path.join(base, "furnace")
-    if not os.path.exists(link):
-        os.symlink(os.path.join(ROOT, "torchseg_amd", "furnace"), link)
-    return exp_dir
+    if have_reference():
+        base = os.path.join(str(tmp_path), "TorchSeg")
+        exp_dir = os.path.join(base, "model", family, exp)
+        os.makedirs(exp_dir, exist_ok=True)
+        for f in files:
+            shutil.copy(os.path.join(REF, "model", family, exp, f), exp_dir)   # test-time copy only, never committed
+        link = os.path.join(base, "furnace")
+        if not os.path.exists(link):
+            os.symlink(os.path.join(ROOT, "torchseg_amd", "furnace"), link)
+        return exp_dir
+    return _sr.stage(tmp_path, family, exp, files)
 
 
 def run_in(exp_dir, script, timeout=600):

@@ -261,3 +261,103 @@ def test_add_underscore_call_is_never_deferred(standin):
         fm = a * 2.0
         fm.add_(torch.ones(1, 8, 2, 2))
         assert isinstance(fm, torch.Tensor) and torch.equal(fm, torch.full((1, 8, 2, 2), 3.0))
+
+
+# ---- consecutive ConvBnRelu modules (bisenet network.py:131-137) ----------------------------------------------------
+
+def _spatial_path(seed=0):
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    from seg_opr.seg_oprs import ConvBnRelu
+    from torchseg_amd.syncbn import SyncBatchNorm
+    torch.manual_seed(seed)
+
+    class SpatialPath(nn.Module):                      # the statements of network.py:131-137, literally
+        def __init__(self):
+            super().__init__()
+            kw = dict(has_bn=True, norm_layer=SyncBatchNorm, has_relu=True, has_bias=False)
+            self.conv_7x7 = ConvBnRelu(3, 64, 7, 2, 3, **kw)
+            self.conv_3x3_1 = ConvBnRelu(64, 64, 3, 2, 1, **kw)
+            self.conv_3x3_2 = ConvBnRelu(64, 64, 3, 2, 1, **kw)
+            self.conv_1x1 = ConvBnRelu(64, 128, 1, 1, 0, **kw)
+
+        def forward(self, x):
+            x = self.conv_7x7(x)
+            x = self.conv_3x3_1(x)
+            x = self.conv_3x3_2(x)
+            output = self.conv_1x1(x)
+            return output
+    return SpatialPath()
+
+
+def test_consecutive_conv_bn_relu_modules_hand_their_batchnorm_on(standin, monkeypatch):
+    from torchseg_amd import fusion
+    monkeypatch.setattr(fusion, "_on_device", lambda t: True)
+    ref, net = _spatial_path(), _spatial_path()
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    want = ref(x)
+    want.square().mean().backward()
+    before = dict(fusion.stats)
+    with fusion.FuseMode(loss=False, add_up=False, chain=True):
+        got = net(x)
+        assert isinstance(got, torch.Tensor)           # 128 output channels: nothing downstream could take its BatchNorm
+    got.square().mean().backward()
+    d = {k: fusion.stats[k] - before[k] for k in fusion.stats}
+    assert (d["cbr_deferred"], d["cbr_fed"], d["cbr_materialized"]) == (3, 3, 0), d
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=0, atol=0, msg=n)
+    for (n, b), (_, c) in zip(net.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b, c, rtol=0, atol=0, msg=n)   # every BatchNorm updated its running statistics once
+    assert fusion.CHAIN_ACTIVE is False
+
+
+def test_pending_conv_bn_relu_is_a_real_tensor_for_everything_else(standin, monkeypatch):
+    from torchseg_amd import fusion
+    monkeypatch.setattr(fusion, "_on_device", lambda t: True)
+    ref, net = _spatial_path(), _spatial_path()
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    pool = nn.AvgPool2d(2)
+    a = ref.conv_7x7(x)
+    want = pool(a) .sum() + a.mean() + float(a.size(1))
+    with fusion.FuseMode(loss=False, add_up=False, chain=True):
+        p = net.conv_7x7(x)
+        assert isinstance(p, fusion.PendingCbr)
+        got = pool(p).sum() + p.mean() + float(p.size(1))        # a module, a torch function, an attribute
+        dead = net.conv_3x3_1(p)                                 # consumed by the next ConvBnRelu AFTER it was materialised
+        assert isinstance(dead, fusion.PendingCbr)               # ... and never used: its BatchNorm still has to run
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+    ref.conv_3x3_1(a)
+    torch.testing.assert_close(net.conv_3x3_1.bn.running_mean, ref.conv_3x3_1.bn.running_mean, rtol=0, atol=0)
+    assert int(net.conv_3x3_1.bn.num_batches_tracked) == 1
+
+
+def test_a_conv_bn_relu_output_consumed_twice_is_reported(standin, monkeypatch):
+    from torchseg_amd import fusion
+    monkeypatch.setattr(fusion, "_on_device", lambda t: True)
+    net = _spatial_path()
+    x = torch.randn(2, 3, 32, 32)
+    with pytest.raises(RuntimeError, match="TSG_FUSE_CHAIN=0"):
+        with fusion.FuseMode(loss=False, add_up=False, chain=True):
+            p = net.conv_7x7(x)
+            net.conv_3x3_1(p)
+            p.sum()                                              # the first BatchNorm already ran inside the fused pair
+
+
+def test_inplace_keyword_settles_a_pending_sum(standin):
+    """F.relu(x, inplace=True) dispatches as 'relu'; the pending `a += b` must happen before it."""
+    from torchseg_amd.fusion import FuseMode
+    a0 = torch.randn(1, 4, 3, 3)
+    b0 = torch.randn(1, 4, 3, 3)
+
+    def run(mode):
+        a = (a0 * 1.0).requires_grad_(True) * 1.0
+        b = (b0 * 1.0).requires_grad_(True) * 1.0
+        with mode:
+            a += b
+            F.relu(b, inplace=True)
+            return a * 1.0
+    import contextlib
+    torch.testing.assert_close(run(FuseMode(loss=False)), run(contextlib.nullcontext()), rtol=0, atol=0)

@@ -50,6 +50,8 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_FUSE_HEAD=1|0     (default 1 on GPU: a bilinear F.interpolate of <= 32-channel logits by >= 4 stays pending and is
                         evaluated inside the criterion's kernels, tsg_ohem_up_*: 3x faster than writing and re-reading
                         the full-resolution logits; any other consumer materialises it.  fusion.py)
+  TSG_FUSE_CHAIN=1|0    (default 1 on GPU: a ConvBnRelu called right after another one (bisenet network.py:131-137) applies
+                        the first one's BatchNorm + ReLU while its own convolution loads its input; fusion.PendingCbr)
   TSG_SPLIT_BIAS=1|0    (default 1 on GPU: conv bias add / bias grad through our column-sum kernel)
   TSG_STEM_CONV=1|0     (default 1 on GPU: 7x7/2 image stems on tsg_stem_conv_* instead of MIOpen)
   TSG_ADAPTIVE_POOL=1|0 (default 1 on GPU: nn.AdaptiveAvgPool2d on channels_last maps -> tsg_adaptive_avgpool_nhwc_*)
@@ -381,6 +383,7 @@ class DistributedDataParallel(nn.Module):
         self.fuse_loss = self.on_gpu and _env_flag("TSG_FUSE_LOSS", not native)
         self.fuse_add_up = self.on_gpu and _env_flag("TSG_FUSE_ADD_UP", not native)
         self.fuse_head = self.on_gpu and _env_flag("TSG_FUSE_HEAD", not native)
+        self.fuse_chain = self.on_gpu and _env_flag("TSG_FUSE_CHAIN", not native)
         if self.on_gpu:
             from .upsample import install_aten_overrides
             install_aten_overrides()
@@ -424,9 +427,9 @@ class DistributedDataParallel(nn.Module):
         with contextlib.ExitStack() as stack:
             if self.on_gpu and self.compute_dtype != torch.float32:
                 stack.enter_context(torch.autocast("cuda", dtype=self.compute_dtype))
-            if self.fuse_psa or self.fuse_loss or self.fuse_add_up or self.fuse_head:
+            if self.fuse_psa or self.fuse_loss or self.fuse_add_up or self.fuse_head or self.fuse_chain:
                 from .fusion import FuseMode, materialize
                 stack.enter_context(FuseMode(psa=self.fuse_psa, loss=self.fuse_loss, add_up=self.fuse_add_up,
-                                             head=self.fuse_head))
+                                             head=self.fuse_head, chain=self.fuse_chain))
                 return materialize(self.module(*inputs, **kwargs))
             return self.module(*inputs, **kwargs)

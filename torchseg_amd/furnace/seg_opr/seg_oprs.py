@@ -10,6 +10,7 @@ nn.BatchNorm2d for the CPU plumbing config) takes the plain module sequence.
 import torch
 import torch.nn as nn
 
+from torchseg_amd import fusion as _fusion
 from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool, cat_channels, channel_scale
 from torchseg_amd.syncbn import SyncBatchNorm as _FusedBN
 
@@ -42,12 +43,38 @@ class _ConvNormAct(nn.Module):
         if has_relu:
             self.relu = nn.ReLU(inplace=inplace)
 
+    tsg_accepts_pending = True     # fusion.FuseMode's forward pre-hook leaves a PendingCbr argument to us
+
     def forward(self, x):
+        mode = _fusion.CHAIN_ACTIVE
+        if mode or isinstance(x, _fusion.PendingCbr):
+            return self._forward_chain(x, mode)
         x = self.conv(x)
         relu = self.relu if self.has_relu else None
         if self.has_bn:
             return norm_act(self.bn, relu, x)
         return relu(x) if relu is not None else x
+
+    def _forward_chain(self, x, mode):
+        """Under fusion.FuseMode(chain=True), i.e. around an unchanged network.py that calls ConvBnRelu modules one after
+        the other (bisenet network.py:131-137): a module whose BatchNorm + ReLU the NEXT convolution could apply on its
+        load path (64 output channels: convwrw.bn_relu_conv) returns its result pending; a pending input is consumed
+        here.  What runs is what `cbr_chain` below runs for our own builders."""
+        can_defer = (bool(mode) and self.has_bn and self.has_relu and isinstance(self.bn, _FusedBN)
+                     and isinstance(self.conv, nn.Conv2d) and self.conv.out_channels == 64
+                     and not self._forward_hooks and not self._forward_pre_hooks)
+        if isinstance(x, _fusion.PendingCbr):
+            y = x.feed(self)
+        elif can_defer and isinstance(x, torch.Tensor) and _fusion._on_device(x):
+            return mode.defer_cbr(self, x=x)
+        else:
+            y = self.conv(x)
+        if can_defer and _fusion._on_device(y):
+            return mode.defer_cbr(self, y=y)
+        relu = self.relu if self.has_relu else None
+        if self.has_bn:
+            return norm_act(self.bn, relu, y)
+        return relu(y) if relu is not None else y
 
 
 def cbr_chain(mods, x):

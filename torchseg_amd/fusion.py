@@ -12,6 +12,10 @@ the operator fusions of the hot path have to be recognised at the torch-function
         (`tsg_upsample_bilinear_ac*_presum_fwd`); and `last_fm + F.interpolate(fm)` (dfn network.py:130-133)
         stays `tsg_upsample_bilinear_ac*_fwd(x, add)`.
   * a9  `torch.bmm(x, torch.softmax(a, dim=1))` (psanet network.py:125-126,135-136) -> `tsg_psa_*` (psa.py).
+  * a3  consecutive `ConvBnRelu` modules called one after the other from a network.py (bisenet network.py:131-137,
+        SpatialPath) -> the BatchNorm + ReLU of the first is applied while the convolution of the second loads its
+        input (`PendingCbr`: what `seg_oprs.cbr_chain` does for our own builders); the image stem, its BatchNorm and the
+        next convolution become the one autograd node of convwrw.stem_bn_relu_conv.
 
 Every deferred value materialises itself (with the eager semantics, including the in-place update of `fm`) the
 moment anything other than its fusing consumer touches it.  The `+=` deferral changes WHEN (and, on the fused path,
@@ -52,6 +56,23 @@ class _Deferred(object):
 
     def __getitem__(self, idx):
         return self.materialize()[idx]
+
+
+def _forward_dunder(name):
+    def op(self, *others):
+        return getattr(self.materialize(), name)(*_unwrap(others))
+    op.__name__ = name
+    return op
+
+
+# Python looks operators up on the TYPE (never through __getattr__): `fm += x; y = fm * 2` must find them
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow", "matmul", "and", "or", "xor"):
+    for _fmt in ("__%s__", "__r%s__", "__i%s__"):
+        setattr(_Deferred, _fmt % _n, _forward_dunder(_fmt % _n))
+for _n in ("__neg__", "__pos__", "__abs__", "__invert__", "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__",
+           "__len__", "__iter__", "__bool__", "__float__", "__int__", "__setitem__", "__contains__"):
+    setattr(_Deferred, _n, _forward_dunder(_n))
+_Deferred.__hash__ = object.__hash__
 
 
 def _unwrap(v):
@@ -109,6 +130,72 @@ class DeferredSum(_Deferred):
                                    "sum was used, outside the view of the fusion mode; set TSG_FUSE_ADD_UP=0 for this model")
             self._value = self.a.add_(self.b)
         return self._value
+
+
+class PendingCbr(_Deferred):
+    """The output of a furnace `ConvBnRelu` (conv -> SyncBatchNorm -> ReLU, seg_oprs.py:24-46) whose BatchNorm + ReLU —
+    and, while `y` is None, whose convolution — has not run yet.  The NEXT ConvBnRelu consumes it (`feed`): the pair then
+    runs exactly what seg_oprs.cbr_chain runs for the same two modules.  Any other consumer (a torch function, an
+    attribute, another module: FuseMode's forward pre-hook) materialises it with the eager module sequence."""
+
+    def __init__(self, mod, x=None, y=None):
+        self.mod, self.x, self.y = mod, x, y
+        self.consumed = False
+
+    def materialize(self):
+        if self._value is None:
+            if self.consumed:
+                # its BatchNorm already ran inside the consumer's fused node (running statistics updated once, the
+                # normalised activation never stored): a second evaluation would update them twice
+                raise RuntimeError("torchseg_amd.fusion: the output of a ConvBnRelu was consumed by the next ConvBnRelu "
+                                   "(BatchNorm applied on its load path) and is used again; set TSG_FUSE_CHAIN=0 for this model")
+            from .furnace_glue import norm_act
+            m = self.mod
+            y = m.conv(self.x) if self.y is None else self.y
+            self._value = norm_act(m.bn, m.relu, y)
+            self.x = self.y = None
+            stats["cbr_materialized"] += 1
+        return self._value
+
+    def feed(self, nxt):
+        """-> nxt.conv(relu(bn(conv(x)))), the BatchNorm + ReLU applied on the load path of nxt.conv where covered."""
+        if self._value is not None or self.consumed:
+            return nxt.conv(self.materialize())
+        from .convwrw import bn_relu_conv, stem_bn_relu_conv
+        m = self.mod
+        y = self.y
+        if y is None:
+            out = stem_bn_relu_conv(m.conv, m.bn, m.relu, self.x, nxt.conv)
+            if out is not None:
+                self.consumed = True
+                self.x = None
+                stats["cbr_stem_fused"] += 1
+                return out
+            y = m.conv(self.x)
+        out = bn_relu_conv(m.bn, m.relu, y, nxt.conv)
+        self.consumed = True
+        self.x = self.y = None
+        stats["cbr_fed"] += 1
+        return out
+
+
+def _on_device(t):
+    """tests/ replace this to drive the chain logic on CPU tensors."""
+    return t.is_cuda
+
+
+CHAIN_ACTIVE = False       # set while a FuseMode(chain=True) is entered: ConvBnRelu.forward may return a PendingCbr
+
+
+def _unwrap_pending_inputs(mod, args):
+    """Global forward pre-hook while a chain-fusing FuseMode is entered: every module except a ConvBnRelu (which feeds
+    on it) sees the materialised tensor."""
+    if getattr(mod, "tsg_accepts_pending", False):
+        return None
+    for a in args:
+        if isinstance(a, PendingCbr):
+            return tuple(a.materialize() if isinstance(a, PendingCbr) else a for a in args)
+    return None
 
 
 class _PresumUpFn(torch.autograd.Function):
@@ -190,11 +277,18 @@ def _calibrate_iadd_refs():
     return seen[0] if seen else 0
 
 
+def _storage_ptr(t):
+    try:
+        return t.untyped_storage().data_ptr()
+    except Exception:                                       # noqa: BLE001 - meta / wrapper tensors: identity only
+        return -1 - id(t)
+
+
 def _mutates(func, kwargs):
     """An in-place torch function: `x.zero_()`, `x += y` / `x.add_(y)`, `x[i] = v`, or anything called with out=."""
     name = getattr(func, "__name__", "") or ""
-    if kwargs and kwargs.get("out") is not None:
-        return True
+    if kwargs and (kwargs.get("out") is not None or kwargs.get("inplace")):
+        return True                                      # F.relu(x, inplace=True) dispatches as 'relu' (ADVICE r4)
     if name.startswith("__") and name.endswith("__"):
         return name == "__setitem__" or (name.startswith("__i") and name not in ("__index__", "__int__", "__invert__",
                                                                                 "__init__", "__iter__"))
@@ -205,7 +299,8 @@ def _mutates(func, kwargs):
 # like the one it was calibrated on (reference counts of the augmented assignment, the BINARY_OP bytecode), so the
 # counts say whether the fused path is actually taken
 stats = {"iadd_deferred": 0, "iadd_declined_alias": 0, "iadd_declined_not_augmented": 0, "presum_fused": 0,
-         "materialized_before_mutation": 0}
+         "materialized_before_mutation": 0, "head_deferred": 0, "ce_fused": 0, "psa_deferred": 0,
+         "cbr_deferred": 0, "cbr_fed": 0, "cbr_stem_fused": 0, "cbr_materialized": 0}
 
 
 _LOG_SOFTMAX_FUNCS = (F.log_softmax, torch.log_softmax, torch.Tensor.log_softmax)
@@ -243,12 +338,62 @@ def _ce_args(args, kwargs):
 class FuseMode(TorchFunctionMode):
     """See the module docstring.  `psa`: defer column softmaxes for the PSA contraction; `loss`: plain CE heads on
     the HIP kernels; `add_up`: `+=` -> interpolate fusion; `head`: bilinear up-sampling of <= 32-channel logits by >= 4 is
-    left pending for the criterion (fused upsample + CE / OHEM kernels)."""
+    left pending for the criterion (fused upsample + CE / OHEM kernels); `chain`: consecutive ConvBnRelu modules hand
+    their BatchNorm + ReLU to the next convolution (PendingCbr).
 
-    def __init__(self, psa=False, loss=True, add_up=True, head=False):
+    Host cost: the mode sees EVERY torch function of the forward (a few thousand per step: tensor attributes and the
+    allocations inside our own kernel wrappers included), so the first thing it does is one set lookup that sends
+    everything it has no business with straight on."""
+
+    def __init__(self, psa=False, loss=True, add_up=True, head=False, chain=False):
         super().__init__()
         self.psa, self.loss, self.add_up, self.head = bool(psa), bool(loss), bool(add_up), bool(head)
+        self.chain = bool(chain)
         self._pending = []           # weak references to DeferredSums that have not been used yet
+        self._cbrs = []              # PendingCbrs handed out (settled at exit: a BatchNorm must not be skipped)
+        self._hook = None
+        watch = set()
+        if self.psa:
+            from .psa import _SOFTMAX_FUNCS
+            watch.update(_SOFTMAX_FUNCS)
+        if self.loss:
+            watch.update(_LOG_SOFTMAX_FUNCS)
+            watch.update((F.cross_entropy, F.nll_loss))
+        if self.add_up:
+            watch.update(_IADD_FUNCS)
+        if self.add_up or self.head:
+            watch.add(F.interpolate)
+        self._watch = frozenset(watch)
+
+    def __enter__(self):
+        global CHAIN_ACTIVE
+        if self.chain:
+            import torch.nn.modules.module as _mm
+            self._hook = _mm.register_module_forward_pre_hook(_unwrap_pending_inputs)
+            self._chain_before = CHAIN_ACTIVE
+            CHAIN_ACTIVE = self
+        return super().__enter__()
+
+    def __exit__(self, *exc):
+        global CHAIN_ACTIVE
+        cbrs, self._cbrs = self._cbrs, []
+        if self.chain:
+            CHAIN_ACTIVE = self._chain_before
+            if self._hook is not None:
+                self._hook.remove()
+                self._hook = None
+        out = super().__exit__(*exc)
+        if self.chain and exc[0] is None:
+            for c in cbrs:                               # never consumed: the eager program had run its BatchNorm
+                if c._value is None and not c.consumed:
+                    c.materialize()
+        return out
+
+    def defer_cbr(self, mod, x=None, y=None):
+        c = PendingCbr(mod, x, y)
+        self._cbrs.append(c)
+        stats["cbr_deferred"] += 1
+        return c
 
     def _settle_before_mutation(self, func, args, kwargs):
         """The pending `a += b` happens NOW if `func` is about to change `a` or `b` in place: the eager program had
@@ -262,14 +407,20 @@ class FuseMode(TorchFunctionMode):
         self._pending = live
         if not live or not _mutates(func, kwargs):
             return
-        flat = list(args) + list(kwargs.values())
+        flat = [t for t in list(args) + list(kwargs.values()) if isinstance(t, torch.Tensor)]
         for ref in live:
             sm = ref()
-            if sm is not None and any(t is sm.a or t is sm.b for t in flat):
+            if sm is None:
+                continue
+            # identity, or the same storage (a view of an addend changed in place changes the addend: ADVICE r4)
+            sa, sb = _storage_ptr(sm.a), _storage_ptr(sm.b)
+            if any(t is sm.a or t is sm.b or _storage_ptr(t) in (sa, sb) for t in flat):
                 sm.materialize()
                 stats["materialized_before_mutation"] += 1
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
+        if func not in self._watch and not self._pending:
+            return func(*args, **kwargs) if kwargs else func(*args)
         kwargs = kwargs or {}
         if self.add_up and self._pending:
             self._settle_before_mutation(func, args, kwargs)
@@ -279,6 +430,7 @@ class FuseMode(TorchFunctionMode):
                 dim = kwargs.get("dim", args[1] if len(args) > 1 else None)
                 a = args[0]
                 if dim == 1 and a.dim() == 3 and a.is_cuda and kwargs.get("dtype") is None and a.dtype in _FLOATS:
+                    stats["psa_deferred"] += 1
                     return _DeferredColSoftmax(a)
         if self.loss:
             if func in _LOG_SOFTMAX_FUNCS and args and _is_logits(args[0]) and torch.is_grad_enabled() \
@@ -291,6 +443,7 @@ class FuseMode(TorchFunctionMode):
                 if ce is not None:
                     from .losses import cross_entropy_2d
                     x, tgt, w, ignore = ce
+                    stats["ce_fused"] += 1
                     return cross_entropy_2d(x, tgt, ignore_index=ignore, weight=w)
         if self.add_up:
             if func in _IADD_FUNCS and len(args) == 2 and not kwargs and _is_map(args[0]) and _is_map(args[1]) \
@@ -328,5 +481,6 @@ class FuseMode(TorchFunctionMode):
             OH, OW = _out_size(x, kwargs.get("size", args[1] if len(args) > 1 else None),
                                kwargs.get("scale_factor", args[2] if len(args) > 2 else None))
             if x.shape[1] <= 32 and OH >= 4 * x.shape[2] and OW >= 4 * x.shape[3]:
+                stats["head_deferred"] += 1
                 return DeferredUpsample(x, (OH, OW))
         return func(*args, **kwargs)

@@ -1120,6 +1120,37 @@ _ALGO_FLOPS = {
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 
 
+class CallCounter:
+    """Counts the calls of every public method of a provider (= the C-ABI entry points the host logic reached), so a
+    test or bench.py can assert WHICH kernels a step took — e.g. that the fused head, the summing up-sampling and our
+    convolutions ran for an UNCHANGED reference network.py, not a silent eager fallback.  `stop()` restores the provider."""
+
+    def __init__(self, prov):
+        self.prov = prov
+        self.counts = {}
+        self._names = [n for n in dir(type(prov)) if not n.startswith("_") and callable(getattr(type(prov), n))]
+        for n in self._names:
+            self._wrap(n)
+
+    def _wrap(self, name):
+        fn = getattr(self.prov, name)
+        counts = self.counts
+
+        def counted(*args, **kw):
+            counts[name] = counts.get(name, 0) + 1
+            return fn(*args, **kw)
+
+        setattr(self.prov, name, counted)
+
+    def stop(self):
+        for n in self._names:
+            try:
+                delattr(self.prov, n)
+            except AttributeError:
+                pass
+        return dict(self.counts)
+
+
 class KernelTimer:
     """Brackets every launch of the streaming kernels with HIP events recorded on
     the stream the kernel is enqueued on (torch's current stream) and accumulates
@@ -1175,27 +1206,61 @@ class KernelTimer:
     def summary(self):
         return self.stats
 
+    # kernel families of the bench line's `roofline` (the four bn_* labels are ONE family — SyncBN — and
+    # the line must name the family with the largest total time, not the largest label)
+    FAMILIES = {
+        "syncbn": ("bn_stats", "bn_apply_fwd", "bn_bwd_reduce", "bn_bwd_apply", "bn_apply_fwd_mixed", "bn_bwd_reduce_mixed",
+                   "bn_bwd_apply_mixed", "bn_relu_pool_fwd", "bn_relu_pool_bwd_reduce", "bn_relu_pool_bwd_apply"),
+        "conv3x3_wrw": ("conv3x3_wrw",),
+        "conv3x3_fwd_dgrad": ("conv3x3_gen_fwd", "conv3x3_c64_fwd", "conv3x3_c64_s2_dgrad", "conv3x3_s2_dgrad"),
+        "fused_heads": ("ohem_up_fwd", "ohem_up_bwd", "ohem_fwd", "ohem_bwd"),
+        "stem": ("stem_conv_fwd", "stem_conv_fwd_stats", "stem_conv_wrw", "stem_conv_wrw_bn"),
+        "upsample": ("upsample_fwd", "upsample_presum_fwd", "upsample_bwd", "upsample_fwd_nhwc", "upsample_bwd_nhwc"),
+    }
+
+    def family_stats(self):
+        """Per family: launches, total ms, algorithmic GB/s (and TFLOP/s for the matrix kernels), summed over its labels."""
+        fam = {}
+        for name, members in self.FAMILIES.items():
+            recs = [r for m in members for r in self.records.get(m, ())]
+            if not recs:
+                continue
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            by = sum(r[2] for r in recs)
+            fl = sum(r[3] for r in recs)
+            if ms <= 0:
+                continue
+            st = {"launches": len(recs), "total_ms": round(ms, 3), "avg_us": round(ms * 1e3 / len(recs), 2),
+                  "algo_MB_per_launch": round(by / len(recs) / 1e6, 3), "GBps": round(by / (ms * 1e-3) / 1e9, 1),
+                  "members": [m for m in members if self.records.get(m)]}
+            if fl:
+                st["algo_GFLOP_per_launch"] = round(fl / len(recs) / 1e9, 3)
+                st["TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
+            fam[name] = st
+        return fam
+
     def dominant(self):
-        """Name of the instrumented kernel with the largest total time (None if nothing ran)."""
+        """Name of the instrumented kernel label with the largest total time (None if nothing ran)."""
         return max(self.stats, key=lambda n: self.stats[n]["total_ms"]) if self.stats else None
 
-    def roofline(self, peak_gbs, profiles_dir=None):
-        name = self.dominant()
-        st = self.stats[name]
-        traffic = source = busy = None
-        if profiles_dir:
-            import json
-            import os
-            f = os.path.join(profiles_dir, "traffic.json")
-            if os.path.exists(f):
-                tj = json.load(open(f))
-                traffic = tj.get(name)                   # PMC bytes per launch (separate rocprofv3 --pmc passes)
-                # NOT a counter of this run: rocprofv3 cannot be attached from inside the process it profiles
-                source = "profiles/traffic.json@" + str(tj.get("_round", "r02")) + \
-                    " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench command, tools/pmc_traffic.sh)"
-                busy = (tj.get("_mfma_busy_frac") or {}).get(name)
-        out = {"bound": "hbm", "kernel": name, "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
-               "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic, "traffic_source": source,
+    def dominant_family(self):
+        fam = self.family_stats()
+        return max(fam, key=lambda n: fam[n]["total_ms"]) if fam else None
+
+    def _roof_entry(self, name, st, peak_gbs, tj):
+        traffic = busy = None
+        if tj is not None:
+            # PMC bytes per launch (separate rocprofv3 --pmc passes), launch-weighted over the family's labels
+            tr = [(tj.get(m), self.stats[m]["launches"]) for m in st.get("members", [name]) if m in self.stats]
+            if tr and all(t is not None for t, _ in tr):
+                traffic = int(sum(t * n for t, n in tr) / sum(n for _, n in tr))
+            bz = [((tj.get("_mfma_busy_frac") or {}).get(m), self.stats[m]["total_ms"]) for m in st.get("members", [name])
+                  if m in self.stats]
+            if bz and all(b is not None for b, _ in bz):
+                busy = round(sum(b * w for b, w in bz) / sum(w for _, w in bz), 4)
+        out = {"bound": "hbm", "kernel": name, "launches": st["launches"], "total_ms": st["total_ms"],
+               "achieved": st["GBps"], "peak": peak_gbs, "unit": "GB/s",
+               "frac": round(st["GBps"] / peak_gbs, 4), "traffic": traffic,
                "algo_bytes_per_launch": int(st["algo_MB_per_launch"] * 1e6), "avg_launch_us": st["avg_us"]}
         if "TFLOPs" in st and st["TFLOPs"] / MFMA_PEAK_TFLOPS > out["frac"]:
             # a matrix kernel: the roof it is closer to is the MFMA one (the HBM figure stays alongside)
@@ -1205,4 +1270,30 @@ class KernelTimer:
                         "hbm_GBps": st["GBps"], "hbm_frac": round(st["GBps"] / peak_gbs, 4)})
             if busy is not None:
                 out["mfma_busy_frac"] = busy             # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES), same source
+        return out
+
+    def roofline(self, peak_gbs, profiles_dir=None, by_family=False):
+        """The bench line's `roofline` object.  by_family: the dominant kernel FAMILY (SyncBN = all bn_* passes, ...)
+        with the three largest families listed under `top_families`; otherwise the dominant single label."""
+        tj = source = None
+        if profiles_dir:
+            import json
+            import os
+            f = os.path.join(profiles_dir, "traffic.json")
+            if os.path.exists(f):
+                tj = json.load(open(f))
+                # NOT a counter of this run: rocprofv3 cannot be attached from inside the process it profiles
+                source = "profiles/traffic.json@" + str(tj.get("_round", "r02")) + \
+                    " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench command, tools/pmc_traffic.sh)"
+        if by_family:
+            fam = self.family_stats()
+            order = sorted(fam, key=lambda n: -fam[n]["total_ms"])
+            out = self._roof_entry(order[0], fam[order[0]], peak_gbs, tj)
+            out["family_members"] = fam[order[0]]["members"]
+            out["traffic_source"] = source
+            out["top_families"] = [self._roof_entry(n, fam[n], peak_gbs, tj) for n in order[:3]]
+            return out
+        name = self.dominant()
+        out = self._roof_entry(name, dict(self.stats[name], members=[name]), peak_gbs, tj)
+        out["traffic_source"] = source
         return out
