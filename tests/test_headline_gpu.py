@@ -140,6 +140,61 @@ def test_fp32_logits_loss_and_kept_mask_at_1024(cuda, oracle_run):
     assert rel <= 1e-2, rel      # measured 5.7e-3: the same MIOpen-vs-CPU convolution noise as in the logits, through backward
 
 
+def test_fp32_gradients_per_parameter_against_float64(cuda):
+    """ABSOLUTE bars for the fp32 gradients, against the float64 evaluation of the oracle network —
+    the fp32 CPU path cannot serve as this reference: it sits 5e-2 .. 9e-2 from float64 at its worst parameter (torch's CPU
+    BatchNorm backward accumulates in fp32 and cancels; profiles/r05_smoke_grads_vs_float64.txt), which is what round 4's
+    `worst per-param 5.37e-02` in smoke() was.
+
+    * all parameters together: relative L2 <= 5e-5 (measured 6.9e-6; the fp32 CPU path: 3e-3);
+    * every parameter: max |d| / max |g| <= 2e-2, and at most eight parameters above 1e-4.  An fp32 evaluation cannot
+      promise more per parameter: ONE ReLU whose argument is 7e-8 in float64 and 0 in fp32 (spatial_path.conv_1x1 at this
+      seed, found with tools/r5/debug_ffm_grad.py) moves the four SpatialPath parameters behind it by 1.5e-3 .. 7.8e-3;
+      every other parameter is below 1e-5.  smoke() holds ALL parameters to 1e-4 at a configuration without such a flip."""
+    from oracle.ohem_ref import ProbOhemCrossEntropy2d as OracleOhem
+    from torchseg_amd.ddp import DistributedDataParallel
+    from torchseg_amd.losses import ProbOhemCrossEntropy2d
+    from torchseg_amd.syncbn import SyncBatchNorm
+    from torchseg_amd.workloads.bisenet import BiSeNet
+    b, s = 4, 256            # batch 4: the global-context BatchNorm over [B, 128, 1, 1] is ill-conditioned at 2 values per channel
+    min_kept = b * s * s // 16
+    torch.manual_seed(12345)
+    ref32 = BiSeNet(C, True, OracleOhem(255, thresh=0.7, min_kept=min_kept), None, nn.BatchNorm2d)
+    ref64 = BiSeNet(C, True, OracleOhem(255, thresh=0.7, min_kept=min_kept), None, nn.BatchNorm2d)
+    ref64.load_state_dict(ref32.state_dict())
+    ref64 = ref64.double()
+    net = BiSeNet(C, True, ProbOhemCrossEntropy2d(255, thresh=0.7, min_kept=min_kept), None, SyncBatchNorm)
+    net.load_state_dict(ref32.state_dict())
+    net = DistributedDataParallel(net.to(cuda), compute_dtype=torch.float32)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(b, 3, s, s, generator=g)
+    y = torch.randint(0, C, (b, s, s), generator=g)
+    y[:, :8] = 255
+    ref32(x, y).backward()
+    l64 = ref64(x.double(), y)
+    l64.backward()
+    loss = net(x.to(cuda), y.to(cuda))
+    loss.backward()
+    assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item()), (loss.item(), l64.item())
+
+    def distance(grads):
+        rows, num, den = [], 0.0, 0.0
+        for (n, p), q in zip(grads, ref64.parameters()):
+            d = p.double() - q.grad
+            num += float((d * d).sum())
+            den += float((q.grad ** 2).sum())
+            rows.append((float(d.abs().max() / (q.grad.abs().max() + 1e-30)), n))
+        return (num / den) ** 0.5, sorted(rows, reverse=True)
+    rel, rows = distance([(n, p.grad.cpu()) for n, p in net.module.named_parameters()])
+    rel32, rows32 = distance([(n, p.grad) for n, p in ref32.named_parameters()])
+    above = [r for r in rows if r[0] > 1e-4]
+    print("fp32 gradients vs float64: ours rel-L2 %.2e, worst %.2e (%s), %d of %d parameters above 1e-4; "
+          "the fp32 CPU path rel-L2 %.2e, worst %.2e (%s)" % (rel, rows[0][0], rows[0][1], len(above), len(rows),
+                                                              rel32, rows32[0][0], rows32[0][1]))
+    assert rel <= 5e-5, rel
+    assert rows[0][0] <= 2e-2 and len(above) <= 8, above
+
+
 def test_bf16_step_at_1024_tracks_the_oracle(cuda, oracle_run):
     """The dtype the bench runs (bf16 activations, fp32 statistics and loss).  A randomly initialised network's logits
     are small differences of large intermediate values, so in bf16 they sit ~20 % (relative RMS) from the fp32 oracle

@@ -177,6 +177,11 @@ def lib():
             raise TsgError(
                 f"{LIB_PATH} not found: build it with `python -m torchseg_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback.")
+        # torch FIRST: its wheel bundles its own libamdhip64.so; libtsg_hip.so is linked against /opt/rocm's.  With torch's
+        # runtime already in the process ours resolves to it (same SONAME) and kernels, streams and pointers belong to
+        # ONE HIP runtime; loaded the other way round (`python __graft_entry__.py --smoke`: build() before torch) every
+        # launch on a torch stream came back hipErrorNoDevice (round 5)
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale

@@ -116,8 +116,14 @@ static int pick_vec(int dtype, int layout, int64_t C, int64_t HW, const void* p0
 // fp32 partial into 3-6e-4 of the logits: exactly the distance EVERY GPU path kept from the CPU (round 4,
 // tools/diag_fp64_truth.py; reproduced on the CPU by rounding the two sums to fp32).  bf16 tensors (the bench path) keep
 // fp32 accumulators: their values carry 2^-9 of rounding already.
+// Round 5: the BACKWARD sums of an fp32 tensor (sum dy', sum dy' (x - mean)) take the same accumulators: dx = a dy' + Bc (x -
+// mean) + C2 removes dy's components along 1 and xhat, a difference of sums, and the parity mode should not depend on how
+// benign a layer's gradient happens to be.  (What tests/test_headline_gpu.py::test_fp32_gradients_per_parameter_against_
+// float64 measures at 4 x 256^2 — 6.9e-6 global, 7.8e-3 at one parameter — is NOT this: it is ONE ReLU whose argument is
+// 7e-8 in float64 and 0 in fp32, tools/r5/debug_ffm_grad.py.)
 template <typename T, int MODE> struct RedAcc { typedef float type; };
 template <> struct RedAcc<float, 0> { typedef double type; };
+template <> struct RedAcc<float, 1> { typedef double type; };
 
 // Block-wide sum of two doubles, fixed order; result valid in thread 0.  `sm` needs 2 * (blockDim.x / 64) doubles.
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nchw(
           }
 #pragma unroll
           for (int j = 0; j < V; ++j) {
-            a1[j] += pd.v[j];
-            a2[j] = fmaf(pd.v[j], px.v[j] - mu, a2[j]);
+            a1[j] += (AT)pd.v[j];
+            a2[j] = fma((AT)pd.v[j], (AT)(px.v[j] - mu), a2[j]);
           }
         }
       }
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-              a1[j] += pd.v[j];
-              a2[j] = fmaf(pd.v[j], px.v[j] - mu[j], a2[j]);
+              a1[j] += (AT)pd.v[j];
+              a2[j] = fma((AT)pd.v[j], (AT)(px.v[j] - mu[j]), a2[j]);
             }
           }
         }
@@ -855,7 +861,7 @@ static int bn_reduce_dispatch(int mode, const void* x, const void* dy, const voi
   if (!x || !partial) return TSG_E_NULL;
   hipStream_t st = (hipStream_t)stream;
   const int V = pick_vec(dtype, layout, C, HW, x, dy, mask == 1 ? y : nullptr, nullptr, nullptr);
-  *rows = partial_rows(layout, N, C, HW, V) * ((mode == 0 && dtype == TSG_F32) ? 2 : 1);   // fp32 statistics: hi + lo rows
+  *rows = partial_rows(layout, N, C, HW, V) * (dtype == TSG_F32 ? 2 : 1);   // fp32 tensors: fp64 sums as hi + lo rows
 #define GO(T, VV)                                                                          \
   (mode == 0 ? launch_reduce<T, VV, 0>((const T*)x, nullptr, nullptr, layout, N, C, HW,    \
                                        fp, 0, partial, st)                                 \

@@ -7,6 +7,16 @@
 
 #define TSG_WAVE 64
 
+// Every launch of this library first DROPS whatever error an earlier, unrelated HIP call of the calling thread left
+// behind (the framework's own probing calls leave e.g. hipErrorNoDevice = 100 in the thread's last-error slot: round 5,
+// smoke() after a float64 host pass), so that TSG_CHECK_LAUNCH below reports the error of THIS launch only.
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)          \
+  do {                                                                                             \
+    (void)hipGetLastError();                                                                       \
+    (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);           \
+  } while (0)
+
 #define TSG_CHECK_LAUNCH()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \
