@@ -28,6 +28,13 @@ def test_shadows_equal_the_per_layer_casts_and_follow_updates(cuda):
             wb, wrt = bank.get(p, want_rot=True)
             assert wb.stride() == p.stride() and torch.equal(wb, p.detach().to(torch.bfloat16))
             assert torch.equal(wrt, kp.conv3x3_weight_rot180_t(p.detach()))
+            # round 5: the fragment-order images of the general 3x3 kernel (forward, data gradient, parity data gradient)
+            # come out of the same launch and equal what tsg_conv3x3_gen_prep_filter writes for the same filter
+            O, I = p.shape[0], p.shape[1]
+            for mode, bn in ((0, 64), (1, 64), (1, 32)):
+                like = torch.empty(1, O if mode else I, 8, 8, device=p.device)
+                want, _ = kp.conv3x3_gen_prep_filter(p.detach(), mode, like, bn=bn)     # detached: the per-call kernel
+                assert torch.equal(bank.get_gen(p, mode, bn), want), (tuple(p.shape), mode, bn)
     check_all()
     # a torch-side change of ONE parameter is noticed through its version counter; one launch rewrites all shadows
     with torch.no_grad():
@@ -44,7 +51,7 @@ def test_shadows_equal_the_per_layer_casts_and_follow_updates(cuda):
         opt.step()
         assert all(not torch.equal(b, p.detach()) for b, p in zip(before, ps))
         for p in ps:                                   # no refresh is triggered by get(): versions did not move
-            e = bank.entries[id(p)]
+            e = bank.entries[bank._key(p)]
             assert e.version == p._version
             assert torch.equal(e.wb, p.detach().to(torch.bfloat16))
             assert torch.equal(e.wrt, kp.conv3x3_weight_rot180_t(p.detach()))

@@ -44,10 +44,11 @@ _OWN_C64_S1 = _os.environ.get("TSG_CONV_C64_S1", "1") != "0"
 # SyncBatchNorm behind each of the six 64 -> 64 layers (layer1 x 4 at 16 x 64 x 256^2, SpatialPath x 2) skips its own
 # pass over 134 / 34 MB
 _C64_STATS = _os.environ.get("TSG_CONV_C64_STATS", "1") != "0"
-# TSG_WEIGHT_SHADOW=0|1 (default 0): bf16 / rotated filters from torchseg_amd.shadow (one refresh launch per step instead
+# TSG_WEIGHT_SHADOW=1|0 (default 1 since round 5, when the fragment-order filters of the general 3x3 kernel joined the
+# refresh launch: ~57 tiny launches per step gone; round 2-4 text follows): bf16 / rotated filters from torchseg_amd.shadow (one refresh launch per step instead
 # of ~45 cast / rotate launches).  Measured neutral on one MI355X (1032.5 vs 1035.5 img/s: the 4-us launches it removes sit
 # back to back in the queue and cost the GPU almost nothing), so it stays opt-in for hosts that are launch-bound.
-_SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "0") == "1"
+_SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "1") != "0"
 
 
 def _skip_addend(dskip, like_shape):
@@ -79,6 +80,8 @@ class _ConvWrwFn(torch.autograd.Function):
         ctx.s2_gen = (_OWN_S2_DGRAD and not ctx.own and stride == 2 and wb.is_contiguous(memory_format=torch.channels_last)
                       and K.provider().conv3x3_s2_dgrad_supported(wb.shape[1], wb.shape[0]))
         ctx.wrt = wrt                                  # not a graph tensor: a shadow owned by torchseg_amd.shadow
+        # the fp32 master (a parameter) for the parity data gradient: its fragment-order image comes from the shadow bank
+        ctx.master = weight if (ctx.s2_gen and _SHADOW and weight.dtype == torch.float32) else None
         ctx.save_for_backward(x, wb)
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
@@ -109,7 +112,7 @@ class _ConvWrwFn(torch.autograd.Function):
         if ctx.need_dx:
             add = _skip_addend(dskip, x.shape) if ((ctx.own and ctx.stride == 1) or ctx.s2_gen) else None
             if ctx.s2_gen:
-                dx = K.provider().conv3x3_s2_dgrad(dy, wb, ctx.in_hw, addend=add)
+                dx = K.provider().conv3x3_s2_dgrad(dy, wb if ctx.master is None else ctx.master, ctx.in_hw, addend=add)
                 if add is not None:
                     dskip = None
             elif ctx.own and ctx.stride == 2:

@@ -35,6 +35,9 @@ template <> struct Pack<float, 4> : Vec<float> {};
 template <> struct Pack<bf16_t, 8> : Vec<bf16_t> {};
 template <typename T> struct Pack<T, 1> {
   float v[1];
+  typedef T Raw;
+  static __device__ __forceinline__ Raw ldraw(const T* p) { return *p; }
+  __device__ __forceinline__ void unpack(const Raw& t) { v[0] = ld1<T>(&t); }
   __device__ __forceinline__ void load(const T* p) { v[0] = ld1<T>(p); }
   __device__ __forceinline__ void store(T* p) const { st1<T>(p, v[0]); }
 };
@@ -244,37 +247,55 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
   if (live) {
-    for (int64_t row = row0 + r; row < row1; row += (int64_t)kUnroll * R) {
+    // Full groups of kUnroll rows issue ALL their 16-byte loads before any arithmetic (kUnroll, x 2 / x 3 in MODE 1, in
+    // flight per wave); round 4's `if (rr < row1)` around each unrolled row put every load in a divergent branch of its
+    // own, and a load in a branch is waited for at the end of that branch: one load in flight per wave, s_waitcnt vmcnt(0)
+    // after each (profiles/r05_bn_isa.txt).  Rows are accumulated in the same order as before: bit-identical sums.
+    typedef typename Pack<T, V>::Raw Raw;
+    auto accumulate = [&](const Raw& rx, const Raw& rd, const Raw& ry) {
+      Pack<T, V> px;
+      px.unpack(rx);
+      if (MODE == 0) {
 #pragma unroll
-      for (int k = 0; k < kUnroll; ++k) {
-        const int64_t rr = row + (int64_t)k * R;
-        if (rr < row1) {
-          const int64_t off = rr * C + c0;
-          Pack<T, V> px;
-          px.load(x + off);
-          if (MODE == 0) {
+        for (int j = 0; j < V; ++j) { const AT xv = px.v[j]; a1[j] += xv; a2[j] = fma(xv, xv, a2[j]); }
+      } else {
+        Pack<T, V> pd;
+        pd.unpack(rd);
+        if (MASK == 1) {
+          Pack<T, V> py;
+          py.unpack(ry);
 #pragma unroll
-            for (int j = 0; j < V; ++j) { const AT xv = px.v[j]; a1[j] += xv; a2[j] = fma(xv, xv, a2[j]); }
-          } else {
-            Pack<T, V> pd;
-            pd.load(dy + off);
-            if (MASK == 1) {
-              Pack<T, V> py;
-              py.load(y + off);
+          for (int j = 0; j < V; ++j) pd.v[j] = py.v[j] > 0.f ? pd.v[j] : 0.f;
+        } else if (MASK == 2) {
 #pragma unroll
-              for (int j = 0; j < V; ++j) pd.v[j] = py.v[j] > 0.f ? pd.v[j] : 0.f;
-            } else if (MASK == 2) {
+          for (int j = 0; j < V; ++j) pd.v[j] = fmaf(px.v[j], ca[j], cb[j]) > 0.f ? pd.v[j] : 0.f;
+        }
 #pragma unroll
-              for (int j = 0; j < V; ++j) pd.v[j] = fmaf(px.v[j], ca[j], cb[j]) > 0.f ? pd.v[j] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-              a1[j] += (AT)pd.v[j];
-              a2[j] = fma((AT)pd.v[j], (AT)(px.v[j] - mu[j]), a2[j]);
-            }
-          }
+        for (int j = 0; j < V; ++j) {
+          a1[j] += (AT)pd.v[j];
+          a2[j] = fma((AT)pd.v[j], (AT)(px.v[j] - mu[j]), a2[j]);
         }
       }
+    };
+    int64_t row = row0 + r;
+    for (; row + (int64_t)(kUnroll - 1) * R < row1; row += (int64_t)kUnroll * R) {
+      Raw rx[kUnroll], rd[kUnroll], ry[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) {                 // every load of the group first ...
+        const int64_t off = (row + (int64_t)k * R) * C + c0;
+        rx[k] = Pack<T, V>::ldraw(x + off);
+        if (MODE == 1) rd[k] = Pack<T, V>::ldraw(dy + off);
+        if (MODE == 1 && MASK == 1) ry[k] = Pack<T, V>::ldraw(y + off);
+      }
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) accumulate(rx[k], rd[k], ry[k]);   // ... then the arithmetic, in row order
+    }
+    for (; row < row1; row += R) {
+      const int64_t off = row * C + c0;
+      Raw rx = Pack<T, V>::ldraw(x + off), rd = rx, ry = rx;
+      if (MODE == 1) rd = Pack<T, V>::ldraw(dy + off);
+      if (MODE == 1 && MASK == 1) ry = Pack<T, V>::ldraw(y + off);
+      accumulate(rx, rd, ry);
     }
   }
   // cross-row reduction through LDS, fixed order
@@ -358,25 +379,37 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
   const int64_t row0 = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
-  for (int64_t row = row0 + r; row < row1; row += (int64_t)kUnroll * R) {
+  typedef typename Pack<T, V>::Raw Raw;                   // see bn_reduce_nhwc: a group's loads first, then arithmetic + stores
+  auto finish = [&](const Raw& rx, const Raw& rr_, int64_t off) {
+    Pack<T, V> px, pr;
+    px.unpack(rx);
+    if (RES) pr.unpack(rr_);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float t = fmaf(px.v[j], a[j], b[j]);
+      if (RES) t += pr.v[j];
+      if (RELU) t = t > 0.f ? t : 0.f;
+      px.v[j] = t;
+    }
+    px.store(y + off);
+  };
+  int64_t row = row0 + r;
+  for (; row + (int64_t)(kUnroll - 1) * R < row1; row += (int64_t)kUnroll * R) {
+    Raw rx[kUnroll], rs[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
-      const int64_t rr = row + (int64_t)k * R;
-      if (rr < row1) {
-        const int64_t off = rr * C + c0;
-        Pack<T, V> px, pr;
-        px.load(x + off);
-        if (RES) pr.load(res + off);
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          float t = fmaf(px.v[j], a[j], b[j]);
-          if (RES) t += pr.v[j];
-          if (RELU) t = t > 0.f ? t : 0.f;
-          px.v[j] = t;
-        }
-        px.store(y + off);
-      }
+      const int64_t off = (row + (int64_t)k * R) * C + c0;
+      rx[k] = Pack<T, V>::ldraw(x + off);
+      if (RES) rs[k] = Pack<T, V>::ldraw(res + off);
     }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) finish(rx[k], rs[k], (row + (int64_t)k * R) * C + c0);
+  }
+  for (; row < row1; row += R) {
+    const int64_t off = row * C + c0;
+    Raw rx = Pack<T, V>::ldraw(x + off), rs = rx;
+    if (RES) rs = Pack<T, V>::ldraw(res + off);
+    finish(rx, rs, off);
   }
 }
 
@@ -439,30 +472,43 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
   const int64_t row0 = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
-  for (int64_t row = row0 + r; row < row1; row += (int64_t)kUnroll * R) {
+  typedef typename Pack<T, V>::Raw Raw;                   // see bn_reduce_nhwc: a group's loads first, then arithmetic + stores
+  auto finish = [&](const Raw& rd, const Raw& rx, const Raw& ry, int64_t off) {
+    Pack<T, V> pd, px;
+    pd.unpack(rd);
+    px.unpack(rx);
+    if (MASK == 1) {
+      Pack<T, V> py;
+      py.unpack(ry);
+#pragma unroll
+      for (int j = 0; j < V; ++j) pd.v[j] = py.v[j] > 0.f ? pd.v[j] : 0.f;
+    } else if (MASK == 2) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) pd.v[j] = fmaf(px.v[j], a[j], b[j]) > 0.f ? pd.v[j] : 0.f;
+    }
+    if (DRES) pd.store(dres + off);
+#pragma unroll
+    for (int j = 0; j < V; ++j) px.v[j] = fmaf(a[j], pd.v[j], fmaf(bc[j], px.v[j] - mu[j], c2[j]));
+    px.store(dx + off);
+  };
+  int64_t row = row0 + r;
+  for (; row + (int64_t)(kUnroll - 1) * R < row1; row += (int64_t)kUnroll * R) {
+    Raw rd[kUnroll], rx[kUnroll], ry[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
-      const int64_t rr = row + (int64_t)k * R;
-      if (rr < row1) {
-        const int64_t off = rr * C + c0;
-        Pack<T, V> pd, px;
-        pd.load(dy + off);
-        px.load(x + off);
-        if (MASK == 1) {
-          Pack<T, V> py;
-          py.load(y + off);
-#pragma unroll
-          for (int j = 0; j < V; ++j) pd.v[j] = py.v[j] > 0.f ? pd.v[j] : 0.f;
-        } else if (MASK == 2) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) pd.v[j] = fmaf(px.v[j], a[j], b[j]) > 0.f ? pd.v[j] : 0.f;
-        }
-        if (DRES) pd.store(dres + off);
-#pragma unroll
-        for (int j = 0; j < V; ++j) px.v[j] = fmaf(a[j], pd.v[j], fmaf(bc[j], px.v[j] - mu[j], c2[j]));
-        px.store(dx + off);
-      }
+      const int64_t off = (row + (int64_t)k * R) * C + c0;
+      rd[k] = Pack<T, V>::ldraw(dy + off);
+      rx[k] = Pack<T, V>::ldraw(x + off);
+      if (MASK == 1) ry[k] = Pack<T, V>::ldraw(y + off);
     }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) finish(rd[k], rx[k], ry[k], (row + (int64_t)k * R) * C + c0);
+  }
+  for (; row < row1; row += R) {
+    const int64_t off = row * C + c0;
+    Raw rd = Pack<T, V>::ldraw(dy + off), rx = Pack<T, V>::ldraw(x + off), ry = rx;
+    if (MASK == 1) ry = Pack<T, V>::ldraw(y + off);
+    finish(rd, rx, ry, off);
   }
 }
 

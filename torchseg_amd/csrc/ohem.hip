@@ -110,13 +110,22 @@ __device__ __forceinline__ bool label_is_class(int64_t lab, int64_t ignore_label
 }
 
 template <int LT> struct Lab;
+// raw_t / get_raw / widen: a label as the load instruction leaves it in its register(s).  A prefetching loop keeps THAT
+// and widens at the use (behind an asm barrier): any arithmetic on a loaded value, the zero-extension included, is
+// scheduled right behind the load and drags the s_waitcnt for it along.
 template <> struct Lab<TSG_I64> {
   typedef int64_t type;
+  typedef int64_t raw_t;
   static __device__ __forceinline__ int64_t get(const void* p, int64_t i) { return ((const int64_t*)p)[i]; }
+  static __device__ __forceinline__ raw_t get_raw(const void* p, int64_t i) { return ((const int64_t*)p)[i]; }
+  static __device__ __forceinline__ int64_t widen(raw_t r) { asm volatile("" : "+v"(r)); return r; }
 };
 template <> struct Lab<TSG_U8> {
   typedef uint8_t type;
+  typedef uint32_t raw_t;
   static __device__ __forceinline__ int64_t get(const void* p, int64_t i) { return (int64_t)((const uint8_t*)p)[i]; }
+  static __device__ __forceinline__ raw_t get_raw(const void* p, int64_t i) { return ((const uint8_t*)p)[i]; }
+  static __device__ __forceinline__ int64_t widen(raw_t r) { asm volatile("" : "+v"(r)); return (int64_t)(r & 0xffu); }
 };
 
 template <typename T, int V> struct PixVec;
@@ -711,6 +720,205 @@ __global__ __launch_bounds__(kT) void ohem_up_fwd_k(
   fold_block(acc, lh, bins0, hist0, part);
 }
 
+
+// ---- forward, second form (round 5; VERDICT r4 item 4: the first form spent 2.8x the exponential floor on index
+// arithmetic).  Same tile (256 columns x 32 rows), same results up to the rounding of the log-sum-exp shift; what changed:
+//   * the z window sits in LDS PIXEL-major, [WR x WC][CP]: the four taps of a column are four pixels, and a rebuild of
+//     H0 / D reads each as CP / 4 ds_read_b128 (20 LDS instructions for 20 classes; the class-major window took 80
+//     ds_read_b32 with an address per class).  Pixels 80 B apart: 16-byte reads of 8 distinct pixels per wave fall on
+//     disjoint bank groups;
+//   * the window is staged by (class, source row) pairs per WAVE with the source column on the lanes: no integer division
+//     per element (the first form: two divisions and a modulo by run-time values for each of its 16 elements per thread);
+//   * the softmax shift is an upper BOUND of the pixel's logits instead of their maximum: M = the largest class maximum of
+//     the four tap pixels (one pass over the window per tile), folded into H0 when H0 / D are rebuilt, so that
+//     v_c = fma(ly, D_c, H0_c) already is logit - M: no 10-step v_max3 chain and no 10 packed subtractions per pixel.  An
+//     interpolated logit never exceeds the largest tap logit, so exp2(v_c) <= 1; should every exp2 underflow (taps that
+//     disagree by > 100 in log2 units about which class is large) the wave redoes the row with the exact maximum;
+//   * the row's (y0, ly) come from a 32-entry LDS table filled once per tile (they were recomputed on the VALU by every
+//     thread for every row), nll / lse addresses advance by a row stride.
+template <typename T, int LT, int CP>
+__global__ __launch_bounds__(kT) void ohem_up_fwd2_k(
+    const T* __restrict__ z, const void* __restrict__ labels, int64_t B, UpFwdGeom g,
+    int64_t ignore_label, float thresh, int64_t tb, int shift0, int bins0,
+    const float* __restrict__ weight, float* __restrict__ nll_out, float* __restrict__ lse_out,
+    uint32_t* __restrict__ hist0, BlkPart* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lh[];       // [hist_words] histogram
+  const int C = g.C, IH = g.IH, IW = g.IW, OH = g.OH, OW = g.OW, WR = g.WR, WC = g.WC;
+  const int npix = WR * WC;
+  float* Zw = reinterpret_cast<float*>(lh + g.hist_words);            // [npix][CP] window of z * log2(e), pixel-major
+  float* Zmax = Zw + (size_t)npix * CP;                               // [npix] class maximum of each window pixel
+  int* yro = reinterpret_cast<int*>(Zmax + ((npix + 3) & ~3));        // [kFwdBand] window pixel offset of the row's y0
+  float* yly = reinterpret_cast<float*>(yro + kFwdBand);              // [kFwdBand] lambda_y of the row
+  float* wtab = yly + kFwdBand;                                       // [32] class weights (1 without a weight vector): no
+  //                                                                     global load, hence no vmcnt wait, in the row loop
+  uint8_t* lab_s = reinterpret_cast<uint8_t*>(wtab + 32);             // [kFwdBand][kT] labels (255 = ignored)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < bins0; i += kT) lh[i] = 0;
+  if (tid < 32) wtab[tid] = (weight && tid < g.C) ? weight[tid] : 1.f;
+  PassAcc acc;
+  const int64_t total = B * g.bands * (int64_t)g.xblocks;
+  const int64_t plane = (int64_t)IH * IW;
+  for (int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int xb = (int)(tile % g.xblocks);
+    const int band = (int)((tile / g.xblocks) % g.bands);
+    const int64_t b = tile / ((int64_t)g.xblocks * g.bands);
+    const int oy_beg = band * kFwdBand;
+    const int oy_end = oy_beg + kFwdBand < OH ? oy_beg + kFwdBand : OH;
+    const int ox = xb * kT + tid;
+    const bool live = ox < OW;
+    int ys_lo, xs_lo, t1; float tf;
+    src_index0(g.sy, oy_beg, IH, ys_lo, t1, tf);
+    src_index0(g.sx, xb * kT, IW, xs_lo, t1, tf);
+    const T* zb = z + b * C * plane;
+    __syncthreads();                                   // the previous tile's readers are done (also orders lh init)
+    // window: wave wv takes the (class, row) pairs wv, wv + 4, ...; lanes = source columns.  EIGHT pairs' loads are in
+    // flight per wave before the first LDS write (one load -> one write per iteration was a chain of 30 L2 round trips per
+    // tile and held the VALU at 0.68 busy: profiles/r05_heads.txt)
+    for (int x0s = 0; x0s < WC; x0s += 64) {
+      const int xx = x0s + lane;
+      const int xg = xs_lo + xx < IW ? xs_lo + xx : IW - 1;
+      const bool xin = xx < WC;
+      int c = 0, rr = wv;
+      while (rr >= WR) { rr -= WR; ++c; }
+      while (c < CP) {
+        float val[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          // UNCONDITIONAL loads from clamped addresses, the condition applied to the value: a load inside a divergent
+          // branch is followed by s_waitcnt vmcnt(0) at the end of that branch, i.e. one memory round trip per element
+          const bool on = c < CP;
+          const int yy = ys_lo + rr < IH ? ys_lo + rr : IH - 1;
+          const int cc = c < C ? c : C - 1;
+          const float raw = ld1<T>(zb + (int64_t)cc * plane + (int64_t)yy * IW + xg) * kLog2e;
+          val[u] = c < C ? raw : kNegBig;
+          off[u] = (on && xin) ? (rr * WC + xx) * CP + c : -1;
+          rr += kT / 64;
+          while (rr >= WR) { rr -= WR; ++c; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (off[u] >= 0) Zw[off[u]] = val[u];
+      }
+    }
+    if (tid < kFwdBand) {
+      int y0, y1; float ly;
+      const int oy = oy_beg + tid < OH ? oy_beg + tid : OH - 1;
+      src_index0(g.sy, oy, IH, y0, y1, ly);
+      yro[tid] = (y0 - ys_lo) * WC;
+      yly[tid] = ly;
+    }
+    // labels of the whole tile: kFwdBand independent loads in flight per thread; each thread only ever reads
+    // back its own column
+#pragma unroll 1
+    for (int u0 = 0; u0 < kFwdBand; u0 += 16) {
+      int64_t lab[16];
+      const int oxc = ox < OW ? ox : OW - 1;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int oy = oy_beg + u0 + u;
+        const int oyc = oy < OH ? oy : OH - 1;
+        const int64_t v = Lab<LT>::get(labels, (b * OH + oyc) * (int64_t)OW + oxc);     // unconditional, clamped (see above)
+        lab[u] = (live && oy < oy_end) ? v : ignore_label;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool is_cls = label_is_class(lab[u], ignore_label, C);
+        if (!is_cls && lab[u] != ignore_label) acc.cnt_bad++;
+        lab_s[(u0 + u) * kT + tid] = is_cls ? (uint8_t)lab[u] : (uint8_t)255;
+      }
+    }
+    __syncthreads();
+    for (int p = tid; p < npix; p += kT) {             // class maximum of every window pixel (padding classes hold -1e30)
+      const float4* zp = reinterpret_cast<const float4*>(Zw + (size_t)p * CP);
+      float m = kNegBig;
+#pragma unroll
+      for (int q = 0; q < CP / 4; ++q) { const float4 t = zp[q]; m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w)); }
+      Zmax[p] = m;
+    }
+    __syncthreads();
+    if (!live) continue;
+    int x0, x1; float lx;
+    src_index0(g.sx, ox, IW, x0, x1, lx);
+    const int xl0 = x0 - xs_lo;                        // x1 = x0 + 1 except on the last source column, where lx = 0 and the
+    //                                                    window's clamped copy of that column sits at xl0 + 1
+    up_f2 H0[CP / 2], D[CP / 2];                       // H0 already holds (row-y0 logit - M)
+    const up_f2 lx2 = {lx, lx};
+    float M = 0.f;
+    int cro = -1, p00 = 0;
+    float* nll_p = nll_out + (b * OH + oy_beg) * (int64_t)OW + ox;
+    float* lse_p = lse_out + (b * OH + oy_beg) * (int64_t)OW + ox;
+    const int nrows = oy_end - oy_beg;
+    for (int r = 0; r < nrows; ++r, nll_p += OW, lse_p += OW) {
+      const int ro = __builtin_amdgcn_readfirstlane(yro[r]);
+      const float ly = yly[r];
+      if (ro != cro) {
+        p00 = (ro + xl0) * CP;
+        const float* zm = Zmax + ro + xl0;
+        M = fmaxf(fmaxf(zm[0], zm[1]), fmaxf(zm[WC], zm[WC + 1]));
+        const float4* A0 = reinterpret_cast<const float4*>(Zw + p00);
+        const float4* A1 = reinterpret_cast<const float4*>(Zw + p00 + CP);
+        const float4* B0 = reinterpret_cast<const float4*>(Zw + p00 + WC * CP);
+        const float4* B1 = reinterpret_cast<const float4*>(Zw + p00 + WC * CP + CP);
+        const up_f2 M2 = {M, M};
+#pragma unroll
+        for (int q = 0; q < CP / 4; ++q) {
+          const float4 a0 = A0[q], a1 = A1[q], b0 = B0[q], b1 = B1[q];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const up_f2 a0p = k ? up_f2{a0.z, a0.w} : up_f2{a0.x, a0.y};
+            const up_f2 a1p = k ? up_f2{a1.z, a1.w} : up_f2{a1.x, a1.y};
+            const up_f2 b0p = k ? up_f2{b0.z, b0.w} : up_f2{b0.x, b0.y};
+            const up_f2 b1p = k ? up_f2{b1.z, b1.w} : up_f2{b1.x, b1.y};
+            const up_f2 h0 = __builtin_elementwise_fma(lx2, a1p - a0p, a0p);
+            const up_f2 h1 = __builtin_elementwise_fma(lx2, b1p - b0p, b0p);
+            H0[q * 2 + k] = h0 - M2;
+            D[q * 2 + k] = h1 - h0;
+          }
+        }
+        cro = ro;
+      }
+      up_f2 v[CP / 2];
+      const up_f2 ly2 = {ly, ly};
+      up_f2 s2 = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CP / 2; ++c) {
+        v[c] = __builtin_elementwise_fma(ly2, D[c], H0[c]);
+        s2 += up_f2{__builtin_amdgcn_exp2f(v[c].x), __builtin_amdgcn_exp2f(v[c].y)};
+      }
+      float ssum = s2.x + s2.y;
+      float lr = __builtin_amdgcn_logf(ssum);          // log2(sum exp2(logit - M))
+      if (__builtin_amdgcn_ballot_w64(!(ssum >= 1.0e-30f)) != 0) {
+        // every term underflowed somewhere in this wave (or a NaN): the row again with the exact maximum
+        float m = kNegBig;
+#pragma unroll
+        for (int c = 0; c < CP / 2; ++c) m = fmaxf(m, fmaxf(v[c].x, v[c].y));
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP / 2; ++c) s += __builtin_amdgcn_exp2f(v[c].x - m) + __builtin_amdgcn_exp2f(v[c].y - m);
+        lr = m + __builtin_amdgcn_logf(s);
+      }
+      const int lab = lab_s[r * kT + tid];
+      const bool valid = lab != 255;
+      const int t = valid ? lab : 0;
+      float xt;
+      {  // the target logit (- M), by the expressions that produced v[t]
+        const float a0 = Zw[p00 + t], a1 = Zw[p00 + CP + t], b0 = Zw[p00 + WC * CP + t], b1 = Zw[p00 + WC * CP + CP + t];
+        const float h0 = __builtin_fmaf(lx, a1 - a0, a0), h1 = __builtin_fmaf(lx, b1 - b0, b0);
+        xt = __builtin_fmaf(ly, h1 - h0, h0 - M);
+      }
+      float nl = (lr - xt) * kLn2;
+      nl = nl < 0.f ? 0.f : nl;
+      nl = valid ? nl : 0.f;
+      *nll_p = nl;
+      *lse_p = (lr + M) * kLn2;
+      const float w = wtab[t];
+      account(acc, valid, nl, w, thresh, tb, shift0, bins0, lh);
+    }
+  }
+  fold_block(acc, lh, bins0, hist0, part);
+}
+
 struct UpBwdGeom { int C, IH, IW, OH, OW; float sy, sx; int RB, SB, XS; };
 
 template <typename T, int LT, int CP, int NTMAX>
@@ -727,6 +935,9 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
   float* lxs = Zr + 2 * CP * XS;                      // [NT] lambda_x of every column of the block
   float* Vs = lxs + NT;                               // [NT][VP] a completed source row, before the horizontal taps
   int* xst = reinterpret_cast<int*>(Vs + NT * VP);    // [XS + 2] first column whose x0 is xs_lo + j
+  float* wtab = reinterpret_cast<float*>(xst + XS + 2);   // [CP] gs * class weight: read per pixel from LDS, so that the row
+  //                                                         loop holds no global load whose wait would also wait for the
+  //                                                         prefetched next row (round 5: SQ_WAIT_ANY 0.54 was this)
   const int s0 = blockIdx.x * g.SB, s1 = s0 + g.SB < IW ? s0 + g.SB : IW;
   const int r0 = blockIdx.y * g.RB, r1 = r0 + g.RB < IH ? r0 + g.RB : IH;
   const int64_t b = blockIdx.z;
@@ -743,6 +954,7 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
   lxs[tid] = live ? lx : 0.f;
   for (int i = tid; i < CP * CP; i += NT) oh[i] = (i / CP == i % CP) ? 1.f : 0.f;
   for (int j = tid; j < XS + 2; j += NT) xst[j] = nact;
+  if (tid < CP) wtab[tid] = (weight && tid < C) ? weight[tid] : 1.f;
   __syncthreads();
   if (live) {
     int p0 = -1, p1; float pf;
@@ -800,11 +1012,15 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
       Zr[slot * CP * XS + i] = c < C ? ld1<T>(zb + c * plane + (int64_t)y * IW + xg) * kLog2e : kNegBig;
     }
   };
-  struct Side { int64_t lab; float nl, ls; };
+  struct Side { typename Lab<LT>::raw_t lab; float nl, ls; };
   auto load_side = [&](int oy) {
     Side sd;
     const int64_t gp = (b * OH + oy) * (int64_t)OW + ox;
-    sd.lab = live ? Lab<LT>::get(labels, gp) : ignore_label;
+    // unconditional (ox is clamped) and NOT touched here: a load inside a divergent branch is waited for at the end of that
+    // branch, and so is a loaded value the moment anything (even `live ? v : ignore`) consumes it — either way the
+    // prefetch of the next row degenerated into one exposed memory round trip per row (round 5: SQ_WAIT_ANY 0.54).
+    // `live` is applied where the label is used.
+    sd.lab = Lab<LT>::get_raw(labels, gp);
     sd.nl = nll[gp];
     sd.ls = lse[gp];
     return sd;
@@ -844,11 +1060,12 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
       }
       cur = y0;
     }
-    const bool valid = live && label_is_class(sd.lab, ignore_label, C);
+    const int64_t lab = Lab<LT>::widen(sd.lab);
+    const bool valid = live && label_is_class(lab, ignore_label, C);
     bool kept = valid;
     if (valid && branch != 2) kept = prob_of_nll(sd.nl) <= thr;
-    const int t = valid ? (int)sd.lab : 0;
-    const float coef = kept ? gs * (weight ? weight[t] : 1.f) : 0.f;
+    const int t = valid ? (int)lab : 0;
+    const float coef = kept ? gs * wtab[t] : 0.f;
     if (__builtin_amdgcn_ballot_w64(coef != 0.f) == 0) continue;      // nothing kept in this wave's 64 columns
     const float l2 = sd.ls * kLog2e;
     const float ca = coef - ly * coef, cb = ly * coef;
@@ -872,7 +1089,12 @@ __global__ __launch_bounds__(NTMAX) void ohem_up_bwd_k(
 }
 
 static int up_class_pad(int C) { return C <= 8 ? 8 : C <= 16 ? 16 : C <= 20 ? 20 : C <= 24 ? 24 : 32; }
-static int up_bwd_ntmax(int CP) { return CP <= 20 ? 1024 : 512; }   // 4 register arrays of CP floats per thread
+// 4 register arrays of CP floats per thread.  TSG_HEAD_BWD_NT=512|1024: threads (= output columns) per backward block
+static int up_bwd_ntmax(int CP) {
+  static const int forced = [] { const char* e = getenv("TSG_HEAD_BWD_NT"); return e ? atoi(e) : 0; }();
+  const int lim = CP <= 20 ? 1024 : 512;
+  return (forced == 512 || forced == 256) ? (forced < lim ? forced : lim) : lim;
+}
 
 static UpFwdGeom up_fwd_geom(int C, int IH, int IW, int OH, int OW, int bins0) {
   UpFwdGeom g;
@@ -886,7 +1108,13 @@ static UpFwdGeom up_fwd_geom(int C, int IH, int IW, int OH, int OW, int bins0) {
   return g;
 }
 static size_t up_fwd_lds(const UpFwdGeom& g, int CP) {
-  return (size_t)g.hist_words * 4 + (size_t)CP * g.WR * g.WC * 4 + (size_t)kFwdBand * kT;
+  return (size_t)g.hist_words * 4 + (size_t)CP * g.WR * g.WC * 4 + (size_t)((g.WR * g.WC + 3) & ~3) * 4 +
+         (size_t)kFwdBand * 8 + 32 * 4 + (size_t)kFwdBand * kT;
+}
+// TSG_HEAD_FWD=2|1 (default 2): the forward form (ohem_up_fwd2_k / the round-3 ohem_up_fwd_k)
+static int up_fwd_form() {
+  static const int v = [] { const char* e = getenv("TSG_HEAD_FWD"); return e ? atoi(e) : 2; }();
+  return v == 1 ? 1 : 2;
 }
 
 // backward tiling: the fewest column tiles whose output-column footprint fits one block
@@ -911,7 +1139,7 @@ static UpBwdCfg up_bwd_cfg(int64_t B, int C, int IH, int IW, int OH, int OW) {
     if (need > ntmax) continue;
     const int NT = (need + 63) / 64 * 64;
     const int XS = SB + 5;
-    const size_t lds = ((size_t)CP * CP + 2 * (size_t)CP * XS + NT + (size_t)NT * (CP + 1) + XS + 2 + 4) * 4;
+    const size_t lds = ((size_t)CP * CP + 2 * (size_t)CP * XS + NT + (size_t)NT * (CP + 1) + XS + 2 + CP + 4) * 4;
     if (lds > 150 * 1024) continue;
     g.SB = SB; g.XS = XS;
     cf.k = (IW + SB - 1) / SB; cf.NT = NT; cf.lds = lds; cf.ok = true;
@@ -1127,9 +1355,12 @@ int tsg_ohem_up_fwd(const void* z, int dtype, const void* labels, int ltype, int
   const UpFwdGeom g = up_fwd_geom(C, IH, IW, OH, OW, bins0);
   const int CP = up_class_pad(C);
   const size_t sh = up_fwd_lds(g, CP);
+  const bool form2 = up_fwd_form() == 2;
 #define PA(T, LTT, CM)                                                                                \
-  hipLaunchKernelGGL((ohem_up_fwd_k<T, LTT, CM>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, g, \
-                     ignore_label, thresh, tb, pl.shift[0], bins0, weight, nll, lse, w.hist[0], w.part)
+  do { if (form2) hipLaunchKernelGGL((ohem_up_fwd2_k<T, LTT, CM>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, g, \
+                     ignore_label, thresh, tb, pl.shift[0], bins0, weight, nll, lse, w.hist[0], w.part); \
+       else hipLaunchKernelGGL((ohem_up_fwd_k<T, LTT, CM>), dim3(pl.grid), dim3(kT), sh, st, (const T*)z, labels, B, g, \
+                     ignore_label, thresh, tb, pl.shift[0], bins0, weight, nll, lse, w.hist[0], w.part); } while (0)
 #define PC(T, LTT) do { switch (CP) { case 8: PA(T, LTT, 8); break; case 16: PA(T, LTT, 16); break; \
     case 20: PA(T, LTT, 20); break; case 24: PA(T, LTT, 24); break; default: PA(T, LTT, 32); } } while (0)
   if (dtype == TSG_F32) { if (ltype == TSG_I64) PC(float, TSG_I64); else PC(float, TSG_U8); }

@@ -260,9 +260,19 @@ struct ShadowEntry {
   const float* w;
   bf16_t* wb;
   bf16_t* wrt;
-  int n, O, I, pad;
+  bf16_t* wf0;        // round 5: the filter in MFMA fragment order for tsg_conv3x3_gen_fwd (g3_prep_filter_k mode 0), or 0
+  bf16_t* wf1;        // ... and for the data gradient (mode 1: rot180 + transpose; tile width bn1 = 32 for tsg_conv3x3_s2_dgrad)
+  int n, O, I, bn0, bn1, pad;
 };
-static_assert(sizeof(ShadowEntry) == 40 || sizeof(ShadowEntry) == 48, "layout shared with torchseg_amd/shadow.py");
+static_assert(sizeof(ShadowEntry) == 64, "layout shared with torchseg_amd/shadow.py");
+
+// element offset of W'[oc][tap][ci] in the fragment-order image of csrc/conv3g.hip (g3_prep_filter_k):
+//   out[oc tile][chunk][tap][ocb][lane][e],  oc = tile BN + ocb 32 + (lane & 31),  ci = chunk 16 + (lane >> 5) 8 + e
+__device__ __forceinline__ int64_t g3_frag_offset(int oc, int tap, int ci, int Ci, int BN) {
+  const int nch = Ci >> 4, ocb_n = BN >> 5;
+  const int tile = oc / BN, rem = oc - tile * BN, ocb = rem >> 5, ln = ((ci >> 3) & 1) * 32 + (rem & 31);
+  return ((((int64_t)(tile * nch + (ci >> 4)) * 9 + tap) * ocb_n + ocb) * 64 + ln) * 8 + (ci & 7);
+}
 
 __global__ __launch_bounds__(256) void weight_shadow_k(const ShadowEntry* __restrict__ table, const int2* __restrict__ map) {
   const int2 m = map[blockIdx.x];
@@ -270,12 +280,15 @@ __global__ __launch_bounds__(256) void weight_shadow_k(const ShadowEntry* __rest
   const int base = m.y * kSgdChunk;
   const int end = base + kSgdChunk < e.n ? base + kSgdChunk : e.n;
   const int tapI = 9 * e.I;
+  const bool geo = e.wrt || e.wf0 || e.wf1;
   for (int i = base + threadIdx.x; i < end; i += 256) {
     const bf16_t v = f32_to_bf16(e.w[i]);
-    e.wb[i] = v;
-    if (e.wrt) {
+    if (e.wb) e.wb[i] = v;
+    if (geo) {                                         // w is [O][3][3][I] (a channels_last 3x3 filter)
       const int o = i / tapI, r = i - o * tapI, tap = r / e.I, ci = r - tap * e.I;
-      e.wrt[(ci * 9 + (8 - tap)) * e.O + o] = v;
+      if (e.wrt) e.wrt[(ci * 9 + (8 - tap)) * e.O + o] = v;
+      if (e.wf0) e.wf0[g3_frag_offset(o, tap, ci, e.I, e.bn0)] = v;             // W' = w: C_out' = O, C_in' = I
+      if (e.wf1) e.wf1[g3_frag_offset(ci, 8 - tap, o, e.O, e.bn1)] = v;         // W'[ci][8 - tap][o] = w[o][tap][ci]
     }
   }
 }

@@ -55,9 +55,15 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
 // Vec<T>: one 16-byte global access worth of elements, unpacked to floats.
 template <typename T> struct Vec;
 
+// Raw / ldraw / unpack: the 16 bytes as the load leaves them, and the conversion as a separate step.  A streaming loop that
+// wants SEVERAL loads in flight issues all its ldraw() first and unpacks afterwards: load() converts at once, and any
+// arithmetic on a loaded value is where the compiler puts the s_waitcnt for it.
 template <> struct Vec<float> {
   static constexpr int N = 4;
   float v[4];
+  typedef float4 Raw;
+  static __device__ __forceinline__ Raw ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void unpack(const Raw& t) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
   __device__ __forceinline__ void load(const float* p) {
     float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -70,6 +76,16 @@ template <> struct Vec<float> {
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
   float v[8];
+  typedef uint4 Raw;
+  static __device__ __forceinline__ Raw ldraw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(const Raw& t) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i]     = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
   __device__ __forceinline__ void load(const bf16_t* p) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
     uint32_t w[4] = {t.x, t.y, t.z, t.w};

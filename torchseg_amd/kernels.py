@@ -53,6 +53,11 @@ def _label_code(t):
 
 
 
+# TSG_WEIGHT_SHADOW=1|0 (default 1 since round 5): prepared (fragment-order) filters of parameters come from
+# torchseg_amd.shadow — ONE refresh launch per optimizer step instead of one preparation launch per convolution and direction
+_SHADOW_PREP = os.environ.get("TSG_WEIGHT_SHADOW", "1") != "0"
+
+
 class HipKernels:
     """libtsg_hip.so kernels on torch's current HIP stream."""
 
@@ -781,6 +786,9 @@ class HipKernels:
             raise ValueError("conv3x3_gen_prep_filter: the input does not have the filter's channel count")
         if bn is None:
             bn = self.conv3x3_gen_tile(B, H, W, Cin, Cout)
+        if _SHADOW_PREP and weight.dtype == torch.float32 and weight.is_leaf and weight.requires_grad:
+            from .shadow import bank                  # a parameter: its prepared images are refreshed once per optimizer step
+            return bank.get_gen(weight, int(mode), bn), bn
         out = torch.empty(9 * O * I, dtype=torch.bfloat16, device=weight.device)
         L.check(self.lib.tsg_conv3x3_gen_prep_filter(weight.data_ptr(), L.dtype_code(weight), out.data_ptr(), O, I, int(mode),
                                                      bn, L.stream_ptr(weight)), "tsg_conv3x3_gen_prep_filter")

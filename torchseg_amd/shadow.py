@@ -21,22 +21,26 @@ _CHUNK = 4096          # elements per block (kSgdChunk of csrc/sgd.hip)
 
 
 class _Entry(object):
-    __slots__ = ("ref", "wb", "wrt", "version")
+    __slots__ = ("ref", "wb", "wrt", "wf", "version")
 
     def __init__(self, param, want_rot):
         self.ref = weakref.ref(param)
         self.wb = torch.empty_like(param, dtype=torch.bfloat16)                       # same strides as the parameter
         self.wrt = None
+        self.wf = {}                 # mode (0 forward / 1 data gradient) -> (fragment-order filter, tile width)
         if want_rot:
-            O, I = param.shape[0], param.shape[1]
-            self.wrt = torch.empty((I, O, 3, 3), dtype=torch.bfloat16, device=param.device,
-                                   memory_format=torch.channels_last)
+            self.add_rot(param)
         self.version = -1
+
+    def add_rot(self, param):
+        O, I = param.shape[0], param.shape[1]
+        self.wrt = torch.empty((I, O, 3, 3), dtype=torch.bfloat16, device=param.device,
+                               memory_format=torch.channels_last)
 
 
 class _Bank(object):
     def __init__(self):
-        self.entries = {}            # id(param) -> _Entry
+        self.entries = {}            # (data_ptr, shape, stride) of the parameter -> _Entry
         self._table = None           # (device table, block map, n_entries)
 
     def _prune(self):
@@ -46,33 +50,50 @@ class _Bank(object):
         if dead:
             self._table = None
 
+    @staticmethod
+    def _key(param):
+        # the storage, not the Python object: autograd hands a saved parameter back as an alias of the same storage
+        return (param.data_ptr(), tuple(param.shape), tuple(param.stride()))
+
     def register(self, param, want_rot):
-        e = self.entries.get(id(param))
-        if e is not None and e.ref() is param and (e.wrt is not None or not want_rot) and e.wb.device == param.device \
-                and e.wb.stride() == param.stride():
+        e = self.entries.get(self._key(param))
+        if e is not None and e.ref() is not None and e.wb.device == param.device:
+            if want_rot and e.wrt is None:                # first asked for later than the plain cast: extend the entry
+                self._check_rot(param)
+                e.add_rot(param)
+                e.version = -1
+                self._table = None
             return e
         if param.dtype != torch.float32 or not param.is_cuda:
             raise K.L.TsgError("weight shadows are kept for fp32 parameters on the GPU")
-        if want_rot and not (param.dim() == 4 and tuple(param.shape[2:]) == (3, 3)
-                             and param.is_contiguous(memory_format=torch.channels_last)):
-            raise K.L.TsgError("the rotated shadow needs a channels_last [O, I, 3, 3] filter")
+        if want_rot:
+            self._check_rot(param)
         if not (param.is_contiguous() or (param.dim() == 4 and param.is_contiguous(memory_format=torch.channels_last))):
             raise K.L.TsgError("weight shadows need a dense parameter")
         self._prune()
-        e = self.entries[id(param)] = _Entry(param, want_rot)
+        e = self.entries[self._key(param)] = _Entry(param, want_rot)
         self._table = None
         return e
 
+    @staticmethod
+    def _check_rot(param):
+        if not (param.dim() == 4 and tuple(param.shape[2:]) == (3, 3)
+                and param.is_contiguous(memory_format=torch.channels_last)):
+            raise K.L.TsgError("the rotated / fragment-order shadows need a channels_last [O, I, 3, 3] filter")
+
     def _build(self, device):
         ents = [e for e in self.entries.values() if e.ref() is not None and e.wb.device == device]
-        dt = np.dtype([("w", "<u8"), ("wb", "<u8"), ("wrt", "<u8"), ("n", "<i4"), ("O", "<i4"), ("I", "<i4"), ("pad", "<i4")])
+        dt = np.dtype([("w", "<u8"), ("wb", "<u8"), ("wrt", "<u8"), ("wf0", "<u8"), ("wf1", "<u8"), ("n", "<i4"), ("O", "<i4"),
+                       ("I", "<i4"), ("bn0", "<i4"), ("bn1", "<i4"), ("pad", "<i4")])
         assert dt.itemsize == K.provider().lib.tsg_weight_shadow_entry_bytes()
         tab = np.zeros(len(ents), dtype=dt)
         maps = []
         for i, e in enumerate(ents):
             p = e.ref()
-            tab[i] = (p.data_ptr(), e.wb.data_ptr(), 0 if e.wrt is None else e.wrt.data_ptr(), p.numel(),
-                      p.shape[0], p.shape[1] if p.dim() > 1 else 1, 0)
+            f0, f1 = e.wf.get(0), e.wf.get(1)
+            tab[i] = (p.data_ptr(), e.wb.data_ptr(), 0 if e.wrt is None else e.wrt.data_ptr(),
+                      0 if f0 is None else f0[0].data_ptr(), 0 if f1 is None else f1[0].data_ptr(), p.numel(),
+                      p.shape[0], p.shape[1] if p.dim() > 1 else 1, 0 if f0 is None else f0[1], 0 if f1 is None else f1[1], 0)
             nb = (p.numel() + _CHUNK - 1) // _CHUNK
             maps.append(np.stack([np.full(nb, i, dtype=np.int32), np.arange(nb, dtype=np.int32)], 1))
         bmap = np.concatenate(maps, 0)
@@ -105,6 +126,26 @@ class _Bank(object):
         if e.version != param._version:
             self.refresh_all(param.device)
         return e.wb, e.wrt
+
+
+    def get_gen(self, param, mode, bn):
+        """The filter of `param` ([O, I, 3, 3] channels_last fp32 master) in the MFMA fragment order of csrc/conv3g.hip
+        (what tsg_conv3x3_gen_prep_filter writes: mode 0 forward, mode 1 data gradient; `bn` = tile width), kept fresh by
+        the same one launch per optimizer step as the plain bf16 casts — 32 preparation launches per BiSeNet step gone."""
+        e = self.register(param, False)
+        cur = e.wf.get(mode)
+        if cur is None or cur[1] != bn:
+            self._check_rot(param)
+            O, I = param.shape[0], param.shape[1]
+            Co, Ci = (I, O) if mode else (O, I)
+            if Ci % 16 or Co % bn or bn not in (32, 64, 128):
+                raise K.L.TsgError("fragment-order shadow: C_in %% 16 / C_out %% tile width (%d, %d, %d)" % (Ci, Co, bn))
+            e.wf[mode] = (torch.empty(9 * O * I, dtype=torch.bfloat16, device=param.device), bn)
+            e.version = -1
+            self._table = None
+        if e.version != param._version:
+            self.refresh_all(param.device)
+        return e.wf[mode][0]
 
 
 bank = _Bank()

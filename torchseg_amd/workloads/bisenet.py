@@ -17,6 +17,20 @@ from base_model import resnet18  # noqa: E402
 from seg_opr.seg_oprs import AttentionRefinement, ConvBnRelu, FeatureFusion, cbr_chain  # noqa: E402
 
 
+import os as _os
+# TSG_FORK_SPATIAL=1|0: SpatialPath on a side HIP stream beside the context path (forward and, through autograd, backward)
+_FORK_SPATIAL = _os.environ.get("TSG_FORK_SPATIAL", "0") == "1"
+_SIDE = {}
+
+
+def _side_stream(device):
+    import torch
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _cbr(cin, cout, k, s, p, norm_layer, relu=True):
     return ConvBnRelu(cin, cout, k, s, p, has_bn=True, norm_layer=norm_layer, has_relu=relu, has_bias=False)
 
@@ -84,13 +98,29 @@ class BiSeNet(nn.Module):
 
     def features(self, data):
         """-> [1/16 aux fm, 1/8 aux fm, fused 1/8 fm] (network.py:75-101)."""
-        spatial_out = self.spatial_path(data)
+        fork = None
+        if data.is_cuda and _FORK_SPATIAL:
+            # the two paths share nothing until the fusion module: the detail branch (large maps: HBM-bound BatchNorm passes
+            # and stems) runs on a side stream beside the context path's deep layers (small maps: matrix-core bound, too few
+            # tiles to fill the chip on their own); autograd replays each node on its forward stream, so the backward
+            # overlaps the same way
+            import torch
+            cur = torch.cuda.current_stream(data.device)
+            fork = _side_stream(data.device)
+            fork.wait_stream(cur)
+            with torch.cuda.stream(fork):
+                spatial_out = self.spatial_path(data)
+        else:
+            spatial_out = self.spatial_path(data)
         c2, c3, c4, c5 = self.context_path(data)
         last_fm = _up(self.global_context(c5), size=c5.shape[2:])
         outs = []
         for fm, nxt, arm, refine in zip((c5, c4), (c4, c3), self.arms, self.refines):
             last_fm = refine(add_then_upsample(arm(fm), last_fm, nxt.shape[2:]))   # network.py:91-95
             outs.append(last_fm)
+        if fork is not None:
+            cur.wait_stream(fork)
+            spatial_out.record_stream(cur)
         outs.append(self.ffm(spatial_out, last_fm))
         return outs
 
