@@ -7,34 +7,49 @@ oracle/augment_ref.py:
     :28     cgt = cv2.dilate(cgt, cv2.getStructuringElement(cv2.MORPH_RECT, (7, 7)))        (:19-21)
     :29     cgt[cgt == 255] = 1
     :38     p_cgt = random_crop_pad_to_shape(cgt, crop_pos, crop_size, 255)
-cv2 is not installed in the build image: Canny and dilate are restated from OpenCV's documented algorithm (separable
-Sobel of the given aperture with reflect-101 borders, L1 gradient magnitude, non-maximum suppression along the gradient
-direction quantised to four sectors, hysteresis between the two thresholds; rectangular dilation with zero borders).
-Parity with OpenCV's own integer implementation is UNPINNED; the restatement is pinned to the cv2 stand-in
-of this repository (torchseg_amd/shims_optional/cv2), on which the reference's UNCHANGED dataloader runs
-(tests/test_oracles_cpu.py)."""
+cv2 is not installed in the build image: Canny and dilate are restated from OpenCV's algorithm (modules/imgproc/src/
+canny.cpp of OpenCV 3.x / 4.x, the versions a 2018-19 checkout of the reference ran on; round 5 follows the advisor's
+reading of that source where round 4 followed the documentation's prose):
+  * Sobel of the given aperture into 16-bit integers with BORDER_REPLICATE; for aperture 7 the gradients are scaled by
+    1 / 16 (rounded half to even: a 7 x 7 Sobel of an 8-bit image does not fit 16 bits) and BOTH thresholds are divided by
+    16 and floored — `Canny(gt, 5, 5, apertureSize=7)` therefore thresholds at 0;
+  * L1 magnitude |dx| + |dy|; direction sectors from the fixed-point test |dy| << 15 against |dx| tan(22.5) and
+    |dx| tan(67.5) with TG22 = round(tan(22.5 deg) 2^15);
+  * non-maximum suppression: horizontal gradient `m > left && m >= right`, vertical `m > up && m >= down`, diagonal
+    STRICT on both sides, the diagonal chosen by the sign of dx * dy; magnitudes outside the image are 0;
+  * hysteresis: pixels above `high` and the pixels above `low` 8-connected to them.
+Parity with OpenCV itself stays UNPINNED (no OpenCV here to produce a single vector: SURVEY 8 row f3); the restatement is
+pinned to the cv2 stand-in of this repository (torchseg_amd/shims_optional/cv2), on which the reference's UNCHANGED
+dataloader runs (tests/test_oracles_cpu.py)."""
 import numpy as np
 
 from . import augment_ref as A
 
 
 def sobel(a, aperture):
-    """cv2.Sobel kernels: binomial smoothing x its difference, BORDER_REFLECT_101.  -> (gx, gy) float64 (exact integers)."""
-    smooth = np.array([1.0])
+    """cv2.Sobel(a, CV_16S, ..., ksize=aperture, scale, borderType=BORDER_REPLICATE) as cv2.Canny calls it: binomial
+    smoothing x its difference; scale 1 / 16 with round-half-to-even for aperture 7.  -> (dx, dy) int64."""
+    smooth = np.array([1], dtype=np.int64)
     for _ in range(aperture - 1):
-        smooth = np.convolve(smooth, [1.0, 1.0])
-    diff = np.array([1.0])
+        smooth = np.convolve(smooth, [1, 1])
+    diff = np.array([1], dtype=np.int64)
     for _ in range(aperture - 2):
-        diff = np.convolve(diff, [1.0, 1.0])
-    diff = -np.convolve(diff, [1.0, -1.0])[::-1]
+        diff = np.convolve(diff, [1, 1])
+    diff = -np.convolve(diff, [1, -1])[::-1]
     r = aperture // 2
-    p = np.pad(a.astype(np.float64), r, mode="reflect")
+    p = np.pad(a.astype(np.int64), r, mode="edge")
     H, W = a.shape
 
     def sep(ky, kx):
-        t = sum(ky[i] * p[i:i + H, :] for i in range(aperture))
-        return sum(kx[j] * t[:, j:j + W] for j in range(aperture))
-    return sep(smooth, diff), sep(diff, smooth)
+        t = sum(int(ky[i]) * p[i:i + H, :] for i in range(aperture))
+        return sum(int(kx[j]) * t[:, j:j + W] for j in range(aperture))
+    gx, gy = sep(smooth, diff), sep(diff, smooth)
+    if aperture == 7:
+        def rne16(g):                                    # cvRound(g / 16.0): round half to even
+            q, rem = g >> 4, g & 15
+            return q + ((rem > 8) | ((rem == 8) & ((q & 1) == 1)))
+        gx, gy = rne16(gx), rne16(gy)
+    return np.clip(gx, -32768, 32767), np.clip(gy, -32768, 32767)
 
 
 def dilate(a, size):
@@ -47,20 +62,33 @@ def dilate(a, size):
     return out
 
 
+TG22 = int(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
+
+
 def canny(a, t1, t2, aperture=3):
+    if aperture == 7:
+        t1, t2 = t1 / 16.0, t2 / 16.0
+    lo, hi = int(np.floor(min(t1, t2))), int(np.floor(max(t1, t2)))
     gx, gy = sobel(a, aperture)
     mag = np.abs(gx) + np.abs(gy)
-    lo, hi = min(t1, t2), max(t1, t2)
-    ang = (np.rad2deg(np.arctan2(gy, gx)) + 180.0) % 180.0
-    q = ((ang + 22.5) // 45).astype(int) % 4
+    x, y = np.abs(gx), np.abs(gy) << 15
+    tg22x = x * TG22
+    tg67x = tg22x + (x << 16)
+    horiz = y < tg22x
+    vert = (~horiz) & (y > tg67x)
+    diag = ~(horiz | vert)
+    s_neg = (gx ^ gy) < 0                                       # dx, dy of opposite sign: the other diagonal
     pm = np.pad(mag, 1, mode="constant")
     H, W = mag.shape
-    keep = np.zeros((H, W), bool)
-    for k, (dy, dx) in {0: (0, 1), 1: (1, 1), 2: (1, 0), 3: (1, -1)}.items():
-        n1 = pm[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
-        n2 = pm[1 - dy:1 - dy + H, 1 - dx:1 - dx + W]
-        keep |= (q == k) & (mag > n1) & (mag >= n2)
-    strong, weak = keep & (mag > hi), keep & (mag > lo)
+
+    def at(dy, dx):
+        return pm[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    keep = horiz & (mag > at(0, -1)) & (mag >= at(0, 1))
+    keep |= vert & (mag > at(-1, 0)) & (mag >= at(1, 0))
+    keep |= diag & ~s_neg & (mag > at(-1, -1)) & (mag > at(1, 1))
+    keep |= diag & s_neg & (mag > at(-1, 1)) & (mag > at(1, -1))
+    keep &= mag > lo
+    strong, weak = keep & (mag > hi), keep
     out = strong.copy()
     while True:
         grown = dilate(out.astype(np.uint8), 3).astype(bool) & weak

@@ -154,13 +154,14 @@ namespace tsg {
 // label image, the lines of model/dfn/cityscapes.dfn.R101_v1c/dataloader.py:24-29:
 //     no255_gt = gt with 255 -> 0;  cgt = cv2.Canny(no255_gt, 5, 5, apertureSize=7);  cgt = cv2.dilate(cgt, 7 x 7 ones);
 //     cgt[cgt == 255] = 1;  p_cgt = random_crop_pad_to_shape(cgt, crop_pos, crop_size, 255)
-// cv2 is not in this image: the arithmetic is the one of torchseg_amd/shims_optional/cv2 (OpenCV's documented Canny:
-// separable Sobel of aperture 7 with reflect-101 borders, L1 magnitude, non-maximum suppression along the gradient
-// direction quantised to 4 sectors with `mag > n1 && mag >= n2`, hysteresis — which degenerates to `mag > threshold` when
-// both thresholds are equal, the reference's only use).  Labels are small integers, so gx / gy / |gx| + |gy| are exact in
-// int32; the sector comes from comparing |gy| with |gx| tan(22.5 deg) / tan(67.5 deg) in double, which decides exactly what
-// the stand-in's arctan2 decides (the sector borders have irrational tangents: integer gradients never sit on one).
-// Parity with OpenCV's own Canny is UNPINNED, like the rest of row f3.
+// cv2 is not in this image: the arithmetic is OpenCV's integer Canny as torchseg_amd/shims_optional/cv2 and
+// oracle/edge_ref.py restate it (imgproc/src/canny.cpp of 3.x / 4.x; round 5): separable Sobel of aperture 7 with
+// REPLICATED borders, scaled by 1 / 16 and rounded half to even into 16-bit gradients; L1 magnitude; thresholds / 16,
+// floored (5 -> 0); sectors by the fixed-point test |dy| << 15 against |dx| TG22 and |dx| (TG22 + 2^16); non-maximum
+// suppression `m > left && m >= right` / `m > up && m >= down` / strict on both sides along the diagonal picked by the
+// sign of dx dy; zero magnitude outside the image; hysteresis degenerates to `m > low` when both thresholds are equal,
+// the reference's only use.  Everything is exact in int32.  Parity with OpenCV's own Canny is UNPINNED, like the rest of
+// row f3 (no OpenCV in the image to produce a vector).
 //   k1 scaled label S (nearest, mirrored, 255 -> 0)   k2 Sobel -> magnitude + sector   k3 NMS + threshold -> edge map
 //   k4 7 x 7 dilation, crop, centred padding -> aux label.   Workspace: 7 bytes per scaled pixel.
 struct EdgeGeom { int H, W, SH, SW, flip, crop_y, crop_x, top, left, ch, cw, CH, CW; double fy, fx; int thr, rad, pad_label; };
@@ -176,10 +177,11 @@ __global__ __launch_bounds__(256) void edge_scale_k(const uint8_t* __restrict__ 
   S[(int64_t)y * g.SW + x] = v == (uint8_t)ignore_label ? (uint8_t)0 : v;
 }
 
-__device__ __forceinline__ int edge_reflect(int i, int n) {          // BORDER_REFLECT_101 (numpy "reflect")
-  if (n == 1) return 0;
-  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
-  return i;
+__device__ __forceinline__ int edge_clamp(int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); }   // BORDER_REPLICATE
+
+__device__ __forceinline__ int edge_div16_half_even(int g) {         // cvRound(g / 16.0)
+  const int q = g >> 4, r = g & 15;
+  return q + ((r > 8 || (r == 8 && (q & 1))) ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void edge_sobel_k(const uint8_t* __restrict__ S, int32_t* __restrict__ mag,
@@ -189,23 +191,26 @@ __global__ __launch_bounds__(256) void edge_sobel_k(const uint8_t* __restrict__ 
   const int sm[7] = {1, 6, 15, 20, 15, 6, 1}, df[7] = {1, 4, 5, 0, -5, -4, -1};
   int cx[7];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) cx[j] = edge_reflect(x + j - 3, g.SW);
+  for (int j = 0; j < 7; ++j) cx[j] = edge_clamp(x + j - 3, g.SW);
   int gx = 0, gy = 0;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const uint8_t* row = S + (int64_t)edge_reflect(y + i - 3, g.SH) * g.SW;
+    const uint8_t* row = S + (int64_t)edge_clamp(y + i - 3, g.SH) * g.SW;
     int rs = 0, rd = 0;                                              // row filtered with the smoothing / the difference taps
 #pragma unroll
     for (int j = 0; j < 7; ++j) { const int v = row[cx[j]]; rs += sm[j] * v; rd += df[j] * v; }
     gx += sm[i] * rd;                                                // sep(ky = smooth, kx = diff)
     gy += df[i] * rs;                                                // sep(ky = diff, kx = smooth)
   }
+  gx = edge_div16_half_even(gx);                                     // the 16-bit gradients of aperture 7
+  gy = edge_div16_half_even(gy);
   const int a = gx < 0 ? -gx : gx, b = gy < 0 ? -gy : gy;
+  const int TG22 = 13573;                                            // (int)(tan(22.5 deg) * 2^15 + 0.5)
+  const int64_t yb = (int64_t)b << 15, tg22x = (int64_t)a * TG22, tg67x = tg22x + ((int64_t)a << 16);
   int q;
-  const double t1 = 0.41421356237309503, t2 = 2.414213562373095;    // tan(22.5 deg), tan(67.5 deg)
-  if ((double)b < t1 * (double)a || (a == 0 && b == 0)) q = 0;
-  else if ((double)b > t2 * (double)a) q = 2;
-  else q = ((gx < 0) == (gy < 0)) ? 1 : 3;
+  if (yb < tg22x) q = 0;
+  else if (yb > tg67x) q = 2;
+  else q = ((gx ^ gy) < 0) ? 3 : 1;
   mag[(int64_t)y * g.SW + x] = a + b;
   sec[(int64_t)y * g.SW + x] = (uint8_t)q;
 }
@@ -216,10 +221,15 @@ __global__ __launch_bounds__(256) void edge_nms_k(const int32_t* __restrict__ ma
   if (x >= g.SW) return;
   const int64_t i = (int64_t)y * g.SW + x;
   const int m = mag[i], q = sec[i];
-  const int dy = q == 0 ? 0 : 1, dx = q == 0 ? 1 : (q == 1 ? 1 : (q == 2 ? 0 : -1));
   auto at = [&](int yy, int xx) { return (yy < 0 || yy >= g.SH || xx < 0 || xx >= g.SW) ? 0 : mag[(int64_t)yy * g.SW + xx]; };
-  const int n1 = at(y + dy, x + dx), n2 = at(y - dy, x - dx);
-  E[i] = (m > n1 && m >= n2 && m > g.thr) ? 1 : 0;
+  bool keep;
+  if (q == 0) keep = m > at(y, x - 1) && m >= at(y, x + 1);          // previous neighbour strict, next one >=
+  else if (q == 2) keep = m > at(y - 1, x) && m >= at(y + 1, x);
+  else {
+    const int s = q == 3 ? -1 : 1;                                   // dx, dy of opposite sign: the other diagonal
+    keep = m > at(y - 1, x - s) && m > at(y + 1, x + s);             // strict on both sides
+  }
+  E[i] = (keep && m > g.thr) ? 1 : 0;
 }
 
 template <typename LT>
@@ -271,7 +281,8 @@ int tsg_edge_labels(const void* gt, const int32_t* geom, const double* inv_scale
   const double isx = inv_scale ? inv_scale[1] : (double)g.SW / (double)g.W;
   if (!(isy > 0.0) || !(isx > 0.0)) return TSG_E_SHAPE;
   g.fy = 1.0 / isy; g.fx = 1.0 / isx;
-  g.thr = threshold1; g.rad = dilate_size; g.pad_label = pad_label;
+  g.thr = threshold1 >> 4;                                           // aperture 7: floor(threshold / 16) against the scaled gradients
+  g.rad = dilate_size; g.pad_label = pad_label;
   const size_t n = (size_t)g.SH * g.SW, na = (n + 15) / 16 * 16;
   uint8_t* S = (uint8_t*)ws;
   uint8_t* sec = S + na;

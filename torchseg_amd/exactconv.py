@@ -87,22 +87,64 @@ class ExactConvMode(TorchFunctionMode):
 
 
 def _exact_conv_forward(self, input, weight, bias):
-    """Instance-level replacement of nn.Conv2d._conv_forward (what every Conv2d subclass of this package ends in)."""
+    """nn.Conv2d._conv_forward of the re-classed modules (what every Conv2d subclass of this package ends in)."""
     if (ENABLED and self.padding_mode == "zeros" and not torch.is_autocast_enabled()
             and supported(input, weight, self.padding, self.groups)):
         return conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups)
     return torch.nn.Conv2d._conv_forward(self, input, weight, bias)
 
 
+# One subclass per convolution class met: `Exact__<module path>__<class name>`, living in this module's namespace so that
+# pickling a whole model (torch.save(model), multiprocessing) finds it again — round 4 stored a bound method in every
+# instance's __dict__, which pickle reduces to an attribute lookup that does not exist at load time (ADVICE r4).  The
+# module-level __getattr__ below rebuilds a class from its name when an unpickler asks for it in a fresh process.
+_PREFIX = "Exact__"
+_classes = {}
+
+
+def _exact_class(base):
+    cls = _classes.get(base)
+    if cls is None:
+        name = _PREFIX + base.__module__.replace(".", "_DOT_") + "__" + base.__qualname__
+        cls = type(name, (base,), {"_conv_forward": _exact_conv_forward, "_tsg_exact_base": base, "__module__": __name__})
+        _classes[base] = cls
+        globals()[name] = cls
+    return cls
+
+
+def __getattr__(name):
+    if name.startswith(_PREFIX) and "__" in name[len(_PREFIX):]:
+        import importlib
+        mod, _, qual = name[len(_PREFIX):].rpartition("__")
+        base = importlib.import_module(mod.replace("_DOT_", "."))
+        for part in qual.split("."):
+            base = getattr(base, part)
+        return _exact_class(base)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+
+
 def install(module):
     """Route the convolutions of `module` through the exact kernels whenever they are called on fp32 HIP tensors outside
     autocast (the DDP wrapper does this for compute_dtype = fp32).  Works whichever way the model is entered — forward,
-    `.logits()`, a sub-module call — because the hook sits on the Conv2d instances; parameters, state-dict keys and
-    classes are untouched.  Returns the number of convolutions found."""
-    import types
+    `.logits()`, a sub-module call — because the override sits on the Conv2d modules' class; parameters and state-dict
+    keys are untouched, and `isinstance` checks against the original classes still hold (the new class derives from the
+    old one).  `uninstall` restores the classes (e.g. before a fast fp32 evaluation outside the wrapper).  Returns the
+    number of convolutions found."""
     n = 0
     for m in module.modules():
         if isinstance(m, torch.nn.Conv2d):
-            m._conv_forward = types.MethodType(_exact_conv_forward, m)
+            if not hasattr(type(m), "_tsg_exact_base"):
+                m.__class__ = _exact_class(type(m))
+            n += 1
+    return n
+
+
+def uninstall(module):
+    """Undo install()."""
+    n = 0
+    for m in module.modules():
+        base = getattr(type(m), "_tsg_exact_base", None)
+        if base is not None:
+            m.__class__ = base
             n += 1
     return n

@@ -112,42 +112,66 @@ def dilate(src, kernel):
     return out
 
 
-def _sobel(a, aperture):
-    """Separable Sobel of the given aperture (binomial smoothing x its difference), like cv2.Sobel's kernels."""
-    smooth = np.array([1.0])
+def _sobel16(a, aperture):
+    """The two cv2.Sobel calls of cv2.Canny (imgproc/src/canny.cpp): 16-bit results, BORDER_REPLICATE; for aperture 7 scaled
+    by 1 / 16 and rounded half to even (the unscaled 7 x 7 response of an 8-bit image overflows 16 bits)."""
+    smooth = np.array([1], dtype=np.int64)
     for _ in range(aperture - 1):
-        smooth = np.convolve(smooth, [1.0, 1.0])
-    diff = np.array([1.0])
+        smooth = np.convolve(smooth, [1, 1])
+    diff = np.array([1], dtype=np.int64)
     for _ in range(aperture - 2):
-        diff = np.convolve(diff, [1.0, 1.0])
-    diff = np.convolve(diff, [1.0, -1.0])[::-1] * -1.0 if aperture > 1 else diff
+        diff = np.convolve(diff, [1, 1])
+    diff = np.convolve(diff, [1, -1])[::-1] * -1 if aperture > 1 else diff
     r = aperture // 2
-    p = np.pad(a.astype(np.float64), r, mode="reflect")
+    p = np.pad(a.astype(np.int64), r, mode="edge")
+    H, W = a.shape[0], a.shape[1]
 
     def sep(ky, kx):
-        t = sum(ky[i] * p[i:i + a.shape[0] + 2 * r - (aperture - 1) + 0, :] for i in range(aperture))
-        return sum(kx[j] * t[:, j:j + a.shape[1]] for j in range(aperture))
-    return sep(smooth, diff), sep(diff, smooth)
+        t = sum(int(ky[i]) * p[i:i + H, :] for i in range(aperture))
+        return sum(int(kx[j]) * t[:, j:j + W] for j in range(aperture))
+    gx, gy = sep(smooth, diff), sep(diff, smooth)
+    if aperture == 7:
+        def half_even(g):
+            q, rem = g >> 4, g & 15
+            return q + ((rem > 8) | ((rem == 8) & ((q & 1) == 1)))
+        gx, gy = half_even(gx), half_even(gy)
+    return np.clip(gx, -32768, 32767), np.clip(gy, -32768, 32767)
+
+
+_TG22 = int(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
 
 
 def Canny(image, threshold1, threshold2, apertureSize=3, L2gradient=False):
+    """OpenCV's integer Canny (L1 gradient): see _sobel16; thresholds of aperture 7 divided by 16, both floored; sectors by
+    the fixed-point tangent test; non-maximum suppression strict against the left / upper neighbour and >= against the
+    right / lower one, strict on both sides along the diagonals; zero magnitude outside the image; 8-connected hysteresis."""
+    if L2gradient:
+        raise NotImplementedError("the stand-in restates the L1-gradient path (what the reference calls)")
     a = np.asarray(image)
-    gx, gy = _sobel(a, apertureSize)
-    mag = np.hypot(gx, gy) if L2gradient else np.abs(gx) + np.abs(gy)
-    lo, hi = min(threshold1, threshold2), max(threshold1, threshold2)
-    ang = (np.rad2deg(np.arctan2(gy, gx)) + 180.0) % 180.0
-    q = ((ang + 22.5) // 45).astype(int) % 4
+    if apertureSize == 7:
+        threshold1, threshold2 = threshold1 / 16.0, threshold2 / 16.0
+    lo = int(np.floor(min(threshold1, threshold2)))
+    hi = int(np.floor(max(threshold1, threshold2)))
+    gx, gy = _sobel16(a, apertureSize)
+    mag = np.abs(gx) + np.abs(gy)
+    x, y = np.abs(gx), np.abs(gy) << 15
+    tg22x = x * _TG22
+    tg67x = tg22x + (x << 16)
+    horiz = y < tg22x
+    vert = ~horiz & (y > tg67x)
+    diag = ~(horiz | vert)
+    opposite = (gx ^ gy) < 0
     pm = np.pad(mag, 1, mode="constant")
     H, W = mag.shape
-    offs = {0: (0, 1), 1: (1, 1), 2: (1, 0), 3: (1, -1)}
-    keep = np.zeros_like(mag, dtype=bool)
-    for k, (dy, dx) in offs.items():
-        n1 = pm[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
-        n2 = pm[1 - dy:1 - dy + H, 1 - dx:1 - dx + W]
-        keep |= (q == k) & (mag > n1) & (mag >= n2)
-    strong = keep & (mag > hi)
+
+    def nb(dy, dx):
+        return pm[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    keep = horiz & (mag > nb(0, -1)) & (mag >= nb(0, 1))
+    keep |= vert & (mag > nb(-1, 0)) & (mag >= nb(1, 0))
+    keep |= diag & ~opposite & (mag > nb(-1, -1)) & (mag > nb(1, 1))
+    keep |= diag & opposite & (mag > nb(-1, 1)) & (mag > nb(1, -1))
     weak = keep & (mag > lo)
-    out = strong.copy()
+    out = weak & (mag > hi)
     while True:                                   # hysteresis: grow strong edges through connected weak ones
         grown = dilate(out.astype(np.uint8), np.ones((3, 3), np.uint8)).astype(bool) & weak
         if (grown == out).all():

@@ -52,12 +52,36 @@ def _eligible(m):
             and m.padding_mode == "zeros" and m.in_channels % 16 == 0 and m.out_channels % 16 == 0)
 
 
+def _is_global_pool(m):
+    if isinstance(m, nn.AdaptiveAvgPool2d):
+        o = m.output_size
+        return o == 1 or o == (1, 1)
+    return type(m).__name__ in ("GlobalAvgPool", "GlobalAvgPool2d")
+
+
 def install_pooled_conv(module):
-    """Re-class the bias-free 1x1 convolutions in place (the kernel is chosen per call, by the input's shape); returns how
-    many were found."""
+    """Re-class, in place, the bias-free 1x1 convolutions that FOLLOW A GLOBAL POOL inside an nn.Sequential (`nn.Sequential(
+    AdaptiveAvgPool2d(1) | GlobalAvgPool, ConvBnRelu(.., 1, 1, 0), ...)`: seg_oprs.py:199-205, :222-231, bisenet
+    network.py:34-39) — the only places their input is a [B, C, 1, 1] map.  Round 4 re-classed EVERY bias-free 1x1
+    convolution (Bottleneck conv1 / conv3, shortcuts): they fell through to the stock forward, but each call paid the
+    extra checks, and the class swap hid them from later `type(m) is nn.Conv2d` installers.  Returns how many
+    were re-classed."""
     n = 0
-    for m in module.modules():
-        if _eligible(m):
-            m.__class__ = PooledConv2d
-            n += 1
+    for seq in module.modules():
+        if not isinstance(seq, nn.Sequential):
+            continue
+        pooled = False
+        for child in seq.children():
+            if _is_global_pool(child):
+                pooled = True
+                continue
+            if not pooled:
+                continue
+            convs = [child] if isinstance(child, nn.Conv2d) else [c for c in child.children() if isinstance(c, nn.Conv2d)]
+            for m in convs:
+                if _eligible(m):
+                    m.__class__ = PooledConv2d
+                    n += 1
+            if isinstance(child, (nn.Conv2d,)) and child.kernel_size != (1, 1):
+                pooled = False                         # a spatial operator: what follows is no pooled vector any more
     return n
