@@ -202,17 +202,23 @@ def test_every_python_source_compiles():
 
 
 def test_pooled_conv_swap_and_kernel_choice_of_the_general_3x3():
-    """CPU: install_pooled_conv re-classes only bias-free 1x1 / stride-1 convolutions with channel counts the kernel takes and
-    passes CPU tensors to the stock forward; the host-side geometry queries of the library (no kernel launch) pick the
-    16-row LDS-DMA kernel exactly for the problems that fill 2 x 256 block slots, keep the statistics partial's row count
-    independent of that choice, and refuse what the kernels cannot index."""
+    """CPU: install_pooled_conv re-classes only bias-free 1x1 / stride-1 convolutions with channel counts the kernel takes
+    THAT FOLLOW A GLOBAL POOL inside an nn.Sequential (round 5, ADVICE r4: the same convolutions elsewhere — Bottleneck
+    conv1 / conv3, shortcuts — keep their class) and passes CPU tensors to the stock forward; the host-side geometry queries
+    of the library (no kernel launch) pick the 16-row LDS-DMA kernel exactly for the problems that fill 2 x 256 block slots,
+    keep the statistics partial's row count independent of that choice, and refuse what the kernels cannot index."""
     from torchseg_amd.vecconv import PooledConv2d, install_pooled_conv
     from torchseg_amd import _lib as L
-    net = nn.Sequential(nn.Conv2d(128, 64, 1, bias=False), nn.Conv2d(64, 19, 1, bias=False), nn.Conv2d(64, 64, 1, bias=True),
-                        nn.Conv2d(64, 64, 1, stride=2, bias=False), nn.Conv2d(64, 64, 3, padding=1, bias=False))
+    plain = nn.Sequential(nn.Conv2d(128, 64, 1, bias=False), nn.Conv2d(64, 64, 1, bias=False))
+    assert install_pooled_conv(plain) == 0 and [type(m) for m in plain] == [nn.Conv2d] * 2        # no pool in front: untouched
+    net = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(128, 64, 1, bias=False), nn.Conv2d(64, 19, 1, bias=False),
+                        nn.Conv2d(64, 64, 1, bias=True), nn.Conv2d(64, 64, 1, stride=2, bias=False),
+                        nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.Conv2d(64, 64, 1, bias=False))
     keys = list(net.state_dict().keys())
-    assert install_pooled_conv(net) == 1 and isinstance(net[0], PooledConv2d)
-    assert [type(m) for m in list(net)[1:]] == [nn.Conv2d] * 4 and list(net.state_dict().keys()) == keys
+    assert install_pooled_conv(net) == 1 and isinstance(net[1], PooledConv2d)
+    assert [type(m) for m in list(net)[2:]] == [nn.Conv2d] * 5 and list(net.state_dict().keys()) == keys   # the last 1x1 sits
+    #                                                                          behind a 3x3: no pooled vector any more
+    net = nn.Sequential(*list(net)[1:])
     x = torch.randn(2, 128, 1, 1)
     assert torch.equal(net[0](x), nn.functional.conv2d(x, net[0].weight))
     lib = L.lib()
