@@ -13,7 +13,7 @@ HEAD=$(cat .git_head 2>/dev/null || echo unknown)
 bash tools/prof_bench.sh > $O/prof_bench.out 2>&1; cp gpurun_out/prof/kernel_stats_compact.csv $O/kernel_stats.csv; grep "kernels total" $O/prof_bench.out
 bash tools/pmc_traffic.sh > $O/pmc_traffic.out 2>&1; cp gpurun_out/pmc/summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc/traffic_by_kernel.json $O/traffic_by_kernel.json
 out=$PWD/gpurun_out/pmc_busy; rm -rf $out; mkdir -p $out
-(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-ohem-probe --no-psa-probe --i64-steps 0 > $out.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-ohem-probe --no-psa-probe --i64-steps 0 --ref-steps 0 --fp32-steps 0 > $out.log 2>&1)
 python tools/pmc_mfma_busy.py $out $O/mfma_busy.json
 find $out -name "*.csv" -size +8M -delete
 python tools/make_traffic_json.py $O/traffic_by_kernel.json $O/traffic.json "$TAG@$HEAD" $O/mfma_busy.json > /dev/null
@@ -21,6 +21,7 @@ if [ -n "$FAM" ]; then
 for c in pspnet dfn psanet; do
   ( time timeout 900 python bench.py --config $c --steps 20 --warmup 10 ) > $O/bench_$c.log 2>&1
   grep "^{" $O/bench_$c.log | tail -n 1 > $O/bench_$c.json; grep -o '"value": [0-9.]*' $O/bench_$c.log | head -2
+  bash tools/prof_bench.sh $c > $O/prof_bench_$c.out 2>&1; cp gpurun_out/prof_$c/kernel_stats_compact.csv $O/kernel_stats_$c.csv
 done
 fi
 ls -la $O
