@@ -51,6 +51,57 @@ _C64_STATS = _os.environ.get("TSG_CONV_C64_STATS", "1") != "0"
 _SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "1") != "0"
 
 
+# TSG_WRW_STREAM=1|0: the 3x3 weight gradients on a side HIP stream (round 5).  A layer's weight gradient is needed by
+# nobody until the optimizer step, while everything else in the backward pass waits for the DATA gradient; issued on the
+# compute stream it sits in the dependent chain all the same.  On a side stream its matrix-core work (25 launches, 2.7 ms
+# of the step, MFMA pipe busy 0.41) runs beside the HBM-bound SyncBatchNorm backward passes of the layers in front of it
+# (2.3 ms that leave the matrix pipes idle).  The operands are kept alive for the side stream (record_stream), the result
+# belongs to the compute stream, and the end of the backward pass (an autograd engine callback) makes the compute stream
+# wait for the side stream, so the optimizer, the DDP buckets' gather and anything after .backward() see finished gradients.
+_WRW_STREAM = _os.environ.get("TSG_WRW_STREAM", "1") != "0"
+_wrw_side = {}
+_wrw_join_queued = [False]
+
+
+def _wrw_join():
+    _wrw_join_queued[0] = False
+    for dev, side in _wrw_side.items():
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+
+def join_wrw_stream():
+    """Make the current stream wait for weight gradients still running on the side stream (the engine callback does this
+    at the end of every backward pass; the DDP reducer calls it before it gathers a bucket early)."""
+    if _wrw_side:
+        _wrw_join()
+
+
+def wrw_on_side_stream(fn, *operands):
+    """`fn()` (launches a weight-gradient kernel, returns its result tensor) on the side stream of the operands' device."""
+    if not _WRW_STREAM or not operands[0].is_cuda or torch.cuda.is_current_stream_capturing():
+        return fn()
+    dev = operands[0].device
+    cur = torch.cuda.current_stream(dev)
+    side = _wrw_side.get(dev)
+    if side is None:
+        side = _wrw_side[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)                              # the operands (dy above all) are complete
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in operands:
+        if t is not None:
+            t.record_stream(side)                      # their memory must not be handed out again under the running kernel
+    out.record_stream(cur)
+    if not _wrw_join_queued[0]:
+        _wrw_join_queued[0] = True
+        from torch.autograd import Variable
+        try:
+            Variable._execution_engine.queue_callback(_wrw_join)
+        except RuntimeError:                           # not inside a backward pass (a test calling the function directly)
+            _wrw_join()
+    return out
+
+
 def _skip_addend(dskip, like_shape):
     """The gradient of a skip connection as an epilogue addend of the data-gradient kernel (bf16, channels_last,
     the shape of dx), or None when it cannot be one."""
@@ -131,7 +182,7 @@ class _ConvWrwFn(torch.autograd.Function):
                                                          [True, False, False])[0]
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
-        dw = K.provider().conv3x3_wrw(x, dy, stride=ctx.stride)
+        dw = wrw_on_side_stream(lambda: K.provider().conv3x3_wrw(x, dy, stride=ctx.stride), x, dy)
         return dx, dw.to(ctx.wdtype), None, None, None, None, None
 
 
@@ -191,7 +242,7 @@ class _ConvGenFn(torch.autograd.Function):
                 dx = F.conv2d(dy, kp.conv3x3_weight_rot180_t(weight.detach().to(torch.bfloat16)), None, 1, 1)
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
-        dw = kp.conv3x3_wrw(x, dy, stride=1)
+        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=1), x, dy)
         return dx, dw.to(weight.dtype), None, None
 
 
@@ -318,7 +369,7 @@ class _BnReluConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp)
+        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp), x, dy, fp)
         if gen:                                                  # wb is the fp32 master weight here
             da = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(wb, 1, dy), wb.shape[1])
         else:
@@ -381,7 +432,7 @@ class _StemBnReluConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp)
+        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp), xc, dy, fp)
         rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
         da = kp.conv3x3_c64_s2_dgrad(dy, rot, (xc.shape[2], xc.shape[3])) if stride == 2 else kp.conv3x3_c64_fwd(dy, rot)
         partial, Sn = kp.bn_bwd_reduce(da, xc, None, layout, N, C, HW, fp, True)

@@ -241,6 +241,173 @@ __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restric
 }
 
 // =====================================================================================================================
+// Round 5: the same kernel with the patch staged by LDS-DMA and double-buffered (the launches WITHOUT normalise-on-load:
+// six of the step's eight).  conv64_fwd_k<., 2, false> runs load -> wait -> LDS write -> barrier -> 72 MFMAs -> epilogue
+// per tile with nothing of its own in flight during the MFMAs (the 28 prefetch registers do not fit twice per CU): the
+// matrix pipe was busy 0.33 of the time, and the second block of the CU only half covers a tile's 1-2 us of load latency
+// with its own 1 us of MFMAs.  Here the NEXT tile's patch is requested by buffer_load_dwordx4 ... lds into the other of
+// two patch buffers right after the barrier that opens a tile — no staging registers, no ds_write, no VALU — and lands
+// while the MFMAs and the epilogue of the current tile run.
+//   * DMA writes 1 KB per wave instruction, lane L at byte 16 L: pixels are 128 B apart (no padding possible).  Unpadded,
+//     the 16 lanes of a ds_read_b128 phase would all hit the same four banks; so the eight 16-byte parts of a pixel are
+//     stored XOR-swizzled by the pixel's patch COLUMN: part j of column c sits at slot j ^ ((c >> 1) & 7).  Sixteen
+//     consecutive columns then cover every slot twice, once on an even and once on an odd pixel, i.e. on the two 128-byte
+//     halves of the bank period: conflict-free.  The swizzle costs the DMA nothing (each lane picks WHICH global 16 bytes it
+//     fetches) and the reader one v_xad_u32 per fragment;
+//   * padding pixels = buffer offsets beyond num_records (the load returns zeros), as in conv3h_fwd_k;
+//   * LDS: 2 x 26 KB patch buffers + the 18 KB output staging tile = 70 KB: two blocks per CU.
+constexpr int C6D_PIECES = 26;                           // 204 pixels x 8 parts = 1632 vectors = 25.5 wave pieces of 64
+constexpr int C6D_PBYTES = C6D_PIECES * 1024;
+constexpr int C6D_OUTS = 2 * C6D_PBYTES;
+constexpr size_t C6D_LDS = (size_t)C6D_OUTS + (size_t)C6_TH * C6_TW * C6_PS * 2;     // 71,680 B
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void conv64_dma_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, C6Geom g, float* __restrict__ partial,
+                                                          const bf16_t* __restrict__ addend) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c6d_smem[];
+  bf16_t* outs = reinterpret_cast<bf16_t*>(c6d_smem + C6D_OUTS);
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wr = wave >> 1;
+
+  c6_bf16x8 fw[9][4];                                    // filter fragments: oc = 32 wm + p, ci = 16 kc + 8 half ..
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      fw[t][kc] = *reinterpret_cast<const c6_bf16x8*>(w + ((wm * 32 + p) * 9 + t) * C6_C + kc * 16 + half * 8);
+  const int spl = tid >> 3, spart = tid & 7;             // store: tile column spl, 16-B part spart
+
+  // DMA: piece q = wave + 4 u; this lane's vector v = 64 q + lane = slot (v & 7) of patch pixel v >> 3.  Everything about
+  // a vector is recomputed per tile from v (a dozen VALU instructions per piece against ~2300 cycles of MFMAs): seven
+  // pieces' worth of per-lane constants were the registers that spilled, and a scratch reload in front of a DMA is an
+  // s_waitcnt vmcnt(0), i.e. a wait for the PREVIOUS piece's DMA
+  auto dma = [&](const C6Tile& t, int buf) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (int64_t)t.b * g.H * g.W * C6_C), 0, g.H * g.W * C6_C * 2, 0x00020000);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                         // opaque per call: keeps the compiler from hoisting the per-lane
+    //                                                      geometry out of the tile loop (= 20 more live registers = spills)
+#pragma unroll
+    for (int u = 0; u < 7; ++u)
+      if (wave + 4 * u < C6D_PIECES) {                   // wave-uniform
+        const int v = (wave + 4 * u) * 64 + ln, px = v >> 3;
+        const int pr = px / C6_PW, pc = px - pr * C6_PW;
+        const int ih = t.oh0 - 1 + pr, iw = t.ow0 - 1 + pc;
+        const bool ok = v < C6_NV && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+        const int voff = ok ? (ih * g.W + iw) * (C6_C * 2) + (((v & 7) ^ ((pc >> 1) & 7)) << 4) : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(c6d_smem + buf * C6D_PBYTES + (wave + 4 * u) * 1024), 16, voff,
+                                                 0, 0, 0);
+      }
+  };
+  // B fragment of step s: patch pixel (2 wr + i + kh, p + kw), 16-byte part 2 kc + half, at slot part ^ swizzle(column)
+  int swz16[3], pcol[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    swz16[kw] = (((p + kw) >> 1) & 7) << 4;
+    pcol[kw] = ((2 * wr) * C6_PW + p + kw) * 128;
+  }
+
+  float st1 = 0.f, st2 = 0.f;                            // STATS: channel tid & 63 over tile row tid >> 6
+  int tile = blockIdx.x, buf = 0;
+  C6Tile tp = c6_tile(g, tile < g.ntiles ? tile : 0);
+  if (tile < g.ntiles) dma(tp, 0);
+  for (; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the tile's patch have landed ...
+    __syncthreads();                                     // ... and everybody's; the previous tile is done with outs and buf ^ 1
+    C6Tile tn = tp;
+    if (tile + (int)gridDim.x < g.ntiles) {              // in flight during the MFMAs and the epilogue below
+      tn = c6_tile(g, tile + gridDim.x);
+      dma(tn, buf ^ 1);
+    }
+
+    c6_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned char* pbuf = c6d_smem + buf * C6D_PBYTES;
+    auto frag = [&](int s) {
+      const int t = s >> 3, kc = (s >> 1) & 3, i = s & 1, kh = t / 3, kw = t % 3;
+      const int off = (swz16[kw] ^ (((kc * 2) << 4) | (half << 4))) + pcol[kw];
+      return *reinterpret_cast<const c6_bf16x8*>(pbuf + off + (i + kh) * (C6_PW * 128));
+    };
+    constexpr int AHEAD = 4;
+    c6_bf16x8 ring[AHEAD];
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) ring[s] = frag(s);
+#pragma unroll
+    for (int s = 0; s < 72; ++s) {
+      const c6_bf16x8 fb = ring[s % AHEAD];
+      if (s + AHEAD < 72) ring[s % AHEAD] = frag(s + AHEAD);
+      acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s >> 3][(s >> 1) & 3], fb, acc[s & 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // acc[i][r]: oc = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, pixel = (row 2 wr + i, column p).  Re-lay as [pixel][oc].
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int oc0 = 32 * wm + 8 * gq + 4 * half;
+        uint2 v;
+        v.x = pack2_bf16(acc[i][4 * gq + 0], acc[i][4 * gq + 1]);
+        v.y = pack2_bf16(acc[i][4 * gq + 2], acc[i][4 * gq + 3]);
+        *reinterpret_cast<uint2*>(outs + ((2 * wr + i) * C6_TW + p) * C6_PS + oc0) = v;
+      }
+    const int64_t tile_off = (((int64_t)tp.b * g.H + tp.oh0) * g.W + tp.ow0) * C6_C;
+    bf16_t* yt = y + tile_off;
+    const bool colok = tp.ow0 + spl < g.W;
+    uint4 ad[C6_TH];
+    __builtin_amdgcn_sched_barrier(0);
+    if (addend) {
+#pragma unroll
+      for (int qd = 0; qd < C6_TH; ++qd) {
+        ad[qd] = make_uint4(0u, 0u, 0u, 0u);
+        if (tp.oh0 + qd < g.H && colok)
+          ad[qd] = *reinterpret_cast<const uint4*>(addend + tile_off + ((int64_t)qd * g.W + spl) * C6_C + spart * 8);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qd = 0; qd < C6_TH; ++qd)
+      if (tp.oh0 + qd < g.H && colok) {
+        uint4 o = *reinterpret_cast<const uint4*>(outs + (qd * C6_TW + spl) * C6_PS + spart * 8);
+        const int64_t off = ((int64_t)qd * g.W + spl) * C6_C + spart * 8;
+        if (addend) o = c6_add_bf16x8(o, ad[qd]);
+        *reinterpret_cast<uint4*>(yt + off) = o;
+      }
+    if (STATS) {
+      const int c = tid & 63, qd = tid >> 6;
+      if (tp.oh0 + qd < g.H) {
+        const int npx = g.W - tp.ow0 < C6_TW ? g.W - tp.ow0 : C6_TW;
+        const bf16_t* col = outs + qd * C6_TW * C6_PS + c;
+        if (npx == C6_TW) {
+#pragma unroll 8
+          for (int px = 0; px < C6_TW; ++px) { const float v = bf16_to_f32(col[px * C6_PS]); st1 += v; st2 = fmaf(v, v, st2); }
+        } else {
+          for (int px = 0; px < npx; ++px) { const float v = bf16_to_f32(col[px * C6_PS]); st1 += v; st2 = fmaf(v, v, st2); }
+        }
+      }
+    }
+    tp = tn;
+  }
+  if (STATS) {                                           // fold the four tile rows in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(outs);
+    red[tid] = st1; red[256 + tid] = st2;
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;
+      const float* r = red + which * 256 + c;
+      partial[((int64_t)blockIdx.x * 2 + which) * C6_C + c] = (r[0] + r[64]) + (r[128] + r[192]);
+    }
+  }
+}
+
+// =====================================================================================================================
 // Stride 2 (BiSeNet's SpatialPath.conv_3x3_1 / conv_3x3_2, network.py:117-118: 64 -> 64, 3x3 / 2 / 1, on the 512^2 and
 // 256^2 maps).  Both directions move 5 bytes of activation per 2 flops/byte of MFMA work: memory-bound, so the aim is
 // to stream the big tensor exactly once at the HBM rate, which the vendor kernels miss by 1.7x (forward) and 3x (data
@@ -574,6 +741,24 @@ int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, c
   const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
 #define C6_GO(ST, OC, AF) hipLaunchKernelGGL((conv64_fwd_k<ST, OC, AF>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, \
                                              (const bf16_t*)w, (bf16_t*)y, g, partial, in_ab, (const bf16_t*)addend)
+  // TSG_CONV64_DMA=1|0 (default 1): the launches without normalise-on-load on conv64_dma_fwd_k (patch by LDS-DMA, double
+  // buffered); needs two blocks per CU (occ 2) and 32-bit byte offsets into one image
+  static const bool use_dma = [] { const char* e = getenv("TSG_CONV64_DMA"); return !(e && e[0] == '0'); }();
+  if (!in_ab && use_dma && occ == 2 && (int64_t)g.H * g.W * C6_C * 2 < 0x7fffffffLL) {
+    if (partial) {
+      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C6D_LDS));
+      hipLaunchKernelGGL((conv64_dma_fwd_k<true>), dim3(grid), dim3(256), C6D_LDS, st, (const bf16_t*)x, (const bf16_t*)w,
+                         (bf16_t*)y, g, partial, (const bf16_t*)addend);
+    } else {
+      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C6D_LDS));
+      hipLaunchKernelGGL((conv64_dma_fwd_k<false>), dim3(grid), dim3(256), C6D_LDS, st, (const bf16_t*)x, (const bf16_t*)w,
+                         (bf16_t*)y, g, partial, (const bf16_t*)addend);
+    }
+    TSG_CHECK_LAUNCH();
+    return 0;
+  }
   if (in_ab) { if (partial) C6_GO(true, 2, true); else C6_GO(false, 2, true); }
   else if (partial) { if (occ == 1) C6_GO(true, 1, false); else C6_GO(true, 2, false); }
   else { if (occ == 1) C6_GO(false, 1, false); else C6_GO(false, 2, false); }

@@ -64,6 +64,8 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_CAT=1|0           (default 1 on GPU: FeatureFusion's torch.cat([x1, x2], 1) on tsg_cat2_rows; pool.py)
   TSG_VEC_CONV=1|0      (default 1 on GPU: bias-free 1x1 convolutions applied to pooled [B, C, 1, 1] maps (channel attention,
                         global context) on tsg_conv1x1_vec_*: one launch forward, one backward, fp32 master weight; vecconv.py)
+  TSG_WRW_STREAM=1|0    (default 1 on GPU: the 3x3 weight gradients run on a side HIP stream beside the SyncBatchNorm backward
+                        passes of the layers in front of them and are joined at the end of the backward pass; convwrw.py)
   TSG_FP32_EXACT=1|0    (default 1: with TSG_DTYPE=fp32 every convolution runs on tsg_conv2d_f32_exact_* — exact products,
                         fp64 accumulation — instead of the vendor library's fp32 kernels: the parity mode, exactconv.py)
 """
@@ -273,6 +275,8 @@ class Reducer(object):
             work.wait()                                             # torch.distributed Work: fence on HIP, blocking on gloo
 
     def _launch(self, bucket):
+        from .convwrw import join_wrw_stream
+        join_wrw_stream()                                # weight gradients issued on the side stream (convwrw.py) are complete
         # averaging = pre-division by the world size inside the gather copy; apex's gradient_predivide_factor only
         # chooses where the same division happens (overflow control for fp16 buckets), irrelevant for fp32 buckets
         self._gather(bucket, 1.0 / self.world if self.average else 1.0)
