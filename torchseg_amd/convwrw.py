@@ -438,7 +438,8 @@ class _StemBnReluConvFn(torch.autograd.Function):
         partial, Sn = kp.bn_bwd_reduce(da, xc, None, layout, N, C, HW, fp, True)
         dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
                                              world, xc.device)
-        dw_stem = kp.stem_conv_wrw_bn(img, da, xc, bp)           # the BN backward apply happens in its staging
+        dw_stem = wrw_on_side_stream(lambda: kp.stem_conv_wrw_bn(img, da, xc, bp), img, da, xc, bp)   # the BN backward apply
+        #                                                                                     happens in its staging
         if gamma is None:
             dgamma = dbeta = None
         else:

@@ -58,7 +58,9 @@ class _StemConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        return None, K.provider().stem_conv_wrw(x, dy).to(ctx.wdtype), None
+        from .convwrw import wrw_on_side_stream           # nothing but the optimizer waits for a stem's weight gradient
+        dw = wrw_on_side_stream(lambda: K.provider().stem_conv_wrw(x, dy), x, dy)
+        return None, dw.to(ctx.wdtype), None
 
 
 import os as _os
