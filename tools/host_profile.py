@@ -1,7 +1,7 @@
 """cProfile of a few bench steps: where does the HOST time go?"""
 import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ["bench.py", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing"]
+sys.argv = ["bench.py", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--no-ohem-probe", "--no-psa-probe", "--i64-steps", "0", "--ref-steps", "0", "--fp32-steps", "0"] + sys.argv[1:]
 import bench
 pr = cProfile.Profile()
 import torch

@@ -11,6 +11,7 @@ kernel forward and one fused pair of kernels backward.
 import torch.nn as nn
 
 from seg_opr.seg_oprs import norm_act
+from torchseg_amd.fusion import outside_mode as _outside_mode
 from torchseg_amd.pool import MaxPool2d as _MaxPool2d
 from utils.pyt_utils import load_model
 
@@ -150,6 +151,7 @@ class ResNet(nn.Module):
                 return y
         return self.maxpool(norm_act(self.bn1, self.relu, x))
 
+    @_outside_mode
     def forward(self, x):
         x = self._stem(x)
         blocks = []

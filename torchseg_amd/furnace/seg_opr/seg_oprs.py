@@ -45,6 +45,7 @@ class _ConvNormAct(nn.Module):
 
     tsg_accepts_pending = True     # fusion.FuseMode's forward pre-hook leaves a PendingCbr argument to us
 
+    @_fusion.outside_mode
     def forward(self, x):
         mode = _fusion.CHAIN_ACTIVE
         if mode or isinstance(x, _fusion.PendingCbr):
@@ -227,6 +228,7 @@ class AttentionRefinement(nn.Module):
                        has_relu=False, has_bias=False),
             nn.Sigmoid())
 
+    @_fusion.outside_mode
     def forward(self, x):
         fm = self.conv_3x3(x)
         return channel_scale(fm, self.channel_attention(fm))
@@ -247,6 +249,7 @@ class FeatureFusion(nn.Module):
                        has_relu=False, has_bias=False),
             nn.Sigmoid())
 
+    @_fusion.outside_mode
     def forward(self, x1, x2):
         fm = self.conv_1x1(cat_channels(x1, x2))           # torch.cat([x1, x2], dim=1) on HIP channels_last maps
         return channel_scale(fm, self.channel_attention(fm), add_identity=True)

@@ -185,17 +185,39 @@ def _on_device(t):
 
 
 CHAIN_ACTIVE = False       # set while a FuseMode(chain=True) is entered: ConvBnRelu.forward may return a PendingCbr
+MODE_DEPTH = 0             # FuseModes entered: `outside_mode` forwards step out of torch-function dispatch while it is > 0
+
+
+def outside_mode(fn):
+    """Decorator for the forward of OUR furnace modules (ResNet, ConvBnRelu, AttentionRefinement, FeatureFusion, the
+    criteria): nothing inside them is a call pattern FuseMode has to see — the patterns live in the reference's network.py —
+    but the mode is consulted for every torch call they make (tensor attributes and the allocations inside the kernel
+    wrappers included: ~5 000 per BiSeNet forward, ~0.4 us each).  While a FuseMode is entered the wrapped forward runs
+    under torch._C.DisableTorchFunction(); deferred arguments have been materialised by the mode's forward pre-hook before
+    that.  Without a FuseMode (our own builders, evaluation) the wrapper costs one global read."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if MODE_DEPTH <= 0:
+            return fn(*args, **kwargs)
+        with torch._C.DisableTorchFunction():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _unwrap_pending_inputs(mod, args):
-    """Global forward pre-hook while a chain-fusing FuseMode is entered: every module except a ConvBnRelu (which feeds
-    on it) sees the materialised tensor."""
-    if getattr(mod, "tsg_accepts_pending", False):
-        return None
+    """Global forward pre-hook while a FuseMode is entered: a pending ConvBnRelu output or a pending `a += b` handed to a
+    MODULE is the real tensor by the time the module's forward runs (which may run outside torch-function dispatch:
+    `outside_mode`) — except a PendingCbr handed to the next ConvBnRelu, which feeds on it."""
     for a in args:
-        if isinstance(a, PendingCbr):
-            return tuple(a.materialize() if isinstance(a, PendingCbr) else a for a in args)
-    return None
+        if isinstance(a, (PendingCbr, DeferredSum)):
+            break
+    else:
+        return None
+    accepts = getattr(mod, "tsg_accepts_pending", False)
+    return tuple(a.materialize() if (isinstance(a, DeferredSum) or (isinstance(a, PendingCbr) and not accepts)) else a
+                 for a in args)
 
 
 class _PresumUpFn(torch.autograd.Function):
@@ -366,22 +388,24 @@ class FuseMode(TorchFunctionMode):
         self._watch = frozenset(watch)
 
     def __enter__(self):
-        global CHAIN_ACTIVE
+        global CHAIN_ACTIVE, MODE_DEPTH
+        import torch.nn.modules.module as _mm
+        self._hook = _mm.register_module_forward_pre_hook(_unwrap_pending_inputs)
+        MODE_DEPTH += 1
         if self.chain:
-            import torch.nn.modules.module as _mm
-            self._hook = _mm.register_module_forward_pre_hook(_unwrap_pending_inputs)
             self._chain_before = CHAIN_ACTIVE
             CHAIN_ACTIVE = self
         return super().__enter__()
 
     def __exit__(self, *exc):
-        global CHAIN_ACTIVE
+        global CHAIN_ACTIVE, MODE_DEPTH
         cbrs, self._cbrs = self._cbrs, []
+        MODE_DEPTH -= 1
         if self.chain:
             CHAIN_ACTIVE = self._chain_before
-            if self._hook is not None:
-                self._hook.remove()
-                self._hook = None
+        if self._hook is not None:
+            self._hook.remove()
+            self._hook = None
         out = super().__exit__(*exc)
         if self.chain and exc[0] is None:
             for c in cbrs:                               # never consumed: the eager program had run its BatchNorm

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
+from .fusion import outside_mode as _outside_mode
 
 _CITYSCAPES_WEIGHT = [1.4297, 1.4805, 1.4363, 3.365, 2.6635, 1.4311, 2.1943, 1.4817,
                       1.4513, 2.1984, 1.5295, 1.6892, 3.2224, 1.4727, 7.5978, 9.4117,
@@ -134,6 +135,7 @@ class CrossEntropyLoss2d(nn.Module):
             self.weight = None
         self.last_selection = None
 
+    @_outside_mode
     def forward(self, pred, target):
         from .fusion import DeferredLogSoftmax
         if isinstance(pred, DeferredLogSoftmax):
@@ -166,6 +168,7 @@ class ProbOhemCrossEntropy2d(nn.Module):
             self.weight = None
         self.last_selection = None
 
+    @_outside_mode
     def forward(self, pred, target):
         w = self.weight
         if w is not None and w.device != pred.device:
