@@ -64,6 +64,9 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_CAT=1|0           (default 1 on GPU: FeatureFusion's torch.cat([x1, x2], 1) on tsg_cat2_rows; pool.py)
   TSG_VEC_CONV=1|0      (default 1 on GPU: bias-free 1x1 convolutions applied to pooled [B, C, 1, 1] maps (channel attention,
                         global context) on tsg_conv1x1_vec_*: one launch forward, one backward, fp32 master weight; vecconv.py)
+  TSG_FORK_MODULES=a,b  (default none; e.g. "spatial_path": direct sub-modules of an unchanged network.py that run on a side HIP
+                        stream and are joined where their output is first used — BiSeNet's detail branch beside its context
+                        path.  Box-dependent (+1.4 % / -0.2 %), hence opt-in; our own BiSeNet builder: TSG_FORK_SPATIAL=1; fusion.py)
   TSG_WRW_STREAM=1|0    (default 1 on GPU: the 3x3 weight gradients run on a side HIP stream beside the SyncBatchNorm backward
                         passes of the layers in front of them and are joined at the end of the backward pass; convwrw.py)
   TSG_FP32_EXACT=1|0    (default 1: with TSG_DTYPE=fp32 every convolution runs on tsg_conv2d_f32_exact_* — exact products,
@@ -417,6 +420,15 @@ class DistributedDataParallel(nn.Module):
                 from . import exactconv
                 exactconv.install(self.module)
 
+        self._fork_hooks = []
+        if self.on_gpu and not native:
+            # TSG_FORK_MODULES (default none; e.g. "spatial_path"): direct sub-modules that run on a side HIP stream (fusion.py)
+            from . import fusion
+            for name in os.environ.get("TSG_FORK_MODULES", "").split(","):
+                sub = getattr(self.module, name.strip(), None) if name.strip() else None
+                if isinstance(sub, nn.Module):
+                    self._fork_hooks.append(sub.register_forward_pre_hook(fusion.fork_pre_hook))
+                    self._fork_hooks.append(sub.register_forward_hook(fusion.fork_post_hook))
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None
         force = dist.is_initialized() and _env_flag("TSG_FORCE_COLLECTIVES", False)   # 1-rank validation of the N>1 path

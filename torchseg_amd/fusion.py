@@ -206,10 +206,69 @@ def outside_mode(fn):
     return wrapper
 
 
+# ---- a sub-module of the wrapped model on a side stream (TSG_FORK_MODULES, opt-in) --------------------------------
+# BiSeNet's two paths share nothing until the fusion module (bisenet network.py:76-99): the detail branch — large maps,
+# HBM-bound BatchNorm passes and stems — runs on a side HIP stream beside the context path's deep layers (small maps,
+# matrix-core bound, too few tiles to fill the chip on their own); autograd replays every node on its forward stream, so the
+# backward overlaps the same way.  The wrapper (ddp.py) registers the two hooks below on the named sub-modules; the output
+# is joined the moment a module (the FuseMode's global forward pre-hook) or a torch function at network.py level (the
+# mode's slow path) receives it.
+_FORKED = {}               # id(output tensor) -> (weak reference, side stream, the stream the forward came from)
+_FORK_SIDE = {}
+_FORK_STACK = []
+
+
+def fork_pre_hook(mod, args):
+    if MODE_DEPTH <= 0 or not args or not isinstance(args[0], torch.Tensor) or not args[0].is_cuda \
+            or torch.cuda.is_current_stream_capturing():
+        _FORK_STACK.append(None)
+        return None
+    dev = args[0].device
+    cur = torch.cuda.current_stream(dev)
+    side = _FORK_SIDE.get(dev)
+    if side is None:
+        side = _FORK_SIDE[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    for a in args:
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            a.record_stream(side)
+    torch.cuda.set_stream(side)
+    _FORK_STACK.append((cur, side))
+    return None
+
+
+def fork_post_hook(mod, args, out):
+    st = _FORK_STACK.pop() if _FORK_STACK else None
+    if st is None:
+        return None
+    cur, side = st
+    torch.cuda.set_stream(cur)
+    out = _unwrap(out)
+    if isinstance(out, torch.Tensor):
+        import weakref
+        _FORKED[id(out)] = (weakref.ref(out), side, cur)
+        stats["forked"] += 1
+    else:                                               # not a single tensor: nothing to track, join at once
+        cur.wait_stream(side)
+    return out
+
+
+def _join_forked(args):
+    for a in args:
+        ent = _FORKED.get(id(a)) if isinstance(a, torch.Tensor) else None
+        if ent is not None and ent[0]() is a:
+            del _FORKED[id(a)]
+            cur = torch.cuda.current_stream(a.device)
+            cur.wait_stream(ent[1])
+            a.record_stream(cur)
+
+
 def _unwrap_pending_inputs(mod, args):
     """Global forward pre-hook while a FuseMode is entered: a pending ConvBnRelu output or a pending `a += b` handed to a
     MODULE is the real tensor by the time the module's forward runs (which may run outside torch-function dispatch:
     `outside_mode`) — except a PendingCbr handed to the next ConvBnRelu, which feeds on it."""
+    if _FORKED:
+        _join_forked(args)
     for a in args:
         if isinstance(a, (PendingCbr, DeferredSum)):
             break
@@ -322,7 +381,7 @@ def _mutates(func, kwargs):
 # counts say whether the fused path is actually taken
 stats = {"iadd_deferred": 0, "iadd_declined_alias": 0, "iadd_declined_not_augmented": 0, "presum_fused": 0,
          "materialized_before_mutation": 0, "head_deferred": 0, "ce_fused": 0, "psa_deferred": 0,
-         "cbr_deferred": 0, "cbr_fed": 0, "cbr_stem_fused": 0, "cbr_materialized": 0}
+         "cbr_deferred": 0, "cbr_fed": 0, "cbr_stem_fused": 0, "cbr_materialized": 0, "forked": 0}
 
 
 _LOG_SOFTMAX_FUNCS = (F.log_softmax, torch.log_softmax, torch.Tensor.log_softmax)
@@ -407,6 +466,10 @@ class FuseMode(TorchFunctionMode):
             self._hook.remove()
             self._hook = None
         out = super().__exit__(*exc)
+        if _FORKED and MODE_DEPTH <= 0:                  # never consumed inside the forward: join before anybody else can
+            for ref, side, cur in list(_FORKED.values()):
+                cur.wait_stream(side)
+            _FORKED.clear()
         if self.chain and exc[0] is None:
             for c in cbrs:                               # never consumed: the eager program had run its BatchNorm
                 if c._value is None and not c.consumed:
@@ -443,9 +506,16 @@ class FuseMode(TorchFunctionMode):
                 stats["materialized_before_mutation"] += 1
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
-        if func not in self._watch and not self._pending:
+        if func not in self._watch and not self._pending and not _FORKED:
             return func(*args, **kwargs) if kwargs else func(*args)
         kwargs = kwargs or {}
+        if _FORKED:
+            _join_forked(args)
+            if kwargs:
+                _join_forked(tuple(kwargs.values()))
+            for a in args:
+                if isinstance(a, (list, tuple)):
+                    _join_forked(a)
         if self.add_up and self._pending:
             self._settle_before_mutation(func, args, kwargs)
         if self.psa:

@@ -7,6 +7,7 @@ reference tree is absent.  Module attribute names and construction order match
 the reference file, hence state dicts are interchangeable and a fixed seed
 initialises both identically (tests/test_dropin_cpu.py checks both).
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -18,7 +19,9 @@ from seg_opr.seg_oprs import AttentionRefinement, ConvBnRelu, FeatureFusion, cbr
 
 
 import os as _os
-# TSG_FORK_SPATIAL=1|0: SpatialPath on a side HIP stream beside the context path (forward and, through autograd, backward)
+# TSG_FORK_SPATIAL=0|1 (default 0): SpatialPath on a side HIP stream beside the context path (forward and, through autograd,
+# backward).  Measured +1.4 % on two boxes and -0.2 % on a third once the weight gradients had their own side stream
+# (profiles/r05_small_ab.txt): opt-in.  The unchanged network.py gets the same through TSG_FORK_MODULES=spatial_path (ddp.py).
 _FORK_SPATIAL = _os.environ.get("TSG_FORK_SPATIAL", "0") == "1"
 _SIDE = {}
 
@@ -99,15 +102,15 @@ class BiSeNet(nn.Module):
     def features(self, data):
         """-> [1/16 aux fm, 1/8 aux fm, fused 1/8 fm] (network.py:75-101)."""
         fork = None
-        if data.is_cuda and _FORK_SPATIAL:
+        if data.is_cuda and _FORK_SPATIAL and not torch.cuda.is_current_stream_capturing():
             # the two paths share nothing until the fusion module: the detail branch (large maps: HBM-bound BatchNorm passes
             # and stems) runs on a side stream beside the context path's deep layers (small maps: matrix-core bound, too few
             # tiles to fill the chip on their own); autograd replays each node on its forward stream, so the backward
             # overlaps the same way
-            import torch
             cur = torch.cuda.current_stream(data.device)
             fork = _side_stream(data.device)
             fork.wait_stream(cur)
+            data.record_stream(fork)
             with torch.cuda.stream(fork):
                 spatial_out = self.spatial_path(data)
         else:
