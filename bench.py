@@ -156,6 +156,22 @@ def set_lr(opt, lr_policy, it):
         opt.refresh_lr()                                               # device-side lr for graph replay
 
 
+@contextlib.contextmanager
+def serial_kernels(on=True):
+    """Steps whose kernels are bracketed with HIP events run with the weight gradients on the COMPUTE stream: beside the
+    SyncBatchNorm passes on their side stream (convwrw.wrw_on_side_stream, the default) every bracketed kernel's elapsed time
+    would contain the kernel it shares the chip with, and the per-kernel roofline figures would be those of a time-shared
+    GPU (round 5: SyncBN 0.60 -> 0.47 of the HBM peak, weight gradients 0.28 -> 0.15 of the MFMA peak, their sum > the step)."""
+    from torchseg_amd import convwrw
+    old = convwrw._WRW_STREAM
+    if on:
+        convwrw._WRW_STREAM = False
+    try:
+        yield
+    finally:
+        convwrw._WRW_STREAM = old
+
+
 def step_body(model, opt, batch, world, with_optimizer=True):
     from utils.pyt_utils import all_reduce_tensor
     opt.zero_grad()
@@ -277,16 +293,22 @@ def ohem_kth_branch_probe(device, batch, size, reps=5):
     out = {"shape": f"{batch}x{NUM_CLASSES}x{low}^2 -> {size}^2 bf16, uint8 labels, min_kept {k}, thresh 0.7"}
 
     def timed(fn):
+        """median over `reps` of (events around 2 calls) / 2: one host hiccup (a collection of the models the side runs
+        just freed cost one repetition 7 ms in round 5) must not become the figure"""
         for _ in range(2):
             fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        a.record()
+        ts = []
         for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
             fn()
-        b.record()
-        torch.cuda.synchronize()
-        return round(a.elapsed_time(b) / reps * 1e3, 1)
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / 2)
+        ts.sort()
+        return round(ts[len(ts) // 2] * 1e3, 1)
 
     for name, z0 in (("trained_like", z_tr), ("random_init", z_rand)):
         z = z0.clone().requires_grad_(True)
@@ -586,7 +608,8 @@ def main():
             probe = None
             if not args.no_kernel_timing and it == n_eager - 1:
                 probe = K.KernelTimer(K.provider())
-            loss = train_step(model, opt, batch, pol, it, world)
+            with serial_kernels(probe is not None):
+                loss = train_step(model, opt, batch, pol, it, world)
             if probe is not None:
                 probe.stop()
                 dom_family = probe.dominant_family()
@@ -618,7 +641,8 @@ def main():
                     # launches per step cost 0.16 ms of the step (1177 against 1191 img/s in one process, round 5) —
                     # sampled, the roofline figure is still measured live inside the timed region (10 of 50 default steps)
                     timer.enabled = (it % 5 == 0)
-                loss = train_step(model, opt, batch, pol, args.warmup + it, world)
+                with serial_kernels(timer is not None and timer.enabled):
+                    loss = train_step(model, opt, batch, pol, args.warmup + it, world)
             if args.trace_loss and rank == 0:
                 print("step", it, "loss", float(loss.item()), "lr", opt.param_groups[0]["lr"], file=sys.stderr, flush=True)
         t_host = time.perf_counter() - t0                              # all K steps enqueued (the GPU may still be running)
@@ -752,7 +776,8 @@ def main():
             out["roofline"]["measured_over"] = "fully instrumented last warm-up step (every launch of every family bracketed)"
             if timer is not roof_probe:
                 out["roofline"]["timed_region"] = timer.roofline(HBM_PEAK_GBS, os.path.join(ROOT, "profiles"))
-                out["roofline"]["timed_region"]["sampled"] = "every 5th timed step"
+                out["roofline"]["timed_region"]["sampled"] = ("every 5th timed step; bracketed steps (and the instrumented "
+                                                              "warm-up step) keep the weight gradients on the compute stream")
             out["kernels_last_warmup_step"] = all_kernels
         if args.config == "bisenet" and args.dtype == "bf16" and args.size == 1024:
             # whole-step HBM roofline of SURVEY.md 8(d): ~3.4 GB of algorithmic traffic per image in bf16 (our
