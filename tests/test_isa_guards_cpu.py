@@ -125,3 +125,76 @@ def test_lds_dma_convolution_kernels_keep_their_budget(g3_isa):
         assert len(counted) >= 4, (name, counted)
         checked += 1
     assert checked == 3
+
+
+# ---- round 5: the three ISA patterns of DESIGN.md 4.2 ("what the ISA said"), held by the build ------------------------
+
+@pytest.fixture(scope="module")
+def conv64_isa(tmp_path_factory):
+    return _isa(tmp_path_factory, "conv64.hip")
+
+
+@pytest.fixture(scope="module")
+def ohem_isa(tmp_path_factory):
+    return _isa(tmp_path_factory, "ohem.hip")
+
+
+def _body(isa, needle):
+    names = [n for n in re.findall(r"\n(_ZN3tsg\w+):", isa) if needle in n]
+    assert names, needle
+    i = isa.index("\n" + names[0] + ":")
+    return isa[i:isa.index(".Lfunc_end", i)]
+
+
+def _vmem_sequence(body):
+    """loads ('L'), DMA loads to LDS ('D') and vmcnt waits ('W<n>') of a kernel, in program order"""
+    seq = []
+    for line in body.split("\n"):
+        t = line.strip().split(";")[0].strip()
+        if t.startswith(("global_load", "buffer_load", "scratch_load")):
+            seq.append("D" if t.endswith(" lds") else ("S" if t.startswith("scratch") else "L"))
+        m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
+        if m:
+            seq.append("W" + m.group(1))
+    return seq
+
+
+def test_conv64_dma_kernel_does_not_spill_and_issues_its_pieces_back_to_back(conv64_isa):
+    """A spilled register of the DMA geometry is reloaded in front of a `buffer_load ... lds`, and a scratch reload is an
+    s_waitcnt vmcnt(0): a wait for the PREVIOUS piece's DMA (the first build of this kernel did exactly that)."""
+    meta = _kernel_meta(conv64_isa)
+    dma = {k: v for k, v in meta.items() if "conv64_dma_fwd_k" in k}
+    assert len(dma) == 2, sorted(meta)
+    for name, (spill, scratch) in dma.items():
+        assert spill == 0 and scratch == 0, (name, spill, scratch)
+    seq = _vmem_sequence(_body(conv64_isa, "conv64_dma_fwd_kILb0E"))
+    assert "S" not in seq
+    runs = re.findall(r"D+", "".join(s[0] if s[0] in "DS" else "x" for s in seq))
+    assert runs and max(len(r) for r in runs) >= 7, seq[:60]      # the seven pieces of a wave, no wait between them
+
+
+def test_fused_head_forward_keeps_its_staging_loads_in_flight(ohem_isa):
+    """ohem_up_fwd2_k: the window and label loads are unconditional, so they issue in groups; the round-3 form (a load per
+    divergent branch) shows `load, vmcnt(0)` pairs throughout."""
+    seq = _vmem_sequence(_body(ohem_isa, "ohem_up_fwd2_kItLi1ELi20E"))
+    s = "".join("L" if t == "L" else ("0" if t == "W0" else "w") for t in seq)
+    assert len(re.findall(r"L{4,}", s)) >= 2, s                  # window loads and label loads issue in groups ...
+    assert re.search(r"L{3,}w+L{2,}", s), s                      # ... that stream behind counted (non-zero) waits
+    assert s.count("L0") <= 3, s                                 # no load-then-drain pairs in the staging loops
+    old = "".join("L" if t == "L" else ("0" if t == "W0" else "w") for t in _vmem_sequence(_body(ohem_isa, "ohem_up_fwd_kItLi1ELi20E")))
+    assert old.count("L0") >= 8                                  # ... which is what the round-3 form still looks like
+
+
+def test_fused_head_backward_does_not_consume_its_prefetch_at_the_load(ohem_isa):
+    """ohem_up_bwd_k: the next row's label / nll / lse loads are issued together with no wait between or right behind them
+    (round 4: `s_waitcnt vmcnt(1)` two instructions after the label load: the widening sat at the load)."""
+    for inst in ("ohem_up_bwd_kItLi1ELi20ELi1024E", "ohem_up_bwd_kItLi0ELi20ELi1024E"):
+        seq = _vmem_sequence(_body(ohem_isa, inst))
+        s = "".join("L" if t == "L" else "W" for t in seq)
+        assert "LLL" in s, (inst, seq)
+        k = [i for i in range(len(seq) - 2) if seq[i:i + 3] == ["L", "L", "L"]]
+        # the prefetch triple inside the row loop is the last triple of the listing before the flush code; it must not be
+        # followed at once by a counted wait on its first load
+        last = k[-1]
+        nxt = seq[last + 3] if last + 3 < len(seq) else ""
+        assert nxt not in ("W2", "W1"), (inst, seq)
