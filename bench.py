@@ -703,7 +703,7 @@ def main():
     # The reference's UNCHANGED network.py: same shape, same seed, same wrapper; its fused operators
     # are reached through fusion.FuseMode instead of being called by the builder.  Timed after the headline region.
     ref_rec = None
-    if args.ref_steps > 0 and args.network == "native" and not use_graph and args.dtype == "bf16":
+    if args.ref_steps > 0 and args.network == "native" and not use_graph and args.dtype == "bf16" and world == 1:   # rank 0 at N = 1 only, like cpu_baseline
         try:
             rmodel, ropt, _ = build_model(device, args.batch, args.size, ProbOhemCrossEntropy2d, SyncBatchNorm,
                                           seed=12345 if world == 1 else local_rank, fused_sgd=args.optimizer == "fused",
