@@ -71,15 +71,23 @@ def _wrw_join():
 
 def join_wrw_stream():
     """Make the current stream wait for weight gradients still running on the side stream (the engine callback does this
-    at the end of every backward pass; the DDP reducer calls it before it gathers a bucket early)."""
+    at the end of every backward pass; the DDP reducer calls it before it gathers a bucket early, FusedSGD before it
+    reads the gradients, the DDP wrapper at the start of the next forward — which also re-arms the callback should a
+    backward pass have died between queueing and running it)."""
     if _wrw_side:
-        _wrw_join()
+        for dev, side in _wrw_side.items():
+            torch.cuda.current_stream(dev).wait_stream(side)
 
 
-def wrw_on_side_stream(fn, *operands):
-    """`fn()` (launches a weight-gradient kernel, returns its result tensor) on the side stream of the operands' device."""
-    if not _WRW_STREAM or not operands[0].is_cuda or torch.cuda.is_current_stream_capturing():
-        return fn()
+def wrw_on_side_stream(fn, param, *operands):
+    """`fn()` (launches a weight-gradient kernel, returns its result tensor) on the side stream of the operands' device.
+    `param`: the parameter the result is the gradient of.  Only a parameter WITHOUT a gradient takes the side stream:
+    autograd's AccumulateGrad then just keeps the tensor; with a gradient already there (accumulation over several backward
+    passes, zero_grad(set_to_none=False)) it runs `grad += result` on the compute stream right after this node returns,
+    which would read the result under the running kernel."""
+    if not _WRW_STREAM or not operands[0].is_cuda or param is None or not param.is_leaf or param.grad is not None \
+            or param.dtype != torch.float32 or param._backward_hooks or torch.cuda.is_current_stream_capturing():
+        return fn()                                    # (a non-leaf, a cast or a tensor hook would touch the result at once)
     dev = operands[0].device
     cur = torch.cuda.current_stream(dev)
     side = _wrw_side.get(dev)
@@ -134,6 +142,7 @@ class _ConvWrwFn(torch.autograd.Function):
         # the fp32 master (a parameter) for the parity data gradient: its fragment-order image comes from the shadow bank
         ctx.master = weight if (ctx.s2_gen and _SHADOW and weight.dtype == torch.float32) else None
         ctx.save_for_backward(x, wb)
+        ctx.wparam = weight                            # (not a graph tensor here: only its .grad is looked at in backward)
         ctx.wdtype = weight.dtype
         ctx.need_dx = x.requires_grad
         ctx.dgrad_fwd = _DGRAD_FWD and stride == 1 and (_DGRAD_ANY or weight.shape[0] == weight.shape[1])
@@ -182,7 +191,7 @@ class _ConvWrwFn(torch.autograd.Function):
                                                          [True, False, False])[0]
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
-        dw = wrw_on_side_stream(lambda: K.provider().conv3x3_wrw(x, dy, stride=ctx.stride), x, dy)
+        dw = wrw_on_side_stream(lambda: K.provider().conv3x3_wrw(x, dy, stride=ctx.stride), ctx.wparam, x, dy)
         return dx, dw.to(ctx.wdtype), None, None, None, None, None
 
 
@@ -242,7 +251,7 @@ class _ConvGenFn(torch.autograd.Function):
                 dx = F.conv2d(dy, kp.conv3x3_weight_rot180_t(weight.detach().to(torch.bfloat16)), None, 1, 1)
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
-        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=1), x, dy)
+        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=1), weight, x, dy)
         return dx, dw.to(weight.dtype), None, None
 
 
@@ -355,6 +364,7 @@ class _BnReluConvFn(torch.autograd.Function):
         if partial is None:
             partial = x.new_empty(0, dtype=torch.float32)
         ctx.save_for_backward(x, weight if gen else wb, gamma, beta, invstd, fp, count_dev)
+        ctx.wparam = weight
         ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype, gen)
         ctx.wrt = wrt
         ctx.mark_non_differentiable(partial)
@@ -369,7 +379,7 @@ class _BnReluConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp), x, dy, fp)
+        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp), ctx.wparam, x, dy, fp)
         if gen:                                                  # wb is the fp32 master weight here
             da = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(wb, 1, dy), wb.shape[1])
         else:
@@ -418,6 +428,7 @@ class _StemBnReluConvFn(torch.autograd.Function):
         else:
             y, partial = kp.conv3x3_c64_fwd(xc, wb, stride=stride, in_ab=fp), img.new_empty(0, dtype=torch.float32)
         ctx.save_for_backward(img, xc, wb, gamma, beta, invstd, fp, count_dev)
+        ctx.wparam, ctx.wstem = weight, w_stem
         ctx.cfg = (layout, N, C, HW, use_batch_stats, group, world, stride, weight.dtype, w_stem.dtype)
         ctx.wrt = wrt
         ctx.mark_non_differentiable(partial)
@@ -432,13 +443,13 @@ class _StemBnReluConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp), xc, dy, fp)
+        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp), ctx.wparam, xc, dy, fp)
         rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
         da = kp.conv3x3_c64_s2_dgrad(dy, rot, (xc.shape[2], xc.shape[3])) if stride == 2 else kp.conv3x3_c64_fwd(dy, rot)
         partial, Sn = kp.bn_bwd_reduce(da, xc, None, layout, N, C, HW, fp, True)
         dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
                                              world, xc.device)
-        dw_stem = wrw_on_side_stream(lambda: kp.stem_conv_wrw_bn(img, da, xc, bp), img, da, xc, bp)   # the BN backward apply
+        dw_stem = wrw_on_side_stream(lambda: kp.stem_conv_wrw_bn(img, da, xc, bp), ctx.wstem, img, da, xc, bp)   # the BN backward apply
         #                                                                                     happens in its staging
         if gamma is None:
             dgamma = dbeta = None

@@ -312,6 +312,9 @@ class Reducer(object):
 
     def _finish_backward(self):
         self._callback_queued = False
+        from .convwrw import join_wrw_stream
+        join_wrw_stream()                                # this callback may run before convwrw's own: the plan's first copies
+        #                                                  and the stragglers read gradients written on the side stream
         if self.buckets is None:
             if not self._order:
                 return
@@ -440,6 +443,11 @@ class DistributedDataParallel(nn.Module):
 
     def forward(self, *inputs, **kwargs):
         import contextlib
+        if self.on_gpu:
+            from . import convwrw
+            if convwrw._wrw_side and not torch.cuda.is_current_stream_capturing():
+                convwrw.join_wrw_stream()                # normally a no-op wait: the last backward's callback joined already
+                convwrw._wrw_join_queued[0] = False      # re-arm (a backward pass that raised may have left it set)
         with contextlib.ExitStack() as stack:
             if self.on_gpu and self.compute_dtype != torch.float32:
                 stack.enter_context(torch.autocast("cuda", dtype=self.compute_dtype))

@@ -67,6 +67,9 @@ class FusedSGD(torch.optim.Optimizer):
             return None
         if not capturing:
             self._sync_lr(first.device)
+            from .convwrw import join_wrw_stream          # weight gradients still running on the side stream (the engine
+            join_wrw_stream()                             # callback has joined them already; this is the belt to its braces:
+            #                                               a backward pass that ended in an exception never ran it)
         if len(self.param_groups) > kp.SGD_MAX_GROUPS:      # DFN's train.py builds 18 (dfn train.py:66-73)
             raise K.L.TsgError(f"FusedSGD supports at most {kp.SGD_MAX_GROUPS} parameter groups")
         segs = []                                   # (param view, grad view, buffer, group index)

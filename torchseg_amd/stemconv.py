@@ -49,6 +49,7 @@ class _StemConvFn(torch.autograd.Function):
         else:
             y, partial = kp.stem_conv_fwd(x, weight), None
         ctx.save_for_backward(x)
+        ctx.wparam = weight
         ctx.wdtype = weight.dtype
         return y, partial
 
@@ -59,7 +60,7 @@ class _StemConvFn(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         from .convwrw import wrw_on_side_stream           # nothing but the optimizer waits for a stem's weight gradient
-        dw = wrw_on_side_stream(lambda: K.provider().stem_conv_wrw(x, dy), x, dy)
+        dw = wrw_on_side_stream(lambda: K.provider().stem_conv_wrw(x, dy), ctx.wparam, x, dy)
         return None, dw.to(ctx.wdtype), None
 
 
