@@ -235,3 +235,17 @@ def test_pooled_conv_swap_and_kernel_choice_of_the_general_3x3():
     assert lib.tsg_conv1x1_vec_supported(16, 512, 128) == 1 and lib.tsg_conv1x1_vec_supported(33, 512, 128) == 0
     assert lib.tsg_conv1x1_vec_supported(16, 100, 128) == 0
     assert lib.tsg_conv1x1_vec_fwd(None, None, None, 16, 64, 64, None) == -5
+
+
+def test_side_stream_gradient_layout_contract():
+    """convwrw._kept_as_gradient: AccumulateGrad keeps a first gradient only in the parameter's own layout."""
+    import torch
+    from torchseg_amd.convwrw import _kept_as_gradient, wrw_on_side_stream
+    p = torch.zeros(8, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+    assert _kept_as_gradient(torch.empty(8, 4, 3, 3).contiguous(memory_format=torch.channels_last), p)
+    assert not _kept_as_gradient(torch.empty(8, 4, 3, 3), p)
+    assert not _kept_as_gradient(torch.empty(8, 4, 3, 3, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last), p)
+    q = torch.zeros(8, 1, 3, 3)                         # a dimension of length 1: its stride is free
+    assert _kept_as_gradient(torch.empty(8, 1, 3, 3).contiguous(memory_format=torch.channels_last), q)
+    out = wrw_on_side_stream(lambda: torch.ones(2), torch.nn.Parameter(torch.zeros(2)), torch.zeros(2))   # host tensors: plain call
+    assert out.tolist() == [1.0, 1.0]

@@ -79,6 +79,14 @@ def join_wrw_stream():
             torch.cuda.current_stream(dev).wait_stream(side)
 
 
+def _kept_as_gradient(out, param):
+    """autograd's layout contract for a first gradient (torch/csrc/autograd/functions/accumulate_grad.h): the strides of
+    the parameter on every dimension longer than 1."""
+    if out.shape != param.shape or out.dtype != param.dtype:
+        return False
+    return all(a == b for a, b, n in zip(out.stride(), param.stride(), out.shape) if n != 1)
+
+
 def wrw_on_side_stream(fn, param, *operands):
     """`fn()` (launches a weight-gradient kernel, returns its result tensor) on the side stream of the operands' device.
     `param`: the parameter the result is the gradient of.  Only a parameter WITHOUT a gradient takes the side stream:
@@ -100,6 +108,10 @@ def wrw_on_side_stream(fn, param, *operands):
         if t is not None:
             t.record_stream(side)                      # their memory must not be handed out again under the running kernel
     out.record_stream(cur)
+    if not _kept_as_gradient(out, param):
+        # AccumulateGrad keeps a first gradient as it is only when it has the parameter's layout; otherwise it copies it
+        # into that layout on the compute stream, at once: the copy must see the finished kernel
+        cur.wait_stream(side)
     if not _wrw_join_queued[0]:
         _wrw_join_queued[0] = True
         from torch.autograd import Variable
