@@ -361,3 +361,23 @@ def test_inplace_keyword_settles_a_pending_sum(standin):
             return a * 1.0
     import contextlib
     torch.testing.assert_close(run(FuseMode(loss=False)), run(contextlib.nullcontext()), rtol=0, atol=0)
+
+
+def test_outside_mode_materialises_pending_keyword_arguments():
+    """The mode's global forward pre-hook sees positional arguments only: a pending value handed to one of our modules by
+    keyword is materialised by the `outside_mode` wrapper before the forward leaves torch-function dispatch."""
+    import torch
+    from torchseg_amd import fusion
+
+    seen = {}
+
+    @fusion.outside_mode
+    def forward(x, residual=None):
+        seen["type"] = type(residual)
+        return x + residual
+
+    a, b = torch.ones(1, 2, 2, 2), torch.full((1, 2, 2, 2), 2.0)
+    pending = fusion.DeferredSum(a, b)
+    with fusion.FuseMode():
+        out = forward(torch.zeros(1, 2, 2, 2), residual=pending)
+    assert seen["type"] is torch.Tensor and torch.equal(out, torch.full((1, 2, 2, 2), 3.0))

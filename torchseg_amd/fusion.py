@@ -201,6 +201,8 @@ def outside_mode(fn):
     def wrapper(*args, **kwargs):
         if MODE_DEPTH <= 0:
             return fn(*args, **kwargs)
+        if kwargs:                                       # the mode's forward pre-hook sees positional arguments only
+            kwargs = {k: (v.materialize() if isinstance(v, (PendingCbr, DeferredSum)) else v) for k, v in kwargs.items()}
         with torch._C.DisableTorchFunction():
             return fn(*args, **kwargs)
     return wrapper
