@@ -58,7 +58,25 @@ _SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "1") != "0"
 # (2.3 ms that leave the matrix pipes idle).  The operands are kept alive for the side stream (record_stream), the result
 # belongs to the compute stream, and the end of the backward pass (an autograd engine callback) makes the compute stream
 # wait for the side stream, so the optimizer, the DDP buckets' gather and anything after .backward() see finished gradients.
-_WRW_STREAM = _os.environ.get("TSG_WRW_STREAM", "1") != "0"
+#
+# Default: on in a process WITHOUT gradient collectives, off once a DDP reducer exists (N > 1, or TSG_FORCE_COLLECTIVES=1);
+# TSG_WRW_STREAM=1 forces it on there too.  The HIP runtime multiplexes a process's streams onto 4 hardware queues, least
+# used first; with RCCL's and the process group's streams in the process the side stream landed on the compute stream's OWN
+# hardware queue (rocprofv3 kernel trace: Queue_Id 1 for both), where two streams run strictly in order and every
+# cross-stream event is a bubble: zero overlap and 1 091 img/s on the N > 1 code path of one rank, against 1 175 without
+# the side stream and 1 173 with GPU_MAX_HW_QUEUES=8 — i.e. no gain left to defend there
+# (profiles/r05_side_stream_hw_queue.txt).
+_WRW_ENV = _os.environ.get("TSG_WRW_STREAM")
+_WRW_STREAM = _WRW_ENV != "0"
+
+
+def side_stream_off_for_collectives():
+    """ddp.DistributedDataParallel calls this when it builds a reducer (see above); an explicit TSG_WRW_STREAM wins."""
+    global _WRW_STREAM
+    if _WRW_ENV is None:
+        _WRW_STREAM = False
+
+
 _wrw_side = {}
 _wrw_join_queued = [False]
 

@@ -67,8 +67,10 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_FORK_MODULES=a,b  (default none; e.g. "spatial_path": direct sub-modules of an unchanged network.py that run on a side HIP
                         stream and are joined where their output is first used — BiSeNet's detail branch beside its context
                         path.  Box-dependent (+1.4 % / -0.2 %), hence opt-in; our own BiSeNet builder: TSG_FORK_SPATIAL=1; fusion.py)
-  TSG_WRW_STREAM=1|0    (default 1 on GPU: the 3x3 weight gradients run on a side HIP stream beside the SyncBatchNorm backward
-                        passes of the layers in front of them and are joined at the end of the backward pass; convwrw.py)
+  TSG_WRW_STREAM=1|0    (default: 1 on GPU without a gradient reducer, 0 with one — world > 1: the 3x3 weight gradients run on a
+                        side HIP stream beside the SyncBatchNorm backward passes of the layers in front of them and are
+                        joined at the end of the backward pass.  With RCCL's streams in the process the side stream shares the
+                        compute stream's hardware queue and costs 7 % instead of gaining 1.7 %; convwrw.py)
   TSG_FP32_EXACT=1|0    (default 1: with TSG_DTYPE=fp32 every convolution runs on tsg_conv2d_f32_exact_* — exact products,
                         fp64 accumulation — instead of the vendor library's fp32 kernels: the parity mode, exactconv.py)
 """
@@ -440,6 +442,9 @@ class DistributedDataParallel(nn.Module):
             _broadcast_coalesced(tensors, 0, process_group)
             self.reducer = Reducer(module.parameters(), process_group, message_size, delay_allreduce,
                                    gradient_average, gradient_predivide_factor)
+            if self.on_gpu:
+                from .convwrw import side_stream_off_for_collectives
+                side_stream_off_for_collectives()        # its hardware queue collides with the compute stream's (convwrw.py)
 
     def forward(self, *inputs, **kwargs):
         import contextlib
