@@ -249,3 +249,17 @@ def test_side_stream_gradient_layout_contract():
     assert _kept_as_gradient(torch.empty(8, 1, 3, 3).contiguous(memory_format=torch.channels_last), q)
     out = wrw_on_side_stream(lambda: torch.ones(2), torch.nn.Parameter(torch.zeros(2)), torch.zeros(2))   # host tensors: plain call
     assert out.tolist() == [1.0, 1.0]
+
+
+def test_side_stream_default_yields_to_a_gradient_reducer(monkeypatch):
+    """convwrw.side_stream_off_for_collectives: the default (TSG_WRW_STREAM unset) turns the side stream off once a
+    reducer exists; an explicit setting is left alone."""
+    from torchseg_amd import convwrw
+    monkeypatch.setattr(convwrw, "_WRW_ENV", None)
+    monkeypatch.setattr(convwrw, "_WRW_STREAM", True)
+    convwrw.side_stream_off_for_collectives()
+    assert convwrw._WRW_STREAM is False
+    monkeypatch.setattr(convwrw, "_WRW_ENV", "1")
+    monkeypatch.setattr(convwrw, "_WRW_STREAM", True)
+    convwrw.side_stream_off_for_collectives()
+    assert convwrw._WRW_STREAM is True
