@@ -120,3 +120,40 @@ def test_syncbn_and_ddp_world2_match_single_process(rs):
             torch.testing.assert_close(torch.from_numpy(res[r][1][k]), v, rtol=2e-4, atol=2e-5, msg=k)
     for k in res[0][1]:
         assert (res[0][1][k] == res[1][1][k]).all(), k   # replicas stay bit-identical
+
+
+def test_communicator_that_cannot_be_built_falls_back_on_every_rank(tmp_path):
+    """comm._create_agreed: a tsg_comm that fails to build (no librccl, ncclCommInitRank refusing) is agreed on through the
+    process group; every rank then gets None from comm.get (torch.distributed's collectives), once, with a warning."""
+    import subprocess
+    import sys
+    script = tmp_path / "agree.py"
+    script.write_text('''
+import socket, sys, warnings
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from torchseg_amd import comm
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1)
+calls = []
+class Broken(object):
+    def __init__(self, group=None, **kw):
+        calls.append(1)
+        raise RuntimeError("librccl.so: cannot open shared object file")
+comm.Comm = Broken
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    assert comm._create_agreed(None) is False
+assert len(w) == 1 and "torch.distributed" in str(w[0].message) and "librccl" in str(w[0].message)
+comm._comms[None] = False                  # what get() stores
+class FakeCuda(object):
+    is_cuda = True
+dist.get_backend = lambda group=None: "nccl"
+assert comm.get(None, like=FakeCuda()) is None and comm.get(None, like=FakeCuda()) is None
+assert len(calls) == 1                     # not retried on every exchange
+comm.shutdown()
+dist.destroy_process_group()
+print("agreed-fallback-ok")
+''' % ROOT)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "agreed-fallback-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

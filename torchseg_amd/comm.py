@@ -128,8 +128,29 @@ def get(group=None, like=None):
     if c is None:
         if dist.get_backend(group) != "nccl":
             return None
-        c = _comms[key] = Comm(group)
-    return c
+        c = _comms[key] = _create_agreed(group)
+    return c or None
+
+
+def _create_agreed(group):
+    """Comm(group), or False on EVERY rank when the communicator could not be built on any of them (librccl.so not found
+    or lacking a symbol, ncclGetUniqueId / ncclCommInitRank refusing): the ranks agree through the process group that
+    carried the unique id, so that they all take torch.distributed's collectives instead of splitting over two paths."""
+    err = None
+    try:
+        c = Comm(group)
+    except Exception as e:                                 # noqa: BLE001 - whatever it was, the other ranks must hear of it
+        c, err = None, e
+    ok = torch.tensor([1 if c is not None else 0], dtype=torch.int32, device="cuda" if torch.cuda.is_available() else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return c
+    if c is not None:
+        c.destroy()
+    import warnings
+    warnings.warn("torchseg_amd.comm: no tsg_comm communicator on this process group (%s); SyncBN exchanges and gradient "
+                  "buckets stay on torch.distributed" % (err if err is not None else "another rank failed to build its"))
+    return False
 
 
 def get_extra(group=None, tag="extra", like=None):
@@ -149,7 +170,8 @@ def shutdown():
     runtime is torn down: Engine.__exit__ and bench.py call this explicitly; `_atexit_shutdown` is the guarded fallback
     for every other entry point that wrapped a model (eval scripts, user code)."""
     for c in list(_comms.values()):
-        c.destroy()
+        if c:
+            c.destroy()
     _comms.clear()
 
 
