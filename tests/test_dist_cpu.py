@@ -122,38 +122,123 @@ def test_syncbn_and_ddp_world2_match_single_process(rs):
         assert (res[0][1][k] == res[1][1][k]).all(), k   # replicas stay bit-identical
 
 
-def test_communicator_that_cannot_be_built_falls_back_on_every_rank(tmp_path):
-    """comm._create_agreed: a tsg_comm that fails to build (no librccl, ncclCommInitRank refusing) is agreed on through the
-    process group; every rank then gets None from comm.get (torch.distributed's collectives), once, with a warning."""
-    import subprocess
-    import sys
-    script = tmp_path / "agree.py"
-    script.write_text('''
-import socket, sys, warnings
-import torch, torch.distributed as dist
-sys.path.insert(0, %r)
-from torchseg_amd import comm
-s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1)
-calls = []
-class Broken(object):
-    def __init__(self, group=None, **kw):
-        calls.append(1)
-        raise RuntimeError("librccl.so: cannot open shared object file")
-comm.Comm = Broken
-with warnings.catch_warnings(record=True) as w:
-    warnings.simplefilter("always")
-    assert comm._create_agreed(None) is False
-assert len(w) == 1 and "torch.distributed" in str(w[0].message) and "librccl" in str(w[0].message)
-comm._comms[None] = False                  # what get() stores
-class FakeCuda(object):
-    is_cuda = True
-dist.get_backend = lambda group=None: "nccl"
-assert comm.get(None, like=FakeCuda()) is None and comm.get(None, like=FakeCuda()) is None
-assert len(calls) == 1                     # not retried on every exchange
-comm.shutdown()
-dist.destroy_process_group()
-print("agreed-fallback-ok")
-''' % ROOT)
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "agreed-fallback-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+class _FakeLib(object):
+    """Stands in for libtsg_hip.so's tsg_comm_* entry points on a CPU box: `fail` names the call that refuses."""
+
+    def __init__(self, fail=None):
+        self.fail = fail
+        self.created = 0
+        self.destroyed = 0
+
+    def tsg_comm_unique_id_bytes(self):
+        return 128
+
+    def tsg_comm_get_unique_id(self, buf):
+        if self.fail == "get_unique_id":
+            return 3
+        buf.raw = bytes(range(128))
+        return 0
+
+    def tsg_comm_create(self, ident, rank, world, device, out):
+        if self.fail == "create":
+            return 5
+        assert bytes(ident.raw) == bytes(range(128))           # the id rank 0 made arrived on every rank
+        self.created += 1
+        return 0
+
+    def tsg_comm_destroy(self, handle):
+        self.destroyed += 1
+        return 0
+
+    def tsg_comm_xgmi_handle_bytes(self):
+        return 64
+
+    def tsg_comm_xgmi_export(self, handle, cap, buf):
+        return 7 if self.fail == "export" else 0
+
+    def tsg_comm_xgmi_attach(self, handle, allh):
+        return 0
+
+
+def _agree_worker(rank, world, port, q, case):
+    """One rank of comm._create_agreed with a failure injected on ONE rank (the round-5 code raised where the
+    error happened, so the other rank sat in a collective the failing one had skipped)."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from torchseg_amd import _lib as L
+    from torchseg_amd import comm
+    bad_rank, what = case
+    fake = _FakeLib(what if rank == bad_rank else None)
+
+    def lib():
+        if rank == bad_rank and what == "load":
+            raise OSError("librccl.so: cannot open shared object file")
+        return fake
+    L.lib = lib
+    if what == "export":
+        os.environ["TSG_XGMI_ONESHOT"] = "1"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c = comm._create_agreed(None)
+    t = torch.ones(1)
+    dist.all_reduce(t)                             # the ranks' collective sequences are still aligned
+    msgs = [str(x.message) for x in w]
+    q.put((rank, c is False, bool(c) and c.one_shot, msgs, fake.created, fake.destroyed, float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [(0, "load"), (1, "load"), (0, "get_unique_id"), (1, "create"), (1, "export"), (None, None)],
+                         ids=["rank0-no-library", "rank1-no-library", "rank0-no-unique-id", "rank1-create-refuses",
+                              "rank1-mailbox-export-fails", "all-fine"])
+def test_communicator_that_cannot_be_built_falls_back_on_every_rank(case):
+    """comm.Comm keeps the collective sequence identical on every rank whatever fails locally, and comm._create_agreed
+    returns False on EVERY rank (torch.distributed's collectives, with a warning) when any rank failed: no rank hangs in the
+    id broadcast, none splits off."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q, case)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    bad_rank, what = case
+    for r in range(world):
+        is_false, one_shot, msgs, created, destroyed, total = res[r]
+        assert total == world
+        if what in (None, "export"):
+            assert not is_false                    # the communicator exists on both ranks ...
+            assert not one_shot                    # ... and a mailbox that one rank cannot export is used by none
+            assert created == 1
+            if what == "export" and r == bad_rank:
+                assert any("mailbox export failed" in m for m in msgs)
+        else:
+            assert is_false, (case, r)
+            assert len(msgs) == 1 and "torch.distributed" in msgs[0], msgs
+            if r == bad_rank:
+                assert ("librccl" in msgs[0]) if what == "load" else ("tsg_comm" in msgs[0]), msgs
+            assert created == destroyed            # a communicator built on the healthy rank is destroyed again
+
+
+def test_get_does_not_retry_a_failed_communicator(monkeypatch):
+    """comm.get stores the agreed `False` and answers None from then on (not one rendezvous attempt per exchange)."""
+    from torchseg_amd import comm
+    calls = []
+    monkeypatch.setattr(comm, "_create_agreed", lambda group: calls.append(1) or False)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(comm, "_comms", {})
+
+    class FakeCuda(object):
+        is_cuda = True
+    assert comm.get(None, like=FakeCuda()) is None and comm.get(None, like=FakeCuda()) is None
+    assert len(calls) == 1

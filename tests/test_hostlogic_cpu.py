@@ -263,3 +263,26 @@ def test_side_stream_default_yields_to_a_gradient_reducer(monkeypatch):
     monkeypatch.setattr(convwrw, "_WRW_STREAM", True)
     convwrw.side_stream_off_for_collectives()
     assert convwrw._WRW_STREAM is True
+
+
+def test_side_stream_tells_the_reducers_hook_from_a_foreign_one():
+    """convwrw._foreign_grad_hooks: a post-accumulate-grad hook reads p.grad before the end-of-backward join,
+    so it keeps the weight gradient on the compute stream — unless it is the DDP reducer's, which joins first."""
+    import torch
+    from torchseg_amd import convwrw
+    from torchseg_amd.ddp import Reducer
+    p = torch.nn.Parameter(torch.zeros(4))
+    assert not convwrw._foreign_grad_hooks(p)
+    red = Reducer.__new__(Reducer)                       # (its constructor needs a process group: test_dist_cpu.py)
+    convwrw.allow_grad_hook(red._on_grad)                # what Reducer.__init__ does before it registers the hook
+    p.register_post_accumulate_grad_hook(red._on_grad)
+    assert not convwrw._foreign_grad_hooks(p)            # a BOUND method of any reducer instance is recognised
+    other = Reducer.__new__(Reducer)
+    p.register_post_accumulate_grad_hook(other._on_grad)
+    assert not convwrw._foreign_grad_hooks(p)
+    q = torch.nn.Parameter(torch.zeros(4))
+    h = q.register_post_accumulate_grad_hook(lambda t: None)
+    assert convwrw._foreign_grad_hooks(q)
+    h.remove()
+    assert not convwrw._foreign_grad_hooks(q)
+    del red

@@ -94,3 +94,59 @@ def test_side_stream_is_taken_only_for_parameters_without_a_gradient(cuda, monke
         net(x).float().sum().backward()                 # gradients exist now: AccumulateGrad will add on the compute stream
     assert calls == {"side": 3, "main": 3}, calls
     torch.cuda.synchronize()
+
+
+def _run_twice_in_one_backward(cuda, side):
+    """loss = f(net(x1)) + f(net(x2)): every weight is used twice in ONE backward pass."""
+    from torchseg_amd import convwrw
+    old = convwrw._WRW_STREAM
+    convwrw._WRW_STREAM = side
+    try:
+        net = _stack(cuda)
+        g = torch.Generator(device=cuda).manual_seed(3)
+        x1 = torch.randn(8, 64, 64, 64, device=cuda, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x2 = torch.randn(8, 64, 64, 64, device=cuda, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = net(x1).float().square().mean() + net(x2).float().square().mean()
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in net.parameters()]
+        torch.cuda.synchronize()
+        return grads
+    finally:
+        convwrw._WRW_STREAM = old
+
+
+def test_parameter_used_twice_in_one_backward_pass(cuda):
+    """Both uses see `grad is None` when their nodes run; the engine sums the two results on the compute stream.  The second
+    use must therefore wait for the side stream and stay on the compute stream (round 5 sent both to the side stream: a race)."""
+    want = _run_twice_in_one_backward(cuda, False)
+    for _ in range(4):
+        got = _run_twice_in_one_backward(cuda, True)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
+def test_foreign_post_accumulate_hook_keeps_the_compute_stream(cuda, monkeypatch):
+    """An optimizer-in-backward hook reads p.grad as soon as AccumulateGrad has run: such a parameter's weight gradient
+    stays on the compute stream; the DDP reducer's own hook (which joins the side stream first) does not count."""
+    from torchseg_amd import convwrw
+    monkeypatch.setattr(convwrw, "_WRW_STREAM", True)
+    net = _stack(cuda)
+    seen = {}
+
+    def step_in_backward(p):
+        seen["grad"] = p.grad.detach().clone()          # on the compute stream, right now
+    net[0].weight.register_post_accumulate_grad_hook(step_in_backward)
+    assert convwrw._foreign_grad_hooks(net[0].weight) and not convwrw._foreign_grad_hooks(net[2].weight)
+    x = torch.randn(8, 64, 64, 64, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        net(x).float().square().mean().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(seen["grad"], net[0].weight.grad)
+    monkeypatch.setattr(convwrw, "_WRW_STREAM", False)
+    ref = _stack(cuda)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ref(x).float().square().mean().backward()
+    torch.cuda.synchronize()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(a.grad, b.grad)

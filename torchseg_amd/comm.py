@@ -21,45 +21,105 @@ from . import _lib as L
 _MAX_SMALL = 2 * 2048 + 8          # floats: the largest SyncBN message (2C+2 at C = 2048)
 
 
+class CommUnavailable(RuntimeError):
+    """Raised by Comm(...) on EVERY rank of the group when any of them could not build its communicator."""
+
+
+def _agree(ok, group):
+    """MIN all-reduce of a local outcome over `group` (on the device the group's backend moves)."""
+    dev = "cuda" if (dist.get_backend(group) == "nccl" and torch.cuda.is_available()) else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
 class Comm(object):
     """One communicator per process group (one rank per GPU)."""
 
     def __init__(self, group=None, device=None, rccl=True, xgmi=None):
-        self.lib = L.lib()
+        """Every rank of `group` runs the SAME sequence of torch.distributed collectives here whatever fails locally
+        (ADVICE r5): local steps are tried, their outcome is agreed on with a MIN all-reduce, and only then does anybody
+        raise — CommUnavailable, on every rank together.  Round 5 raised where the error happened: rank 0 failing in
+        tsg_comm_get_unique_id skipped the id broadcast the other ranks were already waiting in.
+          1 local   load the library; rank 0: ncclGetUniqueId
+          2 coll    broadcast of the id (rank 0 sends None when step 1 failed there)
+          3 coll    agree
+          4 local   tsg_comm_create (ncclCommInitRank: RCCL's own rendezvous, entered by all ranks or by none)
+          5 coll    agree
+          6 xgmi    export (local) -> all-gather of the handles (None = failed) -> attach (local) -> agree"""
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.device = torch.cuda.current_device() if device is None else int(device)
-        ident = None
-        if rccl:
-            n = self.lib.tsg_comm_unique_id_bytes()
-            buf = C.create_string_buffer(n)
-            if self.rank == 0:
-                L.check(self.lib.tsg_comm_get_unique_id(buf), "tsg_comm_get_unique_id")
-            box = [buf.raw if self.rank == 0 else None]
-            src = dist.get_global_rank(group, 0) if group is not None else 0
-            dist.broadcast_object_list(box, src=src, group=group)
-            ident = C.create_string_buffer(box[0], n)
-        handle = C.c_void_p()
-        L.check(self.lib.tsg_comm_create(ident, self.rank, self.world, self.device, C.byref(handle)), "tsg_comm_create")
-        self.handle = handle
+        self.handle = None
         self.has_rccl = bool(rccl)
         self.one_shot = False
+        err, ident = None, None
+        try:                                                   # 1
+            self.lib = L.lib()
+            self.device = (torch.cuda.current_device() if torch.cuda.is_available() else 0) if device is None else int(device)
+            if rccl:
+                n = self.lib.tsg_comm_unique_id_bytes()
+                buf = C.create_string_buffer(n)
+                if self.rank == 0:
+                    L.check(self.lib.tsg_comm_get_unique_id(buf), "tsg_comm_get_unique_id")
+                    ident = buf.raw
+        except Exception as e:                                 # noqa: BLE001 - the other ranks must hear of it, whatever it was
+            err = e
+        if rccl:                                               # 2
+            box = [ident if self.rank == 0 else None]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            ident = box[0]
+            if ident is None and err is None:
+                err = RuntimeError("rank 0 could not produce the RCCL unique id")
+        self._agree_or_raise(err, "load the library / exchange the RCCL unique id")        # 3
+        try:                                                   # 4
+            handle = C.c_void_p()
+            idbuf = C.create_string_buffer(ident, len(ident)) if rccl else None
+            L.check(self.lib.tsg_comm_create(idbuf, self.rank, self.world, self.device, C.byref(handle)), "tsg_comm_create")
+            self.handle = handle
+        except Exception as e:                                 # noqa: BLE001
+            err = e
+        try:
+            self._agree_or_raise(err, "create the communicator")                             # 5
+        except CommUnavailable:
+            self.destroy()
+            raise
         if xgmi is None:
             xgmi = os.environ.get("TSG_XGMI_ONESHOT", "0") == "1"
         if xgmi:
             self._attach_mailboxes()
 
+    def _agree_or_raise(self, err, what):
+        if not _agree(err is None, self.group):
+            raise CommUnavailable("could not %s on %s" % (what, "this rank: %s" % (err,) if err is not None
+                                                          else "another rank")) from err
+
     def _attach_mailboxes(self):
-        hb = self.lib.tsg_comm_xgmi_handle_bytes()
-        mine = C.create_string_buffer(hb)
-        L.check(self.lib.tsg_comm_xgmi_export(self.handle, _MAX_SMALL, mine), "tsg_comm_xgmi_export")
+        """The one-shot mailboxes (step 6 above); a rank that cannot export or map them leaves EVERY rank on RCCL."""
+        hb, mine = 0, None
+        try:
+            hb = self.lib.tsg_comm_xgmi_handle_bytes()
+            buf = C.create_string_buffer(hb)
+            L.check(self.lib.tsg_comm_xgmi_export(self.handle, _MAX_SMALL, buf), "tsg_comm_xgmi_export")
+            mine = buf.raw
+        except Exception as e:                                 # noqa: BLE001
+            import warnings
+            warnings.warn("torchseg_amd.comm: mailbox export failed (%s); SyncBN messages stay on RCCL" % (e,))
         handles = [None] * self.world
-        dist.all_gather_object(handles, mine.raw, group=self.group)
-        allh = C.create_string_buffer(b"".join(handles), hb * self.world)
-        L.check(self.lib.tsg_comm_xgmi_attach(self.handle, allh), "tsg_comm_xgmi_attach")
-        dist.barrier(group=self.group)          # every mailbox is mapped before the first store into it
-        self.one_shot = True
+        dist.all_gather_object(handles, mine, group=self.group)
+        ok = all(h is not None for h in handles)
+        if ok:
+            try:
+                allh = C.create_string_buffer(b"".join(handles), hb * self.world)
+                L.check(self.lib.tsg_comm_xgmi_attach(self.handle, allh), "tsg_comm_xgmi_attach")
+            except Exception as e:                             # noqa: BLE001
+                import warnings
+                warnings.warn("torchseg_amd.comm: mailbox attach failed (%s); SyncBN messages stay on RCCL" % (e,))
+                ok = False
+        # every mailbox is mapped before the first store into it (the all-reduce is the barrier round 5 had here), and
+        # all ranks use the mailboxes or none does
+        self.one_shot = _agree(ok, self.group)
 
     @staticmethod
     def _check(t):
@@ -134,23 +194,16 @@ def get(group=None, like=None):
 
 def _create_agreed(group):
     """Comm(group), or False on EVERY rank when the communicator could not be built on any of them (librccl.so not found
-    or lacking a symbol, ncclGetUniqueId / ncclCommInitRank refusing): the ranks agree through the process group that
-    carried the unique id, so that they all take torch.distributed's collectives instead of splitting over two paths."""
-    err = None
+    or lacking a symbol, ncclGetUniqueId / ncclCommInitRank refusing): Comm.__init__ keeps the ranks' collective sequences
+    identical and raises CommUnavailable on all of them together, so that they all take torch.distributed's collectives
+    instead of splitting over two paths (or waiting in a collective a failing rank skipped)."""
     try:
-        c = Comm(group)
-    except Exception as e:                                 # noqa: BLE001 - whatever it was, the other ranks must hear of it
-        c, err = None, e
-    ok = torch.tensor([1 if c is not None else 0], dtype=torch.int32, device="cuda" if torch.cuda.is_available() else "cpu")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if int(ok.item()) == 1:
-        return c
-    if c is not None:
-        c.destroy()
-    import warnings
-    warnings.warn("torchseg_amd.comm: no tsg_comm communicator on this process group (%s); SyncBN exchanges and gradient "
-                  "buckets stay on torch.distributed" % (err if err is not None else "another rank failed to build its"))
-    return False
+        return Comm(group)
+    except CommUnavailable as e:
+        import warnings
+        warnings.warn("torchseg_amd.comm: no tsg_comm communicator on this process group (%s); SyncBN exchanges and gradient "
+                      "buckets stay on torch.distributed" % (e,))
+        return False
 
 
 def get_extra(group=None, tag="extra", like=None):
@@ -161,7 +214,10 @@ def get_extra(group=None, tag="extra", like=None):
     key = (id(group) if group is not None else None, tag)
     c = _comms.get(key)
     if c is None:
-        c = _comms[key] = Comm(group, xgmi=False)
+        try:
+            c = _comms[key] = Comm(group, xgmi=False)
+        except CommUnavailable:                                # every rank lands here together: share the first communicator
+            c = _comms[key] = get(group, like)
     return c
 
 

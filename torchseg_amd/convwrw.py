@@ -68,6 +68,13 @@ _SHADOW = _os.environ.get("TSG_WEIGHT_SHADOW", "1") != "0"
 # (profiles/r05_side_stream_hw_queue.txt).
 _WRW_ENV = _os.environ.get("TSG_WRW_STREAM")
 _WRW_STREAM = _WRW_ENV != "0"
+# TSG_WRW_IN_GRAPH=1|0 (default 0): under hipGraph capture the side stream can be kept — its fork (side waits for the
+# capturing stream) and its join (the end-of-backward callback) become EDGES of the captured graph.  Measured in round 6
+# (profiles/r06_graph_ab.txt, interleaved on one box): a single-stream graph of the step 1 198 / 1 203 img/s (host 0.15-0.2 ms
+# per step), the same graph with the 27 weight-gradient forks inside it 1 168 / 1 166 (host 7.2 ms: hipGraphLaunch walks a
+# branching graph node by node), eager with the side stream 1 196 / 1 202 (host 12.2-13.2 ms).  A linear graph replays as
+# fast as the eager step overlaps, without the host; so the captured step stays on one stream.
+_WRW_IN_GRAPH = _os.environ.get("TSG_WRW_IN_GRAPH", "0") == "1"
 
 
 def side_stream_off_for_collectives():
@@ -79,10 +86,27 @@ def side_stream_off_for_collectives():
 
 _wrw_side = {}
 _wrw_join_queued = [False]
+_wrw_pending = set()                   # id(param) of every parameter whose gradient of THIS backward pass is on the side stream
+_OWN_GRAD_HOOKS = set()                # post-accumulate-grad hooks that join the side stream themselves (ddp.Reducer._on_grad)
+
+
+def allow_grad_hook(fn):
+    """Register a post-accumulate-grad hook (by its function object) as one that calls join_wrw_stream() before it reads
+    p.grad: the DDP reducer's.  Any OTHER such hook on a parameter (an optimizer-in-backward step) keeps that parameter's
+    weight gradient on the compute stream."""
+    _OWN_GRAD_HOOKS.add(getattr(fn, "__func__", fn))
+
+
+def _foreign_grad_hooks(param):
+    hooks = getattr(param, "_post_accumulate_grad_hooks", None)
+    if not hooks:
+        return False
+    return any(getattr(h, "__func__", h) not in _OWN_GRAD_HOOKS for h in hooks.values())
 
 
 def _wrw_join():
     _wrw_join_queued[0] = False
+    _wrw_pending.clear()
     for dev, side in _wrw_side.items():
         torch.cuda.current_stream(dev).wait_stream(side)
 
@@ -110,12 +134,28 @@ def wrw_on_side_stream(fn, param, *operands):
     `param`: the parameter the result is the gradient of.  Only a parameter WITHOUT a gradient takes the side stream:
     autograd's AccumulateGrad then just keeps the tensor; with a gradient already there (accumulation over several backward
     passes, zero_grad(set_to_none=False)) it runs `grad += result` on the compute stream right after this node returns,
-    which would read the result under the running kernel."""
+    which would read the result under the running kernel.  The same holds for a parameter used TWICE in one backward pass
+    (shared weights; `loss = net(x1) + net(x2)`): both uses see `grad is None` at node time, and the engine sums the two
+    results on the compute stream — so a parameter that already has a side-stream result in this pass (`_wrw_pending`,
+    cleared by the end-of-backward join) makes the compute stream wait for the side stream and computes the second one
+    there.  A post-accumulate-grad hook that is not the DDP reducer's would read p.grad before the join."""
     if not _WRW_STREAM or not operands[0].is_cuda or param is None or not param.is_leaf or param.grad is not None \
-            or param.dtype != torch.float32 or param._backward_hooks or torch.cuda.is_current_stream_capturing():
+            or param.dtype != torch.float32 or param._backward_hooks or _foreign_grad_hooks(param) \
+            or (torch.cuda.is_current_stream_capturing() and not _WRW_IN_GRAPH):
+        if _wrw_side and operands[0].is_cuda:
+            # anything computed here may be summed with (or share scratch state with) a result still on the side stream
+            dev = operands[0].device
+            side = _wrw_side.get(dev)
+            if side is not None and (param is None or id(param) in _wrw_pending):
+                torch.cuda.current_stream(dev).wait_stream(side)
         return fn()                                    # (a non-leaf, a cast or a tensor hook would touch the result at once)
     dev = operands[0].device
     cur = torch.cuda.current_stream(dev)
+    if id(param) in _wrw_pending:                      # second use of the parameter in this backward pass: see above
+        side = _wrw_side.get(dev)
+        if side is not None:
+            cur.wait_stream(side)
+        return fn()
     side = _wrw_side.get(dev)
     if side is None:
         side = _wrw_side[dev] = torch.cuda.Stream(device=dev)
@@ -126,6 +166,7 @@ def wrw_on_side_stream(fn, param, *operands):
         if t is not None:
             t.record_stream(side)                      # their memory must not be handed out again under the running kernel
     out.record_stream(cur)
+    _wrw_pending.add(id(param))
     if not _kept_as_gradient(out, param):
         # AccumulateGrad keeps a first gradient as it is only when it has the parameter's layout; otherwise it copies it
         # into that layout on the compute stream, at once: the copy must see the finished kernel

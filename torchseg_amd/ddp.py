@@ -153,6 +153,8 @@ class Reducer(object):
         self._rs = _env_flag("TSG_DDP_RS", False)
         self._comm = None            # tsg_comm of the buckets (HIP tensors), resolved at the first launch
         self._side = None            # the HIP stream the bucket collectives run on
+        from .convwrw import allow_grad_hook
+        allow_grad_hook(self._on_grad)  # joins the weight-gradient side stream (_launch / _finish_backward) before it reads a .grad
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     # -- autograd side -------------------------------------------------------

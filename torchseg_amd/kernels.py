@@ -322,12 +322,23 @@ class HipKernels:
                                                      weight.shape[3], stride, padding, dilation, groups,
                                                      x.shape[2], x.shape[3]))
 
-    def _stem_ws(self, dev):
-        ws = getattr(self, "_stem_ws_buf", None)
-        if ws is None or ws.device != dev:
-            ws = torch.empty(self.lib.tsg_stem_conv_ws_bytes(), dtype=torch.uint8, device=dev)
-            self._stem_ws_buf = ws
+    def _scratch(self, name, nbytes, dev):
+        """A scratch buffer per (kernel family, device, STREAM), grown on demand.  Per stream because launches on different
+        streams may overlap (the weight gradients of one backward pass can be split between the side stream of
+        convwrw.wrw_on_side_stream and the compute stream its fallbacks use; one shared buffer would be written by two
+        kernels at once).  Launches of one stream run in order, so they share."""
+        st = torch.cuda.current_stream(dev)
+        key = (name, dev.index, st.cuda_stream)
+        pool = self.__dict__.setdefault("_scratch_bufs", {})
+        ws = pool.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = pool[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            ws.record_stream(st)                  # allocated under whatever stream torch considers current: a grown
+            #                                       buffer's predecessor must outlive the kernel still using it
         return ws
+
+    def _stem_ws(self, dev):
+        return self._scratch("stem", self.lib.tsg_stem_conv_ws_bytes(), dev)
 
     def stem_conv_fwd(self, x, weight):
         """x [B,3,H,W] bf16 contiguous, weight fp32 [64,3,7,7] -> y [B,64,OH,OW] bf16 channels_last"""
@@ -884,9 +895,7 @@ class HipKernels:
         dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if Cin == 64 and Cout == 64 and stride == 1 and variant != "gen":
             fn = self.lib.tsg_conv3x3_wrw_tr if variant == "tr" else self.lib.tsg_conv3x3_wrw
-            ws = getattr(self, "_c3_ws", None)
-            if ws is None or ws.device != x.device:
-                ws = self._c3_ws = torch.empty(self.lib.tsg_conv3x3_wrw_ws_bytes(), dtype=torch.uint8, device=x.device)
+            ws = self._scratch("c3", self.lib.tsg_conv3x3_wrw_ws_bytes(), x.device)
             if in_ab is not None:
                 L.check(self.lib.tsg_conv3x3_wrw_tr_norm(x.data_ptr(), in_ab.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W,
                                                          ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_conv3x3_wrw_tr_norm")
@@ -897,12 +906,7 @@ class HipKernels:
         wsb = self.lib.tsg_conv3x3_wrw_gen_ws_bytes(B, H, W, Cin, Cout, stride)
         if wsb == 0:
             raise L.TsgError("conv3x3_wrw: unsupported shape %s -> %d channels, stride %d" % (tuple(x.shape), Cout, stride))
-        ws = getattr(self, "_c3g_ws", None)                       # one buffer, grown to the largest layer (<= 38 MB)
-        if ws is None or ws.device != x.device or ws.numel() < wsb:
-            ws = self._c3g_ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-        ws.record_stream(torch.cuda.current_stream(x.device))     # shared across launches: they must all be on ONE stream
-        #                                                           (convwrw.wrw_on_side_stream), and a grown buffer's
-        #                                                           predecessor must outlive the kernel still using it
+        ws = self._scratch("c3g", wsb, x.device)                  # per stream, grown to the largest layer (<= 38 MB)
         if in_ab is not None:
             L.check(self.lib.tsg_conv3x3_wrw_gen_norm(x.data_ptr(), in_ab.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, Cin,
                                                       Cout, int(stride), ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
