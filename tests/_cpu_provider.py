@@ -25,10 +25,18 @@ class OracleProvider:
     def _count(count, count_dev):
         return float(count_dev[0]) * 4096.0 + float(count_dev[1]) if count_dev is not None else float(count)
 
+    @staticmethod
+    def _rows(part64, like):
+        """What csrc/bn.hip hands on: one fp32 row for a bf16 tensor; a hi and a lo fp32 row (S = 2) for an fp32 tensor,
+        whose sums it accumulates in fp64 (RedAcc<float, .>)."""
+        hi = part64.float()
+        if like.dtype != torch.float32:
+            return hi.unsqueeze(0).contiguous(), 1
+        return torch.stack([hi, (part64 - hi.double()).float()]).contiguous(), 2
+
     def bn_stats(self, x, layout, N, C, HW):
         x64 = x.detach().double()
-        part = torch.stack([x64.sum(self._axes(x)), (x64 * x64).sum(self._axes(x))]).float().unsqueeze(0)
-        return part.contiguous(), 1
+        return self._rows(torch.stack([x64.sum(self._axes(x)), (x64 * x64).sum(self._axes(x))]), x)
 
     def bn_collapse(self, partial, S, C, out, count=None):
         s, q = self._sums(partial, S, C)
@@ -80,8 +88,7 @@ class OracleProvider:
     def bn_bwd_reduce(self, dy, x, y, layout, N, C, HW, fp, relu):
         d = self._mask(dy, x, y, fp, relu).double()
         xc = x.double() - self._bc(fp[2].double(), x)
-        part = torch.stack([d.sum(self._axes(x)), (d * xc).sum(self._axes(x))]).float().unsqueeze(0)
-        return part.contiguous(), 1
+        return self._rows(torch.stack([d.sum(self._axes(x)), (d * xc).sum(self._axes(x))]), x)
 
     def bn_bwd_coeffs(self, partial, S, C, count, count_dev, batch_stats, invstd, fp, want_param_grads, want_pack):
         s, q = self._sums(partial, S, C)

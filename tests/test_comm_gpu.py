@@ -259,3 +259,59 @@ def test_ddp_buckets_through_tsg_comm_on_a_side_stream(cuda, mode, rs):
     status, info = q.get(timeout=300)
     p.join(60)
     assert status == "ok", info
+
+
+def _parity_gather_worker(port, q):
+    """fp32 SyncBatchNorm on the N > 1 code path of one rank (TSG_FORCE_COLLECTIVES=1): the statistics cross the "rank
+    boundary" as gathered hi / lo rows through tsg_comm_allgather and keep their fp64 accumulation."""
+    try:
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                          TSG_FORCE_COLLECTIVES="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        from torchseg_amd import syncbn
+        from torchseg_amd.syncbn import SyncBatchNorm
+        g = torch.Generator().manual_seed(11)
+        base = 5.0 + torch.rand(128, generator=g, dtype=torch.float64) * 5.0
+        delta = (torch.rand(2, 128, generator=g, dtype=torch.float64) - 0.5) * 2e-2
+        x32 = (base + delta).float().reshape(2, 128, 1, 1)
+        w = (torch.arange(1, 129, dtype=torch.float64) / 64.0).reshape(1, 128, 1, 1) * torch.tensor([1.0, -0.5]).reshape(2, 1, 1, 1)
+        ref = torch.nn.BatchNorm2d(128, eps=1e-5).double()
+        ref.train()
+        xr = x32.double().requires_grad_(True)
+        yr = ref(xr)
+        (yr * w).sum().backward()
+        errs = {}
+        for gather in (True, False):
+            syncbn._FP32_GATHER = gather
+            bn = SyncBatchNorm(128, eps=1e-5).cuda()
+            bn.train()
+            x = x32.cuda().requires_grad_(True)
+            y = bn(x)
+            (y * w.float().cuda()).sum().backward()
+            torch.cuda.synchronize()
+            errs[gather] = (float((y.double().cpu() - yr).abs().max()),
+                            float((x.grad.double().cpu() - xr.grad).abs().max() / xr.grad.abs().max()))
+        from torchseg_amd import comm
+        comm.shutdown()
+        dist.destroy_process_group()
+        q.put(("ok", errs))
+    except Exception:                                    # noqa: BLE001
+        import traceback
+        q.put(("exc", traceback.format_exc()))
+
+
+def test_fp32_statistics_gathered_as_hi_lo_rows_on_the_forced_path(cuda):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_parity_gather_worker, args=(_free_port(), q))
+    p.start()
+    status, info = q.get(timeout=240)
+    p.join(60)
+    assert status == "ok", info
+    print("gathered hi/lo (y, dx):", info[True], "  fp32 all-reduce:", info[False])
+    assert info[True][0] < 5e-4 and info[True][1] < 5e-4
+    assert info[False][0] > 5 * info[True][0]            # the exchange of rounds 1-5 loses the statistics on this case

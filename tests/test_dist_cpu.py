@@ -242,3 +242,73 @@ def test_get_does_not_retry_a_failed_communicator(monkeypatch):
         is_cuda = True
     assert comm.get(None, like=FakeCuda()) is None and comm.get(None, like=FakeCuda()) is None
     assert len(calls) == 1
+
+
+def _parity_worker(rank, world, port, q, gather):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      TSG_BN_FP32_GATHER=gather)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _cpu_provider import OracleProvider
+    from torchseg_amd import kernels as K
+    from torchseg_amd.syncbn import SyncBatchNorm
+    K._set_provider_for_tests(OracleProvider())
+    # BiSeNet's global-context BatchNorm across two ranks with ONE image each: [1, C, 1, 1] per rank, values a, b with
+    # |a - b| << |a|: var = ((a - b) / 2)^2 against a^2
+    g = torch.Generator().manual_seed(11)
+    base = 5.0 + torch.rand(8, generator=g, dtype=torch.float64) * 5.0
+    delta = (torch.rand(2, 8, generator=g, dtype=torch.float64) - 0.5) * 2e-2
+    x = (base + delta[rank]).float().reshape(1, 8, 1, 1).requires_grad_(True)
+    bn = SyncBatchNorm(8, eps=1e-5)
+    bn.train()
+    y = bn(x)
+    w = torch.arange(1, 9, dtype=torch.float32).reshape(1, 8, 1, 1) * (1.0 if rank == 0 else -0.5)
+    (y * w).sum().backward()
+    q.put((rank, y.detach().double().numpy(), x.grad.double().numpy(), bn.running_var.double().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fp32_statistics_keep_their_fp64_accumulation_across_ranks():
+    """in the fp32 parity mode the statistics cross the rank boundary as gathered hi / lo rows
+    (syncbn._gather_hilo), so the E[x^2] - mean^2 cancellation of a [B, C, 1, 1] BatchNorm does not return with world > 1;
+    the round-5 exchange (an fp32 all-reduce of the rounded sums, TSG_BN_FP32_GATHER=0) loses it."""
+    import numpy as np
+    world = 2
+    res = {}
+    for gather in ("1", "0"):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_parity_worker, args=(r, world, port, q, gather)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = {}
+        for _ in range(world):
+            r = q.get(timeout=120)
+            out[r[0]] = r[1:]
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        res[gather] = out
+    # float64 truth: BatchNorm over the two-image batch of the SAME fp32 inputs
+    g = torch.Generator().manual_seed(11)
+    base = 5.0 + torch.rand(8, generator=g, dtype=torch.float64) * 5.0
+    delta = (torch.rand(2, 8, generator=g, dtype=torch.float64) - 0.5) * 2e-2
+    x = torch.stack([(base + delta[r]).float().double() for r in range(2)]).reshape(2, 8, 1, 1).requires_grad_(True)
+    bn = nn.BatchNorm2d(8, eps=1e-5).double()
+    bn.train()
+    y = bn(x)
+    w = torch.arange(1, 9, dtype=torch.float64).reshape(1, 8, 1, 1) * torch.tensor([1.0, -0.5]).reshape(2, 1, 1, 1)
+    (y * w).sum().backward()
+
+    def err(out):
+        ey = max(np.abs(out[r][0] - y[r:r + 1].detach().numpy()).max() for r in range(2))
+        eg = max(np.abs(out[r][1] - x.grad[r:r + 1].numpy()).max() / np.abs(x.grad.numpy()).max() for r in range(2))
+        return ey, eg
+    ey1, eg1 = err(res["1"])
+    ey0, eg0 = err(res["0"])
+    print("gathered hi/lo: y %.2e dx %.2e   fp32 all-reduce: y %.2e dx %.2e" % (ey1, eg1, ey0, eg0))
+    assert ey1 < 5e-4 and eg1 < 5e-4            # |y| ~ 1: what is left is the fp32 rounding of y = a x + b (a ~ 170, b ~ -1300), not of the sums
+    assert ey0 > 10 * ey1                        # the case is one where the old exchange does lose the statistics
+    for r in range(2):                           # both ranks folded the same rows in the same order
+        assert (res["1"][0][2] == res["1"][1][2]).all()

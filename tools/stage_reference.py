@@ -20,7 +20,7 @@ import tarfile
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = "/root/reference"
+REF = os.environ.get("TSG_REFERENCE_DIR", "/root/reference")     # (the override: tests force the archive path)
 OUT_DIR = os.path.join(ROOT, "oracle", "_ref")
 ARCHIVE = os.path.join(OUT_DIR, "reference_models.tar.gz")
 
@@ -33,6 +33,16 @@ EXPERIMENTS = (
     ("psanet", "ade.psanet.R50_v1c"),
 )
 FILES = ("network.py", "config.py")
+# the reference's OWN furnace files its network.py / loss run on (SURVEY 8(d) "CPU reference timing": the unchanged network.py,
+# seg_oprs.py, resnet.py, loss_opr.py, init_func.py + what they import) -> archive members under furnace_ref/; used ONLY by
+# tools/cpu_reference.py (bench.py's cpu_baseline leg of kind "reference", a subprocess of its own: their module names are
+# the ones our furnace/ answers to as well)
+FURNACE_REF = (
+    "base_model/__init__.py", "base_model/resnet.py", "base_model/xception.py",
+    "seg_opr/__init__.py", "seg_opr/seg_oprs.py", "seg_opr/loss_opr.py",
+    "utils/__init__.py", "utils/init_func.py", "utils/pyt_utils.py",
+    "engine/__init__.py", "engine/logger.py", "engine/lr_policy.py",
+)
 
 
 def have_reference():
@@ -56,6 +66,12 @@ def pack():
                 info.mtime, info.uid, info.gid, info.uname, info.gname = 0, 0, 0, "", ""
                 with open(src, "rb") as fh:
                     tar.addfile(info, fh)
+        for f in FURNACE_REF:
+            src = os.path.join(REF, "furnace", f)
+            info = tar.gettarinfo(src, arcname=os.path.join("furnace_ref", f))
+            info.mtime, info.uid, info.gid, info.uname, info.gname = 0, 0, 0, "", ""
+            with open(src, "rb") as fh:
+                tar.addfile(info, fh)
     data = buf.getvalue()
     if not (os.path.exists(ARCHIVE) and open(ARCHIVE, "rb").read() == data):
         with open(ARCHIVE, "wb") as fh:
@@ -65,6 +81,24 @@ def pack():
 
 def available():
     return have_reference() or os.path.exists(ARCHIVE)
+
+
+def stage_reference_furnace(base_dir):
+    """`<base_dir>/TorchSeg/furnace/` = the REFERENCE's own furnace files (FURNACE_REF), for the CPU leg that times the
+    reference code itself.  Call before stage(): stage() then finds `furnace` present and does not link ours."""
+    fdir = os.path.join(str(base_dir), "TorchSeg", "furnace")
+    for f in FURNACE_REF:
+        dst = os.path.join(fdir, f)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        if have_reference():
+            shutil.copy(os.path.join(REF, "furnace", f), dst)                     # scratch copy, never committed
+        elif os.path.exists(ARCHIVE):
+            with tarfile.open(ARCHIVE, "r:gz") as tar:
+                with tar.extractfile(tar.getmember(os.path.join("furnace_ref", f))) as src, open(dst, "wb") as out:
+                    out.write(src.read())
+        else:
+            raise FileNotFoundError("neither %s nor %s is present" % (REF, ARCHIVE))
+    return fdir
 
 
 def stage(base_dir, family, exp, files=FILES):
