@@ -10,8 +10,10 @@ pytestmark = pytest.mark.gpu
 BATCH, SIZE, WARM, STEPS = 8, 512, 3, 12
 
 
-def _run(cuda, mode, fused):
+def _run(cuda, mode, fused, fork_in_graph=False):
     import bench
+    from torchseg_amd import convwrw
+    convwrw._WRW_IN_GRAPH = bool(fork_in_graph)          # the weight-gradient side stream captured as graph edges (opt-in)
     from torchseg_amd.ddp import DistributedDataParallel
     from torchseg_amd.losses import ProbOhemCrossEntropy2d
     from torchseg_amd.syncbn import SyncBatchNorm
@@ -46,10 +48,18 @@ def _run(cuda, mode, fused):
     return losses
 
 
-@pytest.mark.parametrize("mode,fused", [(1, True), (1, False), (2, True)])
-def test_graph_replay_trajectory_equals_eager(cuda, mode, fused):
+@pytest.mark.parametrize("mode,fused,fork", [(1, True, False), (1, False, False), (2, True, False), (2, True, True)],
+                         ids=["fwd+bwd", "fwd+bwd torch SGD", "whole step (bench default)", "whole step, side stream forked inside the graph"])
+def test_graph_replay_trajectory_equals_eager(cuda, mode, fused, fork):
+    """The eager run takes the weight-gradient side stream (the default without a reducer); the captured step is linear
+    unless `fork` (TSG_WRW_IN_GRAPH=1: the forks and the join become graph edges — correct, but slower to launch)."""
+    from torchseg_amd import convwrw
+    assert convwrw._WRW_STREAM
     eager = _run(cuda, 0, fused)
-    graph = _run(cuda, mode, fused)
+    try:
+        graph = _run(cuda, mode, fused, fork)
+    finally:
+        convwrw._WRW_IN_GRAPH = False
     print("eager", ["%.4f" % v for v in eager], "\ngraph", ["%.4f" % v for v in graph])
     assert np.isfinite(graph).all(), graph
     # two EAGER runs of this 8 x 512^2 bf16 configuration already differ by ~0.6 % (MIOpen's atomic split-K weight

@@ -16,7 +16,7 @@ TSG_WRW_STREAM=0 bash tools/prof_bench.sh > $O/prof_bench_serial.out 2>&1; cp gp
 export TSG_WRW_STREAM=0     # counter passes: one kernel at a time, or FETCH_SIZE / WRITE_SIZE / MFMA-busy of a kernel contain its neighbour's
 bash tools/pmc_traffic.sh > $O/pmc_traffic.out 2>&1; cp gpurun_out/pmc/summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc/traffic_by_kernel.json $O/traffic_by_kernel.json
 out=$PWD/gpurun_out/pmc_busy; rm -rf $out; mkdir -p $out
-(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-ohem-probe --no-psa-probe --i64-steps 0 --ref-steps 0 --fp32-steps 0 > $out.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-ohem-probe --no-psa-probe --i64-steps 0 --ref-steps 0 --fp32-steps 0 --forced-steps 0 > $out.log 2>&1)
 python tools/pmc_mfma_busy.py $out $O/mfma_busy.json
 find $out -name "*.csv" -size +8M -delete
 python tools/make_traffic_json.py $O/traffic_by_kernel.json $O/traffic.json "$TAG@$HEAD" $O/mfma_busy.json > /dev/null

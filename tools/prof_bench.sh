@@ -6,7 +6,7 @@ CFG=${1:-bisenet}
 SUF=""; [ "$CFG" != "bisenet" ] && SUF="_$CFG"
 out=$PWD/gpurun_out/prof$SUF
 rm -rf $out; mkdir -p $out
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench -- python $OLDPWD/bench.py --config $CFG --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-psa-probe --no-ohem-probe --i64-steps 0 --ref-steps 0 --fp32-steps 0 > $out.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench -- python $OLDPWD/bench.py --config $CFG --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-psa-probe --no-ohem-probe --i64-steps 0 --ref-steps 0 --fp32-steps 0 --forced-steps 0 > $out.log 2>&1)
 echo "rc=$?"; tail -1 $out.log | cut -c1-200
 PROF_OUT=$out python - <<'PY'
 import csv, glob, collections
