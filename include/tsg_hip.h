@@ -324,6 +324,21 @@ int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial
                            int64_t H, int64_t W, void* stream);
 int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B, int64_t H, int64_t W,
                              void* stream);
+/* The two data gradients with the BACKWARD SUMS of the BatchNorm -> ReLU in front of the convolution in their epilogue
+ * (round 6): where the convolution's input was relu(bn(x)) (seg_oprs.py:39-46 followed by the next ConvBnRelu, bisenet
+ * network.py:116-118; BasicBlock's bn1 -> relu -> conv2, resnet.py:36-46), the gradient dx computed here is the dy' that
+ * SyncBN's backward starts from (syncbn_kernel.cu:160-174 with the ReLU mask folded in).  The thread that stores 16 bytes of
+ * dx reads the 16 bytes of x beside them and accumulates sum dx m and sum dx m (x - mean), m = (a x + b > 0), from the
+ * bf16-ROUNDED values it stores: partial [S][2][64] fp32 in the layout tsg_bn_bwd_coeffs takes, S = *_partials(B, H, W)
+ * (0: shape not covered by this form, run tsg_bn_bwd_reduce instead).  tsg_bn_bwd_reduce(relu = 1, y = NULL) over the stored
+ * dx computes the same sums in a pass of its own (one more read of dx and the same read of x); the two differ in the order
+ * of the fp32 summation only.  bn_x [B,H,W,64] bf16: the BatchNorm's input; bn_fp: its forward pack [3][64] (a, b, mean). */
+int tsg_conv3x3_c64_dgrad_bnsums_partials(int64_t B, int64_t H, int64_t W);
+int tsg_conv3x3_c64_dgrad_bnsums(const void* dy, const void* wt, void* dx, const void* bn_x, const float* bn_fp,
+                                 float* partial, int64_t B, int64_t H, int64_t W, void* stream);
+int tsg_conv3x3_c64_s2_dgrad_partials(int64_t B, int64_t H, int64_t W);
+int tsg_conv3x3_c64_s2_dgrad_bnsums(const void* dy, const void* wt, void* dx, const void* bn_x, const float* bn_fp,
+                                    float* partial, int64_t B, int64_t H, int64_t W, void* stream);
 
 int tsg_conv3x3_weight_rot180_t(const void* w, int dtype, void* out, int O, int I, void* stream);
 

@@ -164,7 +164,7 @@ def test_conv64_dma_kernel_does_not_spill_and_issues_its_pieces_back_to_back(con
     s_waitcnt vmcnt(0): a wait for the PREVIOUS piece's DMA (the first build of this kernel did exactly that)."""
     meta = _kernel_meta(conv64_isa)
     dma = {k: v for k, v in meta.items() if "conv64_dma_fwd_k" in k}
-    assert len(dma) == 2, sorted(meta)
+    assert len(dma) == 3, sorted(meta)            # <STATS, BSUM> = <0,0>, <1,0>, <0,1>
     for name, (spill, scratch) in dma.items():
         assert spill == 0 and scratch == 0, (name, spill, scratch)
     seq = _vmem_sequence(_body(conv64_isa, "conv64_dma_fwd_kILb0E"))

@@ -78,6 +78,10 @@ _PROTOS = {
     "tsg_conv3x3_c64_s2_stats_partials": (_i, [_i64, _i64, _i64]),
     "tsg_conv3x3_c64_s2_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "tsg_conv3x3_c64_s2_dgrad": (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "tsg_conv3x3_c64_dgrad_bnsums_partials": (_i, [_i64, _i64, _i64]),
+    "tsg_conv3x3_c64_dgrad_bnsums": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "tsg_conv3x3_c64_s2_dgrad_partials": (_i, [_i64, _i64, _i64]),
+    "tsg_conv3x3_c64_s2_dgrad_bnsums": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "tsg_conv3x3_gen_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tsg_conv3x3_gen_filter_elems": (_i64, [_i, _i]),
     "tsg_conv3x3_gen_tile": (_i, [_i64, _i64, _i64, _i, _i]),

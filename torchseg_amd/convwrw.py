@@ -401,6 +401,27 @@ def conv_with_skip(conv, x):
     return conv(x), None
 
 
+# TSG_BN_BSUM=1|0 (default 1, round 6): the backward sums of a BatchNorm -> ReLU in the epilogue of the data gradient of the
+# convolution behind it (tsg_conv3x3_c64_*dgrad_bnsums; the general kernels: _gen_dgrad_with_bn_sums below) instead of a
+# pass of their own over the gradient and the BatchNorm's input (tsg_bn_bwd_reduce): one read of the gradient less, and the
+# read of x under a matrix kernel that leaves most of the HBM rate unused.  Same values up to the order of the fp32 sums.
+_BN_BSUM = _os.environ.get("TSG_BN_BSUM", "0") == "1"
+
+
+def _c64_dgrad_and_bn_sums(kp, dy, rot, x, fp, stride, layout, N, C, HW):
+    """(da, partial, S): the data gradient of a 64 -> 64 convolution whose input was relu(bn(x)) and the backward sums of
+    that BatchNorm — from the kernel's epilogue where it has one, else by the separate pass."""
+    if _BN_BSUM and hasattr(kp, "conv3x3_c64_bnsums_supported") and kp.conv3x3_c64_bnsums_supported(x.shape[0], x.shape[2], x.shape[3], stride):
+        if stride == 2:
+            da, partial = kp.conv3x3_c64_s2_dgrad(dy, rot, (x.shape[2], x.shape[3]), bsum=(x, fp))
+        else:
+            da, partial = kp.conv3x3_c64_fwd(dy, rot, bsum=(x, fp))
+        return da, partial, partial.shape[0]
+    da = kp.conv3x3_c64_s2_dgrad(dy, rot, (x.shape[2], x.shape[3])) if stride == 2 else kp.conv3x3_c64_fwd(dy, rot)
+    partial, Sn = kp.bn_bwd_reduce(da, x, None, layout, N, C, HW, fp, True)
+    return da, partial, Sn
+
+
 class _BnReluConvFn(torch.autograd.Function):
     """conv(relu(bn(x))) for the 3x3 layers our kernels cover, with the normalised activation never stored: the
     convolution (tsg_conv3x3_c64_*_fwd for 64 -> 64, tsg_conv3x3_gen_fwd for every other stride-1 layer) and its weight
@@ -453,13 +474,10 @@ class _BnReluConvFn(torch.autograd.Function):
         dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp), ctx.wparam, x, dy, fp)
         if gen:                                                  # wb is the fp32 master weight here
             da = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(wb, 1, dy), wb.shape[1])
+            partial, Sn = kp.bn_bwd_reduce(da, x, None, layout, N, C, HW, fp, True)
         else:
             rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
-            if stride == 2:
-                da = kp.conv3x3_c64_s2_dgrad(dy, rot, (x.shape[2], x.shape[3]))
-            else:
-                da = kp.conv3x3_c64_fwd(dy, rot)
-        partial, Sn = kp.bn_bwd_reduce(da, x, None, layout, N, C, HW, fp, True)
+            da, partial, Sn = _c64_dgrad_and_bn_sums(kp, dy, rot, x, fp, stride, layout, N, C, HW)
         dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
                                              world, x.device)
         dx, _ = kp.bn_bwd_apply(da, x, None, layout, N, C, HW, bp, True, False)
@@ -516,8 +534,7 @@ class _StemBnReluConvFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp), ctx.wparam, xc, dy, fp)
         rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
-        da = kp.conv3x3_c64_s2_dgrad(dy, rot, (xc.shape[2], xc.shape[3])) if stride == 2 else kp.conv3x3_c64_fwd(dy, rot)
-        partial, Sn = kp.bn_bwd_reduce(da, xc, None, layout, N, C, HW, fp, True)
+        da, partial, Sn = _c64_dgrad_and_bn_sums(kp, dy, rot, xc, fp, stride, layout, N, C, HW)
         dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,
                                              world, xc.device)
         dw_stem = wrw_on_side_stream(lambda: kp.stem_conv_wrw_bn(img, da, xc, bp), ctx.wstem, img, da, xc, bp)   # the BN backward apply

@@ -98,6 +98,39 @@ __device__ __forceinline__ uint4 c6_add_bf16x8(uint4 a, uint4 b) {
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- backward sums of the BatchNorm in FRONT of the convolution, in the epilogue of its data gradient (round 6) ----------
+// The data gradient computed here is dy' of a BatchNorm -> ReLU pair (seg_oprs.py:39-46, resnet.py:36-46): SyncBN's backward
+// starts with sum dy' m and sum dy' m (x - mean) per channel, m = (a x + b > 0) (syncbn_kernel.cu:160-174 with the ReLU mask
+// folded in; csrc/bn.hip bn_reduce_* <MODE 1, MASK 2>), a pass that re-reads the tensor this kernel has just written plus
+// x.  Here the thread that stores 16 bytes of the gradient reads the 16 bytes of x beside them and accumulates its eight
+// channels' two sums from the bf16-ROUNDED values it stores — the values the separate pass would read — so only the
+// summation order differs from that pass (fp32 per thread over its pixels, then a fixed-order fold; fp64 across blocks in
+// tsg_bn_bwd_coeffs as before).  abm: LDS copy of the pack's rows a, b, mean ([3][64]).
+struct C6Bsum { float s1[8], s2[8]; };
+__device__ __forceinline__ void c6_bsum_zero(C6Bsum& a) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a.s1[e] = 0.f; a.s2[e] = 0.f; }
+}
+__device__ __forceinline__ void c6_bsum_acc(C6Bsum& acc, uint4 o, uint4 xv, const float* __restrict__ abm, int part8) {
+  const uint32_t ow[4] = {o.x, o.y, o.z, o.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+  const float4 a0 = *reinterpret_cast<const float4*>(abm + part8), a1 = *reinterpret_cast<const float4*>(abm + part8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(abm + C6_C + part8), b1 = *reinterpret_cast<const float4*>(abm + C6_C + part8 + 4);
+  const float4 m0 = *reinterpret_cast<const float4*>(abm + 2 * C6_C + part8), m1 = *reinterpret_cast<const float4*>(abm + 2 * C6_C + part8 + 4);
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float d0 = __uint_as_float(ow[i] << 16), d1 = __uint_as_float(ow[i] & 0xffff0000u);
+    const float x0 = __uint_as_float(xw[i] << 16), x1 = __uint_as_float(xw[i] & 0xffff0000u);
+    const float g0 = fmaf(x0, a[2 * i], b[2 * i]) > 0.f ? d0 : 0.f;            // bn_reduce_nhwc<., ., 1, 2>: the same mask
+    const float g1 = fmaf(x1, a[2 * i + 1], b[2 * i + 1]) > 0.f ? d1 : 0.f;
+    acc.s1[2 * i] += g0;
+    acc.s2[2 * i] = fmaf(g0, x0 - mu[2 * i], acc.s2[2 * i]);
+    acc.s1[2 * i + 1] += g1;
+    acc.s2[2 * i + 1] = fmaf(g1, x1 - mu[2 * i + 1], acc.s2[2 * i + 1]);
+  }
+}
 // 4 waves: wave = (row pair wr) * 2 + (oc half wm)
 template <bool STATS, int OCC, bool AFF>
 __global__ __launch_bounds__(256, OCC) void conv64_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
@@ -261,16 +294,28 @@ constexpr int C6D_PBYTES = C6D_PIECES * 1024;
 constexpr int C6D_OUTS = 2 * C6D_PBYTES;
 constexpr size_t C6D_LDS = (size_t)C6D_OUTS + (size_t)C6_TH * C6_TW * C6_PS * 2;     // 71,680 B
 
-template <bool STATS>
+// BSUM (round 6): the launch is the DATA gradient of a convolution behind BatchNorm -> ReLU (BasicBlock's bn1 -> relu -> conv2,
+// resnet.py:36-46); its epilogue also emits that BatchNorm's backward sums (c6_bsum_* above).  The kernel has no register
+// left (252 of 256 at two blocks per CU), so a thread's 16 sums live only inside one tile's epilogue: they are folded over the
+// eight lanes of the wave that store the same 16-byte part (lanes l, l + 8, ..: three ds_bpermute steps, fixed order) and
+// accumulated into a per-wave LDS row; the four rows are folded at the end.  partial: [grid][2][64].
+template <bool STATS, bool BSUM>
 __global__ __launch_bounds__(256, 2) void conv64_dma_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, C6Geom g, float* __restrict__ partial,
-                                                          const bf16_t* __restrict__ addend) {
+                                                          const bf16_t* __restrict__ addend, const bf16_t* __restrict__ bx,
+                                                          const float* __restrict__ bfp) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char c6d_smem[];
+  __shared__ __attribute__((aligned(16))) float abm[BSUM ? 3 * C6_C : 4];
+  __shared__ __attribute__((aligned(16))) float wred[BSUM ? 4 * 2 * C6_C : 4];
   bf16_t* outs = reinterpret_cast<bf16_t*>(c6d_smem + C6D_OUTS);
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, p = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wr = wave >> 1;
+  if (BSUM) {                                            // visible after the first barrier of the tile loop
+    if (tid < 3 * C6_C) abm[tid] = bfp[tid];
+    wred[tid] = 0.f; wred[256 + tid] = 0.f;
+  }
 
   c6_bf16x8 fw[9][4];                                    // filter fragments: oc = 32 wm + p, ci = 16 kc + 8 half ..
 #pragma unroll
@@ -370,15 +415,35 @@ __global__ __launch_bounds__(256, 2) void conv64_dma_fwd_k(const bf16_t* __restr
           ad[qd] = *reinterpret_cast<const uint4*>(addend + tile_off + ((int64_t)qd * g.W + spl) * C6_C + spart * 8);
       }
     }
+    if (BSUM) {                                          // x beside the four vectors this thread stores: clamped addresses,
+#pragma unroll                                           // unconditional loads (a load in a branch is waited for in that branch)
+      for (int qd = 0; qd < C6_TH; ++qd) {
+        const bool ok = tp.oh0 + qd < g.H && colok;
+        ad[qd] = *reinterpret_cast<const uint4*>(bx + (ok ? tile_off + ((int64_t)qd * g.W + spl) * C6_C + spart * 8 : 0));
+      }
+    }
     __syncthreads();
+    C6Bsum bs;
+    if (BSUM) c6_bsum_zero(bs);
 #pragma unroll
     for (int qd = 0; qd < C6_TH; ++qd)
       if (tp.oh0 + qd < g.H && colok) {
         uint4 o = *reinterpret_cast<const uint4*>(outs + (qd * C6_TW + spl) * C6_PS + spart * 8);
         const int64_t off = ((int64_t)qd * g.W + spl) * C6_C + spart * 8;
-        if (addend) o = c6_add_bf16x8(o, ad[qd]);
+        if (addend && !BSUM) o = c6_add_bf16x8(o, ad[qd]);
         *reinterpret_cast<uint4*>(yt + off) = o;
+        if (BSUM) c6_bsum_acc(bs, o, ad[qd], abm, spart * 8);
       }
+    if (BSUM) {
+      float* mine = wred + wave * 2 * C6_C + spart * 8;  // lanes 0-7 of the wave own [2][8 parts x 8 channels]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s1 = bs.s1[e], s2 = bs.s2[e];
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        if (lane < 8) { mine[e] += s1; mine[C6_C + e] += s2; }
+      }
+    }
     if (STATS) {
       const int c = tid & 63, qd = tid >> 6;
       if (tp.oh0 + qd < g.H) {
@@ -403,6 +468,13 @@ __global__ __launch_bounds__(256, 2) void conv64_dma_fwd_k(const bf16_t* __restr
       const int c = tid & 63, which = tid >> 6;
       const float* r = red + which * 256 + c;
       partial[((int64_t)blockIdx.x * 2 + which) * C6_C + c] = (r[0] + r[64]) + (r[128] + r[192]);
+    }
+  }
+  if (BSUM) {                                            // fold the four waves' rows in a fixed order
+    __syncthreads();
+    if (tid < 128) {
+      const float* r = wred + tid;                       // tid = which * 64 + c
+      partial[(int64_t)blockIdx.x * 2 * C6_C + tid] = (r[0] + r[128]) + (r[256] + r[384]);
     }
   }
 }
@@ -593,13 +665,24 @@ constexpr int D2_NV = D2_PH * D2_PW * 8;                         // 792
 constexpr int D2_NF = (D2_NV + 255) / 256;                       // 4
 constexpr int D2_OW = 2 * D2_TW;                                 // 64 dx columns per tile
 
-template <int OCC>
+template <int OCC, bool BSUM>
 __global__ __launch_bounds__(256, OCC) void conv64_dgrad_s2_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wt,
-                                                            bf16_t* __restrict__ dx, S2Geom g) {
+                                                            bf16_t* __restrict__ dx, S2Geom g,
+                                                            const bf16_t* __restrict__ bx, const float* __restrict__ bfp,
+                                                            float* __restrict__ bpart) {
   __shared__ __attribute__((aligned(16))) bf16_t patch[D2_PH * D2_PW * C6_PS];             // 14256 B
   __shared__ __attribute__((aligned(16))) bf16_t outs[2 * D2_TH * D2_OW * C6_PS];          // 36864 B: 4 x 64 dx pixels
+  __shared__ __attribute__((aligned(16))) float abm[BSUM ? 3 * C6_C : 4];
+  // BSUM: a thread's 16 sums live inside one tile's epilogue only (144 filter registers + two blocks per CU leave no room to
+  // carry them across the MFMA phase): folded over the eight lanes that store the same 16-byte part and accumulated into a
+  // per-wave LDS row, as in conv64_dma_fwd_k<., true>
+  __shared__ __attribute__((aligned(16))) float wred[BSUM ? 4 * 2 * C6_C : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int wm = wave & 1, wr = wave >> 1;
+  if (BSUM) {                                             // visible after the first barrier of the tile loop
+    if (tid < 3 * C6_C) abm[tid] = bfp[tid];
+    wred[tid] = 0.f; wred[256 + tid] = 0.f;
+  }
   // transposed filter: wt[ci][kh'][kw'][co] = w[co][2 - kh'][2 - kw'][ci]; fragment of forward tap (kh, kw): rows ci, K = co
   c6_bf16x8 fw[9][4];
 #pragma unroll
@@ -668,16 +751,68 @@ __global__ __launch_bounds__(256, OCC) void conv64_dgrad_s2_k(const bf16_t* __re
         *reinterpret_cast<uint2*>(outs + ((2 * wr + a) * D2_OW + 2 * p + b) * C6_PS + c0) = v;
       }
     }
-    __syncthreads();
-    bf16_t* xt = dx + (((int64_t)tp.b * g.H + 2 * tp.oh0) * g.W + 2 * tp.ow0) * C6_C;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    const int64_t tile_off = (((int64_t)tp.b * g.H + 2 * tp.oh0) * g.W + 2 * tp.ow0) * C6_C;
+    // BSUM: the eight vectors of x beside the eight this thread stores, requested before the barrier (their latency overlaps
+    // the staging; the accumulators' registers are free by now)
+    uint4 xq[BSUM ? 4 : 1];
+    auto xload = [&](int k) {
       const int v = tid + 256 * k, qd = v >> 9, spl = (v >> 3) & 63, spart = v & 7;
-      if (2 * tp.oh0 + qd < g.H && 2 * tp.ow0 + spl < g.W)
-        *reinterpret_cast<uint4*>(xt + ((int64_t)qd * g.W + spl) * C6_C + spart * 8) =
-            *reinterpret_cast<const uint4*>(outs + (qd * D2_OW + spl) * C6_PS + spart * 8);
+      const bool ok = 2 * tp.oh0 + qd < g.H && 2 * tp.ow0 + spl < g.W;
+      const int64_t off = ok ? tile_off + ((int64_t)qd * g.W + spl) * C6_C + spart * 8 : 0;       // clamped: unconditional load
+      return *reinterpret_cast<const uint4*>(bx + off);
+    };
+    if (BSUM) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xq[BSUM ? k : 0] = xload(k);
+    }
+    __syncthreads();
+    bf16_t* xt = dx + tile_off;
+    C6Bsum bs;
+    if (BSUM) c6_bsum_zero(bs);
+    if (!BSUM) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int v = tid + 256 * k, qd = v >> 9, spl = (v >> 3) & 63, spart = v & 7;
+        if (2 * tp.oh0 + qd < g.H && 2 * tp.ow0 + spl < g.W)
+          *reinterpret_cast<uint4*>(xt + ((int64_t)qd * g.W + spl) * C6_C + spart * 8) =
+              *reinterpret_cast<const uint4*>(outs + (qd * D2_OW + spl) * C6_PS + spart * 8);
+      }
+    } else {
+      // two rounds of four vectors (tile rows 0-1, then 2-3); a consumed x register is refilled with the vector of the
+      // second round at once, so that only four are ever live next to the 144 registers of the filter
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int v = tid + 256 * k, qd = v >> 9, spl = (v >> 3) & 63, spart = v & 7;
+        if (2 * tp.oh0 + qd < g.H && 2 * tp.ow0 + spl < g.W) {
+          const uint4 o = *reinterpret_cast<const uint4*>(outs + (qd * D2_OW + spl) * C6_PS + spart * 8);
+          *reinterpret_cast<uint4*>(xt + ((int64_t)qd * g.W + spl) * C6_C + spart * 8) = o;
+          c6_bsum_acc(bs, o, xq[k & 3], abm, spart * 8);
+        }
+        if (k < 4) {
+          xq[k] = xload(4 + k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (BSUM) {
+      float* mine = wred + wave * 2 * C6_C + (tid & 7) * 8;  // lanes 0-7 of the wave own [2][8 parts x 8 channels]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s1 = bs.s1[e], s2 = bs.s2[e];
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        if (lane < 8) { mine[e] += s1; mine[C6_C + e] += s2; }
+      }
     }
     tp = tn;
+  }
+  if (BSUM) {                                              // fold the four waves' rows in a fixed order
+    __syncthreads();
+    if (tid < 128) {
+      const float* r = wred + tid;                         // tid = which * 64 + c
+      bpart[(int64_t)blockIdx.x * 2 * C6_C + tid] = (r[0] + r[128]) + (r[256] + r[384]);
+    }
   }
 }
 
@@ -746,15 +881,15 @@ int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, c
   static const bool use_dma = [] { const char* e = getenv("TSG_CONV64_DMA"); return !(e && e[0] == '0'); }();
   if (!in_ab && use_dma && occ == 2 && (int64_t)g.H * g.W * C6_C * 2 < 0x7fffffffLL) {
     if (partial) {
-      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<true>),
+      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C6D_LDS));
-      hipLaunchKernelGGL((conv64_dma_fwd_k<true>), dim3(grid), dim3(256), C6D_LDS, st, (const bf16_t*)x, (const bf16_t*)w,
-                         (bf16_t*)y, g, partial, (const bf16_t*)addend);
+      hipLaunchKernelGGL((conv64_dma_fwd_k<true, false>), dim3(grid), dim3(256), C6D_LDS, st, (const bf16_t*)x, (const bf16_t*)w,
+                         (bf16_t*)y, g, partial, (const bf16_t*)addend, (const bf16_t*)nullptr, (const float*)nullptr);
     } else {
-      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<false>),
+      TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C6D_LDS));
-      hipLaunchKernelGGL((conv64_dma_fwd_k<false>), dim3(grid), dim3(256), C6D_LDS, st, (const bf16_t*)x, (const bf16_t*)w,
-                         (bf16_t*)y, g, partial, (const bf16_t*)addend);
+      hipLaunchKernelGGL((conv64_dma_fwd_k<false, false>), dim3(grid), dim3(256), C6D_LDS, st, (const bf16_t*)x, (const bf16_t*)w,
+                         (bf16_t*)y, g, partial, (const bf16_t*)addend, (const bf16_t*)nullptr, (const float*)nullptr);
     }
     TSG_CHECK_LAUNCH();
     return 0;
@@ -763,6 +898,33 @@ int tsg_conv3x3_c64_fwd(const void* x, const void* w, void* y, float* partial, c
   else if (partial) { if (occ == 1) C6_GO(true, 1, false); else C6_GO(true, 2, false); }
   else { if (occ == 1) C6_GO(false, 1, false); else C6_GO(false, 2, false); }
 #undef C6_GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+// Data gradient of a 64 -> 64 / stride-1 convolution (dy, wt = tsg_conv3x3_weight_rot180_t(w)) that ALSO emits the backward
+// sums of the BatchNorm -> ReLU in front of the convolution (bn_x: that BatchNorm's input, bn_fp: its forward pack
+// [3][64] = a, b, mean): partial [tsg_conv3x3_c64_dgrad_bnsums_partials][2][64] = {sum dy' m, sum dy' m (x - mean)},
+// what tsg_bn_bwd_reduce(relu = 1, y = NULL) computes from the stored gradient in a pass of its own.
+int tsg_conv3x3_c64_dgrad_bnsums_partials(int64_t B, int64_t H, int64_t W) {
+  C6Geom g;
+  if (!c6_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  if (c6_occ() != 2 || (int64_t)g.H * g.W * C6_C * 2 >= 0x7fffffffLL) return 0;       // the LDS-DMA kernel only
+  return g.ntiles < 512 ? g.ntiles : 512;
+}
+
+int tsg_conv3x3_c64_dgrad_bnsums(const void* dy, const void* wt, void* dx, const void* bn_x, const float* bn_fp,
+                                 float* partial, int64_t B, int64_t H, int64_t W, void* stream) {
+  if (!dy || !wt || !dx || !bn_x || !bn_fp || !partial) return TSG_E_NULL;
+  C6Geom g;
+  if (!c6_geom(B, H, W, &g)) return TSG_E_SHAPE;
+  if (c6_occ() != 2 || (int64_t)g.H * g.W * C6_C * 2 >= 0x7fffffffLL) return TSG_E_SHAPE;
+  if (!aligned16(dy) || !aligned16(wt) || !aligned16(dx) || !aligned16(bn_x) || !aligned16(bn_fp)) return TSG_E_ALIGN;
+  const int grid = g.ntiles < 512 ? g.ntiles : 512;
+  TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_dma_fwd_k<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C6D_LDS));
+  hipLaunchKernelGGL((conv64_dma_fwd_k<false, true>), dim3(grid), dim3(256), C6D_LDS, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)wt, (bf16_t*)dx, g, partial, (const bf16_t*)nullptr, (const bf16_t*)bn_x, bn_fp);
   TSG_CHECK_LAUNCH();
   return 0;
 }
@@ -793,20 +955,39 @@ int tsg_conv3x3_c64_s2_fwd(const void* x, const void* w, void* y, float* partial
   return 0;
 }
 
-int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B, int64_t H, int64_t W, void* stream) {
+static int c6_s2_dgrad_common(const void* dy, const void* wt, void* dx, const void* bn_x, const float* bn_fp, float* partial,
+                              int64_t B, int64_t H, int64_t W, void* stream) {
   if (!dy || !wt || !dx) return TSG_E_NULL;
   S2Geom g;
   if (!s2_geom(B, H, W, D2_TH, D2_TW, &g)) return TSG_E_SHAPE;
   if (!aligned16(dy) || !aligned16(wt) || !aligned16(dx)) return TSG_E_ALIGN;
+  if (partial && (!aligned16(bn_x) || !aligned16(bn_fp))) return TSG_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int occ = c6_occ();
   const int grid = g.ntiles < 256 * occ ? g.ntiles : 256 * occ;
-  if (occ == 1)
-    hipLaunchKernelGGL(conv64_dgrad_s2_k<1>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, g);
-  else
-    hipLaunchKernelGGL(conv64_dgrad_s2_k<2>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, g);
+#define C6_GO(OC, BS) hipLaunchKernelGGL((conv64_dgrad_s2_k<OC, BS>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,  \
+                                         (const bf16_t*)wt, (bf16_t*)dx, g, (const bf16_t*)bn_x, bn_fp, partial)
+  if (partial) { if (occ == 1) C6_GO(1, true); else C6_GO(2, true); }
+  else { if (occ == 1) C6_GO(1, false); else C6_GO(2, false); }
+#undef C6_GO
   TSG_CHECK_LAUNCH();
   return 0;
+}
+
+int tsg_conv3x3_c64_s2_dgrad(const void* dy, const void* wt, void* dx, int64_t B, int64_t H, int64_t W, void* stream) {
+  return c6_s2_dgrad_common(dy, wt, dx, nullptr, nullptr, nullptr, B, H, W, stream);
+}
+
+int tsg_conv3x3_c64_s2_dgrad_partials(int64_t B, int64_t H, int64_t W) {
+  S2Geom g;
+  if (!s2_geom(B, H, W, D2_TH, D2_TW, &g)) return TSG_E_SHAPE;
+  return g.ntiles < 256 * c6_occ() ? g.ntiles : 256 * c6_occ();
+}
+
+int tsg_conv3x3_c64_s2_dgrad_bnsums(const void* dy, const void* wt, void* dx, const void* bn_x, const float* bn_fp,
+                                    float* partial, int64_t B, int64_t H, int64_t W, void* stream) {
+  if (!bn_x || !bn_fp || !partial) return TSG_E_NULL;
+  return c6_s2_dgrad_common(dy, wt, dx, bn_x, bn_fp, partial, B, H, W, stream);
 }
 
 }  // extern "C"

@@ -729,10 +729,45 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_c64_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                        weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1, in_ab=None, addend=None):
+    def conv3x3_c64_bnsums_supported(self, B, H, W, stride):
+        """can the 64 -> 64 data gradient of this input size emit the BatchNorm backward sums in its epilogue (`bsum=`)?"""
+        fn = self.lib.tsg_conv3x3_c64_dgrad_bnsums_partials if stride == 1 else self.lib.tsg_conv3x3_c64_s2_dgrad_partials
+        key = ("c64_bsum", stride, B, H, W)
+        v = self._npart.get(key)
+        if v is None:
+            v = self._npart[key] = fn(B, H, W)
+        return v > 0
+
+    @staticmethod
+    def _check_bsum(bsum, like_shape):
+        bx, fp = bsum
+        if (tuple(bx.shape) != tuple(like_shape) or bx.dtype != torch.bfloat16
+                or not bx.is_contiguous(memory_format=torch.channels_last)
+                or fp.dtype != torch.float32 or not fp.is_contiguous() or fp.dim() != 2 or fp.shape[0] < 3
+                or fp.shape[1] != like_shape[1]):
+            raise ValueError("bsum = (x of the BatchNorm: bf16 channels_last, the gradient's shape; its forward pack fp32 [>=3, C])")
+        return bx, fp
+
+    def conv3x3_c64_fwd(self, x, wb, with_stats=False, stride=1, in_ab=None, addend=None, bsum=None):
         """x [B,64,H,W] bf16 channels_last, wb bf16 [64,64,3,3] channels_last, 3x3 / stride 1 or 2 / padding 1
         -> y (channels_last) or (y, partial [S,2,64]).  in_ab: fp32 [>=2, 64] whose rows 0 / 1 are the a / b of a BN forward
-        pack: the convolution reads relu(a x + b) (normalise-on-load)."""
+        pack: the convolution reads relu(a x + b) (normalise-on-load).
+        bsum = (bn_x, fp) (stride 1, the launch being a DATA gradient: x = dy, wb = the rotated filter): the backward sums
+        of the BatchNorm -> ReLU in front of the convolution in the epilogue -> (dx, partial [S,2,64]) with the layout of
+        bn_bwd_reduce's partial."""
+        if bsum is not None:
+            if stride != 1 or with_stats or in_ab is not None or addend is not None:
+                raise ValueError("conv3x3_c64_fwd: bsum goes with the plain stride-1 launch only")
+            bx, fp = self._check_bsum(bsum, x.shape)
+            B, _, H, W = x.shape
+            S = self._count(("c64_bsum", 1, B, H, W), lambda: self.lib.tsg_conv3x3_c64_dgrad_bnsums_partials(B, H, W),
+                            "tsg_conv3x3_c64_dgrad_bnsums_partials")
+            y = torch.empty_like(x)
+            partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
+            L.check(self.lib.tsg_conv3x3_c64_dgrad_bnsums(x.data_ptr(), wb.data_ptr(), y.data_ptr(), bx.data_ptr(),
+                                                          fp.data_ptr(), partial.data_ptr(), B, H, W, L.stream_ptr(x)),
+                    "tsg_conv3x3_c64_dgrad_bnsums")
+            return y, partial
         if in_ab is not None and (in_ab.dtype != torch.float32 or not in_ab.is_contiguous() or in_ab.shape[-1] != 64):
             raise ValueError("conv3x3_c64_fwd: in_ab must be a contiguous fp32 [>=2, 64] pack")
         if not x.is_contiguous(memory_format=torch.channels_last) or not wb.is_contiguous(memory_format=torch.channels_last):
@@ -853,8 +888,9 @@ class HipKernels:
                                               L.stream_ptr(dy)), "tsg_conv3x3_s2_dgrad")
         return dx
 
-    def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw):
-        """dy [B,64,OH,OW] bf16 channels_last, wt = conv3x3_weight_rot180_t(w) -> dx [B,64,H,W] of the stride-2 convolution"""
+    def conv3x3_c64_s2_dgrad(self, dy, wt, in_hw, bsum=None):
+        """dy [B,64,OH,OW] bf16 channels_last, wt = conv3x3_weight_rot180_t(w) -> dx [B,64,H,W] of the stride-2 convolution.
+        bsum = (bn_x, fp): also the backward sums of the BatchNorm -> ReLU in front of the convolution -> (dx, partial [S,2,64])"""
         if not dy.is_contiguous(memory_format=torch.channels_last) or not wt.is_contiguous(memory_format=torch.channels_last):
             raise ValueError("conv3x3_c64_s2_dgrad expects channels_last operands")
         B = dy.shape[0]
@@ -862,6 +898,15 @@ class HipKernels:
         if (H - 1) // 2 + 1 != dy.shape[2] or (W - 1) // 2 + 1 != dy.shape[3]:
             raise ValueError("conv3x3_c64_s2_dgrad: dy does not belong to an input of that size")
         dx = torch.empty((B, 64, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        if bsum is not None:
+            bx, fp = self._check_bsum(bsum, dx.shape)
+            S = self._count(("c64_bsum", 2, B, H, W), lambda: self.lib.tsg_conv3x3_c64_s2_dgrad_partials(B, H, W),
+                            "tsg_conv3x3_c64_s2_dgrad_partials")
+            partial = torch.empty((S, 2, 64), dtype=torch.float32, device=dy.device)
+            L.check(self.lib.tsg_conv3x3_c64_s2_dgrad_bnsums(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), bx.data_ptr(),
+                                                             fp.data_ptr(), partial.data_ptr(), B, H, W, L.stream_ptr(dy)),
+                    "tsg_conv3x3_c64_s2_dgrad_bnsums")
+            return dx, partial
         L.check(self.lib.tsg_conv3x3_c64_s2_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), B, H, W, L.stream_ptr(dy)),
                 "tsg_conv3x3_c64_s2_dgrad")
         return dx
@@ -1080,6 +1125,12 @@ def _nbytes(t):
     return 0 if t is None else t.numel() * t.element_size()
 
 
+def _bsum_bytes(kw):
+    """the BatchNorm input a data gradient reads for the backward sums of its epilogue (bsum=(bn_x, fp))"""
+    b = (kw or {}).get("bsum")
+    return _nbytes(b[0]) if b is not None else 0
+
+
 # algorithmic bytes per launch (each operand read once + each result written once, the
 # convention of the reference's own tools/benchmark/compute_memory.py:49-72); DESIGN.md §4
 _ALGO_BYTES = {
@@ -1112,9 +1163,9 @@ _ALGO_BYTES = {
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "stem_conv_wrw_bn": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[2]),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
-    "conv3x3_c64_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "conv3x3_c64_fwd": lambda a, r, kw=None: _nbytes(a[0]) + _nbytes(r) + _bsum_bytes(kw),
     "conv3x3_gen_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1][0]) + _nbytes(r[0] if isinstance(r, tuple) else r),
-    "conv3x3_c64_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
+    "conv3x3_c64_s2_dgrad": lambda a, r, kw=None: _nbytes(a[0]) + _nbytes(r) + _bsum_bytes(kw),
     "conv3x3_s2_dgrad": lambda a, r: _nbytes(a[0]) + _nbytes(r),
     "gap_bwd": lambda a, r: _nbytes(r),
 }
@@ -1196,7 +1247,8 @@ class KernelTimer:
             out = fn(*args, **kw)
             e.record()
             res = out if name in ("maxpool_fwd", "bn_relu_pool_fwd") else (out[0] if isinstance(out, tuple) else out)
-            rec.append((s, e, cost(args, res), flops(args, res) if flops else 0))
+            by = cost(args, res, kw) if cost.__code__.co_argcount == 3 else cost(args, res)
+            rec.append((s, e, by, flops(args, res) if flops else 0))
             return out
 
         setattr(self.prov, name, timed)
