@@ -139,6 +139,21 @@ int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y,
                      int dtype, int layout, int64_t N, int64_t C, int64_t HW,
                      const float* bwd_pack, int relu, void* stream);
 
+/* The block tail BN -> (+identity) -> ReLU (resnet.py:44-51, 92-99) with its ReLU mask kept as ONE BIT per element
+ * (round 6).  The two backward kernels of such a layer need "y > 0"; reading it from the stored output costs a whole
+ * tensor per kernel.  tsg_bn_apply_fwd_maskbits is tsg_bn_apply_fwd(relu = 1) that also writes bits[(pixel * C + c) / V],
+ * bit j = (y[pixel][c + j] > 0) of the ROUNDED output, V = 8 channels per byte for bf16 and 4 for fp32 (NHWC only, C % V
+ * == 0, 16-byte aligned tensors: tsg_bn_maskbits_supported; N * HW * C / V bytes); the _maskbits backward entry points are
+ * tsg_bn_bwd_reduce / tsg_bn_bwd_apply(relu = 1, y) reading that byte instead of y: same values, 2 of the 8 tensor passes
+ * of the layer's backward gone.  residual may be NULL. */
+int tsg_bn_maskbits_supported(int dtype, int layout, int64_t C, int64_t HW);
+int tsg_bn_apply_fwd_maskbits(const void* x, const void* residual, void* y, void* bits, int dtype, int layout, int64_t N,
+                              int64_t C, int64_t HW, const float* fwd_pack, void* stream);
+int tsg_bn_bwd_reduce_maskbits(const void* dy, const void* x, const void* bits, int dtype, int layout, int64_t N, int64_t C,
+                               int64_t HW, const float* fwd_pack, float* partial, int* rows, void* stream);
+int tsg_bn_bwd_apply_maskbits(const void* dy, const void* x, const void* bits, void* dx, void* dres, int dtype, int layout,
+                              int64_t N, int64_t C, int64_t HW, const float* bwd_pack, void* stream);
+
 /* Mixed-layout passes for conv stems: x (conv output) / dx are NCHW [N, C, HW]
  * while y / dy are NHWC [N*HW, C]; a [C x 64-pixel] tile is transposed through
  * LDS inside the BN pass, so no separate layout-conversion copy is needed

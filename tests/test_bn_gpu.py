@@ -138,3 +138,66 @@ def test_bn_mixed_layout_stem(cuda, shape, dtype, relu):
     n = N * H * W
     torch.testing.assert_close(dg1, dg0, rtol=1e-4, atol=1e-4 * n ** 0.5)
     torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-4 * n ** 0.5)
+
+
+# ---- round 6: the block tail's ReLU mask as one bit per element ------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 33, 47), (4, 128, 16, 16), (16, 128, 1, 1), (2, 64, 96, 128), (1, 8, 300, 300),
+                                   (3, 24, 8, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_block_tail_with_bit_mask_equals_the_stored_output_mask(cuda, shape, dtype, monkeypatch):
+    """relu(bn(x) + identity) through tsg_bn_apply_fwd_maskbits / tsg_bn_bwd_*_maskbits: the output, the mask bits
+    (= y > 0 of the ROUNDED output), both input gradients and the parameter gradients are BIT-equal to the path that reads the
+    mask from the stored output (same arithmetic in the same order; only where the mask comes from differs).  Shapes whose
+    channel count is not a multiple of the bits' group (24 for bf16: 8 per byte fits; 19 would not) fall back silently."""
+    from torchseg_amd import kernels as K, syncbn
+    from torchseg_amd.syncbn import SyncBatchNorm
+    kp = K.provider()
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.4).to(dtype)
+    r = torch.randn(shape, generator=g).to(dtype)
+    dy = torch.randn(shape, generator=g).to(dtype)
+    cl = dict(memory_format=torch.channels_last)
+
+    def run(bits):
+        monkeypatch.setattr(syncbn, "_MASKBITS", bits)
+        bn = SyncBatchNorm(C).to(cuda)
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(C, generator=torch.Generator().manual_seed(1)) * 0.5 + 1.0)
+            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.5)
+        xd = x.to(cuda).contiguous(**cl).requires_grad_(True)
+        rd = r.to(cuda).contiguous(**cl).requires_grad_(True)
+        cnt = K.CallCounter(kp)
+        try:
+            y = bn(xd, residual=rd, relu=True)
+            y.backward(dy.to(cuda).contiguous(**cl))
+        finally:
+            counts = cnt.stop()
+        torch.cuda.synchronize()
+        return y.detach(), xd.grad, rd.grad, bn.weight.grad, bn.bias.grad, bn.running_var.clone(), counts
+
+    ref = run(False)
+    got = run(True)
+    layout, _, _, HW = K.bn_layout(x.to(cuda).contiguous(**cl))
+    if kp.bn_maskbits_supported(x.to(cuda).contiguous(**cl), layout, C, HW):
+        assert got[6].get("bn_apply_fwd_bits") == 1 and got[6].get("bn_bwd_reduce_bits") == 1 \
+            and got[6].get("bn_bwd_apply_bits") == 1 and "bn_bwd_reduce" not in got[6], got[6]
+    assert "bn_apply_fwd_bits" not in ref[6]
+    for name, a, b in zip(("y", "dx", "dres", "dgamma", "dbeta", "running_var"), got[:6], ref[:6]):
+        assert torch.equal(a, b), name
+
+
+def test_mask_bits_are_the_sign_of_the_rounded_output(cuda):
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(2, 64, 24, 40, generator=g) * 1e-3).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    r = (torch.randn(2, 64, 24, 40, generator=g) * 1e-3).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    fp = torch.stack([torch.rand(64, generator=g) - 0.5, torch.randn(64, generator=g) * 1e-3, torch.zeros(64)]).to(cuda).contiguous()
+    layout, N, C, HW = K.bn_layout(x)
+    y, bits = kp.bn_apply_fwd_bits(x, r, layout, N, C, HW, fp)
+    assert torch.equal(y, kp.bn_apply_fwd(x, r, layout, N, C, HW, fp, True))
+    want = (y.permute(0, 2, 3, 1).reshape(-1, 8) > 0).to(torch.uint8)          # NHWC order, 8 channels per byte, bit j = channel j
+    packed = (want << torch.arange(8, device=cuda, dtype=torch.uint8)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, packed)
+    assert 0.2 < want.float().mean().item() < 0.8

@@ -47,6 +47,10 @@ _PROTOS = {
     "tsg_bn_bwd_reduce": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p, _ip, _p]),
     "tsg_bn_bwd_coeffs": (_i, [_p, _i, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p]),
     "tsg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _i, _p]),
+    "tsg_bn_maskbits_supported": (_i, [_i, _i, _i64, _i64]),
+    "tsg_bn_apply_fwd_maskbits": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p]),
+    "tsg_bn_bwd_reduce_maskbits": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p, _p, _p]),
+    "tsg_bn_bwd_apply_maskbits": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _p]),
     "tsg_bn_mixed_supported": (_i, [_i, _i64, _i64]),
     "tsg_bn_mixed_num_partials": (_i, [_i64, _i64, _i64]),
     "tsg_bn_apply_fwd_mixed": (_i, [_p, _p, _i, _i64, _i64, _i64, _p, _i, _p]),

@@ -156,7 +156,10 @@ __device__ __forceinline__ void put_partial(float* partial, int64_t C, int S, in
 // =========================================================================
 // reductions (stats and bwd_reduce share one skeleton)
 //   MODE 0: (x)          -> sum x, sum x^2
-//   MODE 1: (dy, x)      -> sum dy', sum dy' * (x - mean)   (MASK: 0 none, 1 y>0, 2 recompute)
+//   MODE 1: (dy, x)      -> sum dy', sum dy' * (x - mean)   (MASK: 0 none, 1 y>0, 2 recompute, 3 bit mask: NHWC only —
+//                           `y` then points at one byte per V channels of a pixel, bit j = (y[.. + j] > 0), written by
+//                           bn_fwd_nhwc<., ., true, true, true>: the block tail BN -> (+identity) -> ReLU (resnet.py:44-51)
+//                           reads 1/16 of a tensor for its ReLU mask instead of the whole output)
 // fp[0]=a, fp[1]=b, fp[2]=mean
 // =========================================================================
 template <typename T, int V, int MODE, int MASK>
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
     // own, and a load in a branch is waited for at the end of that branch: one load in flight per wave, s_waitcnt vmcnt(0)
     // after each (profiles/r05_bn_isa.txt).  Rows are accumulated in the same order as before: bit-identical sums.
     typedef typename Pack<T, V>::Raw Raw;
-    auto accumulate = [&](const Raw& rx, const Raw& rd, const Raw& ry) {
+    auto accumulate = [&](const Raw& rx, const Raw& rd, const Raw& ry, unsigned int mb) {
       Pack<T, V> px;
       px.unpack(rx);
       if (MODE == 0) {
@@ -269,6 +272,9 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
         } else if (MASK == 2) {
 #pragma unroll
           for (int j = 0; j < V; ++j) pd.v[j] = fmaf(px.v[j], ca[j], cb[j]) > 0.f ? pd.v[j] : 0.f;
+        } else if (MASK == 3) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) pd.v[j] = ((mb >> j) & 1u) ? pd.v[j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -277,25 +283,28 @@ __global__ __launch_bounds__(kThreads) void bn_reduce_nhwc(
         }
       }
     };
+    const unsigned char* bits = reinterpret_cast<const unsigned char*>(y);
     int64_t row = row0 + r;
     for (; row + (int64_t)(kUnroll - 1) * R < row1; row += (int64_t)kUnroll * R) {
       Raw rx[kUnroll], rd[kUnroll], ry[kUnroll];
+      unsigned int rb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {                 // every load of the group first ...
         const int64_t off = (row + (int64_t)k * R) * C + c0;
         rx[k] = Pack<T, V>::ldraw(x + off);
         if (MODE == 1) rd[k] = Pack<T, V>::ldraw(dy + off);
         if (MODE == 1 && MASK == 1) ry[k] = Pack<T, V>::ldraw(y + off);
+        rb[k] = (MODE == 1 && MASK == 3) ? bits[off / V] : 0u;
       }
 #pragma unroll
-      for (int k = 0; k < kUnroll; ++k) accumulate(rx[k], rd[k], ry[k]);   // ... then the arithmetic, in row order
+      for (int k = 0; k < kUnroll; ++k) accumulate(rx[k], rd[k], ry[k], rb[k]);   // ... then the arithmetic, in row order
     }
     for (; row < row1; row += R) {
       const int64_t off = row * C + c0;
       Raw rx = Pack<T, V>::ldraw(x + off), rd = rx, ry = rx;
       if (MODE == 1) rd = Pack<T, V>::ldraw(dy + off);
       if (MODE == 1 && MASK == 1) ry = Pack<T, V>::ldraw(y + off);
-      accumulate(rx, rd, ry);
+      accumulate(rx, rd, ry, (MODE == 1 && MASK == 3) ? bits[off / V] : 0u);
     }
   }
   // cross-row reduction through LDS, fixed order
@@ -362,10 +371,11 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw(
   }
 }
 
-template <typename T, int V, bool RELU, bool RES>
+template <typename T, int V, bool RELU, bool RES, bool BITS = false>
 __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
     const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ fp, int rev) {
+    int64_t M, int64_t C, int GT, int R, int64_t rows_per_block, const float* __restrict__ fp, int rev,
+    unsigned char* __restrict__ bits = nullptr) {
   const int tid = threadIdx.x;
   const int gl = tid % GT, r = tid / GT;
   const int64_t g = (int64_t)blockIdx.y * GT + gl;
@@ -392,6 +402,15 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nhwc(
       px.v[j] = t;
     }
     px.store(y + off);
+    if (BITS) {                                         // from the ROUNDED value that was stored: what `y > 0` reads back
+      unsigned int mb = 0u;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float q = sizeof(T) == 2 ? __uint_as_float((uint32_t)f32_to_bf16(px.v[j]) << 16) : px.v[j];
+        mb |= (q > 0.f ? 1u : 0u) << j;
+      }
+      bits[off / V] = (unsigned char)mb;
+    }
   };
   int64_t row = row0 + r;
   for (; row + (int64_t)(kUnroll - 1) * R < row1; row += (int64_t)kUnroll * R) {
@@ -473,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
   int64_t row1 = row0 + rows_per_block;
   if (row1 > M) row1 = M;
   typedef typename Pack<T, V>::Raw Raw;                   // see bn_reduce_nhwc: a group's loads first, then arithmetic + stores
-  auto finish = [&](const Raw& rd, const Raw& rx, const Raw& ry, int64_t off) {
+  auto finish = [&](const Raw& rd, const Raw& rx, const Raw& ry, unsigned int mb, int64_t off) {
     Pack<T, V> pd, px;
     pd.unpack(rd);
     px.unpack(rx);
@@ -485,30 +504,36 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nhwc(
     } else if (MASK == 2) {
 #pragma unroll
       for (int j = 0; j < V; ++j) pd.v[j] = fmaf(px.v[j], a[j], b[j]) > 0.f ? pd.v[j] : 0.f;
+    } else if (MASK == 3) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) pd.v[j] = ((mb >> j) & 1u) ? pd.v[j] : 0.f;
     }
     if (DRES) pd.store(dres + off);
 #pragma unroll
     for (int j = 0; j < V; ++j) px.v[j] = fmaf(a[j], pd.v[j], fmaf(bc[j], px.v[j] - mu[j], c2[j]));
     px.store(dx + off);
   };
+  const unsigned char* bits = reinterpret_cast<const unsigned char*>(y);
   int64_t row = row0 + r;
   for (; row + (int64_t)(kUnroll - 1) * R < row1; row += (int64_t)kUnroll * R) {
     Raw rd[kUnroll], rx[kUnroll], ry[kUnroll];
+    unsigned int rb[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
       const int64_t off = (row + (int64_t)k * R) * C + c0;
       rd[k] = Pack<T, V>::ldraw(dy + off);
       rx[k] = Pack<T, V>::ldraw(x + off);
       if (MASK == 1) ry[k] = Pack<T, V>::ldraw(y + off);
+      rb[k] = MASK == 3 ? bits[off / V] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) finish(rd[k], rx[k], ry[k], (row + (int64_t)k * R) * C + c0);
+    for (int k = 0; k < kUnroll; ++k) finish(rd[k], rx[k], ry[k], rb[k], (row + (int64_t)k * R) * C + c0);
   }
   for (; row < row1; row += R) {
     const int64_t off = row * C + c0;
     Raw rd = Pack<T, V>::ldraw(dy + off), rx = Pack<T, V>::ldraw(x + off), ry = rx;
     if (MASK == 1) ry = Pack<T, V>::ldraw(y + off);
-    finish(rd, rx, ry, off);
+    finish(rd, rx, ry, MASK == 3 ? bits[off / V] : 0u, off);
   }
 }
 
@@ -859,6 +884,51 @@ static int launch_fwd(const T* x, const T* res, T* y, int layout, int64_t N, int
   return 0;
 }
 
+// the bit-mask forms (NHWC, V = 8 bf16 / 4 fp32 channels per byte): forward of BN -> (+identity) -> ReLU that also writes
+// the mask, and the two backward kernels that read it instead of y
+template <typename T, int V>
+static int launch_fwd_bits(const T* x, const T* res, T* y, unsigned char* bits, int64_t N, int64_t C, int64_t HW,
+                           const float* fp, hipStream_t st) {
+  const int64_t M = N * HW;
+  NhwcGeom g = nhwc_geom(M, C, V);
+  dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
+  if (res)
+    hipLaunchKernelGGL((bn_fwd_nhwc<T, V, true, true, true>), grid, dim3(kThreads), 0, st, x, res, y, M, C, g.gt,
+                       g.rows_per_iter, g.rows_per_block, fp, bn_reverse(), bits);
+  else
+    hipLaunchKernelGGL((bn_fwd_nhwc<T, V, true, false, true>), grid, dim3(kThreads), 0, st, x, res, y, M, C, g.gt,
+                       g.rows_per_iter, g.rows_per_block, fp, bn_reverse(), bits);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int V>
+static int launch_reduce_bits(const T* x, const T* dy, const unsigned char* bits, int64_t N, int64_t C, int64_t HW,
+                              const float* fp, float* partial, hipStream_t st) {
+  const int64_t M = N * HW;
+  NhwcGeom g = nhwc_geom(M, C, V);
+  dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
+  const size_t sh = (size_t)2 * g.rows_per_iter * g.gt * V * sizeof(typename RedAcc<T, 1>::type);
+  hipLaunchKernelGGL((bn_reduce_nhwc<T, V, 1, 3>), grid, dim3(kThreads), sh, st, x, dy, reinterpret_cast<const T*>(bits), M, C,
+                     g.gt, g.rows_per_iter, g.rows_per_block, fp, partial);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int V>
+static int launch_bwd_bits(const T* dy, const T* x, const unsigned char* bits, T* dx, T* dres, int64_t N, int64_t C,
+                           int64_t HW, const float* bp, hipStream_t st) {
+  const int64_t M = N * HW;
+  NhwcGeom g = nhwc_geom(M, C, V);
+  dim3 grid((unsigned)g.split, (unsigned)g.ytiles);
+#define L_(D) hipLaunchKernelGGL((bn_bwd_nhwc<T, V, 3, D>), grid, dim3(kThreads), 0, st, dy, x, reinterpret_cast<const T*>(bits), \
+      dx, dres, M, C, g.gt, g.rows_per_iter, g.rows_per_block, bp, bn_reverse())
+  if (dres) L_(true); else L_(false);
+#undef L_
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, int V>
 static int launch_bwd(const T* dy, const T* x, const T* y, T* dx, T* dres, int layout,
                       int64_t N, int64_t C, int64_t HW, const float* bp, int mask, hipStream_t st) {
@@ -1051,6 +1121,62 @@ int tsg_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, voi
 #undef GO
 }
 
+
+// ---- ReLU mask as one bit per element (block tails: BN -> (+identity) -> ReLU) --------------------------------
+static int bits_vec(int dtype, int layout, int64_t C, int64_t HW, const void* a, const void* b, const void* c, const void* d,
+                    const void* e) {
+  if (layout != TSG_NHWC) return 0;
+  const int want = dtype == TSG_BF16 ? 8 : dtype == TSG_F32 ? 4 : 0;
+  if (!want || C % want) return 0;
+  return pick_vec(dtype, layout, C, HW, a, b, c, d, e) == want ? want : 0;
+}
+
+int tsg_bn_maskbits_supported(int dtype, int layout, int64_t C, int64_t HW) {
+  return bits_vec(dtype, layout, C, HW, nullptr, nullptr, nullptr, nullptr, nullptr) != 0;
+}
+
+int tsg_bn_apply_fwd_maskbits(const void* x, const void* residual, void* y, void* bits, int dtype, int layout, int64_t N,
+                              int64_t C, int64_t HW, const float* fwd_pack, void* stream) {
+  int e = check_dims(dtype, layout, N, C, HW);
+  if (e) return e;
+  if (!x || !y || !bits || !fwd_pack) return TSG_E_NULL;
+  if (!aligned16(fwd_pack)) return TSG_E_ALIGN;
+  const int V = bits_vec(dtype, layout, C, HW, x, residual, y, nullptr, nullptr);
+  if (!V) return layout != TSG_NHWC ? TSG_E_LAYOUT : TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TSG_F32)
+    return launch_fwd_bits<float, 4>((const float*)x, (const float*)residual, (float*)y, (unsigned char*)bits, N, C, HW, fwd_pack, st);
+  return launch_fwd_bits<bf16_t, 8>((const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (unsigned char*)bits, N, C, HW, fwd_pack, st);
+}
+
+int tsg_bn_bwd_reduce_maskbits(const void* dy, const void* x, const void* bits, int dtype, int layout, int64_t N, int64_t C,
+                               int64_t HW, const float* fwd_pack, float* partial, int* rows, void* stream) {
+  int e = check_dims(dtype, layout, N, C, HW);
+  if (e) return e;
+  if (!dy || !x || !bits || !fwd_pack || !partial) return TSG_E_NULL;
+  if (!aligned16(fwd_pack)) return TSG_E_ALIGN;
+  const int V = bits_vec(dtype, layout, C, HW, x, dy, nullptr, nullptr, nullptr);
+  if (!V) return layout != TSG_NHWC ? TSG_E_LAYOUT : TSG_E_ALIGN;
+  if (rows) *rows = partial_rows(layout, N, C, HW, V) * (dtype == TSG_F32 ? 2 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TSG_F32)
+    return launch_reduce_bits<float, 4>((const float*)x, (const float*)dy, (const unsigned char*)bits, N, C, HW, fwd_pack, partial, st);
+  return launch_reduce_bits<bf16_t, 8>((const bf16_t*)x, (const bf16_t*)dy, (const unsigned char*)bits, N, C, HW, fwd_pack, partial, st);
+}
+
+int tsg_bn_bwd_apply_maskbits(const void* dy, const void* x, const void* bits, void* dx, void* dres, int dtype, int layout,
+                              int64_t N, int64_t C, int64_t HW, const float* bwd_pack, void* stream) {
+  int e = check_dims(dtype, layout, N, C, HW);
+  if (e) return e;
+  if (!dy || !x || !bits || !dx || !bwd_pack) return TSG_E_NULL;
+  if (!aligned16(bwd_pack)) return TSG_E_ALIGN;
+  const int V = bits_vec(dtype, layout, C, HW, x, dy, nullptr, dx, dres);
+  if (!V) return layout != TSG_NHWC ? TSG_E_LAYOUT : TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TSG_F32)
+    return launch_bwd_bits<float, 4>((const float*)dy, (const float*)x, (const unsigned char*)bits, (float*)dx, (float*)dres, N, C, HW, bwd_pack, st);
+  return launch_bwd_bits<bf16_t, 8>((const bf16_t*)dy, (const bf16_t*)x, (const unsigned char*)bits, (bf16_t*)dx, (bf16_t*)dres, N, C, HW, bwd_pack, st);
+}
 
 // ---- mixed layout (x NCHW, y/dy NHWC) --------------------------------------------
 static int mixed_ok(int dtype, int64_t C, int64_t HW) {

@@ -610,6 +610,51 @@ __global__ __launch_bounds__(256) void conv3_wrw_gen_fold(const float* __restric
   }
 }
 
+// Round 6: the same fold with the row lanes sized to the pair's slot count.  conv3_wrw_gen_fold gives every run of 64 entries
+// 16 row lanes x 8 loads: right for 256 slots (layer1), but a 512 -> 512 layer has 4 slots per pair (64 pairs) — 124 of its
+// 128 loads per 16 lanes were predicated re-reads of a neighbour's rows — and 128 -> 128 has 64.  Here T = 1 .. 16 row lanes
+// (<= 8 rows each up to 128 slots) share one float4 of the output; lane t sums rows t, t + T, .. in row order (fp64), the T
+// sums are folded in lane order: fixed order, bit-reproducible (the ORDER differs from conv3_wrw_gen_fold's, so the last
+// bits of dw do too).  13.3 -> ~8 us per launch x 25 launches.
+__global__ __launch_bounds__(256) void conv3_wrw_gen_fold2(const float* __restrict__ part, W3GenGeom g, int T,
+                                                           float* __restrict__ dw) {
+  __shared__ double sm[256][4];
+  const int outs = 256 / T;                                  // float4 outputs per block
+  const int t = threadIdx.x / outs, o = threadIdx.x - t * outs;
+  constexpr int QP = W3_C * W3_N / 4;                        // 9216 float4 per pair
+  const int64_t q_all = (int64_t)blockIdx.x * outs + o;
+  const int pair = (int)(q_all / QP), q = (int)(q_all - (int64_t)pair * QP);
+  const float* src = part + (int64_t)pair * g.bpp * W3_C * W3_N + (int64_t)q * 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int s0 = t; s0 < g.bpp; s0 += 8 * T) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u * T;
+      v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(s < g.bpp ? s : t) * W3_C * W3_N);
+      if (s >= g.bpp) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
+  }
+  if (T > 1) {
+    sm[threadIdx.x][0] = a0; sm[threadIdx.x][1] = a1; sm[threadIdx.x][2] = a2; sm[threadIdx.x][3] = a3;
+    __syncthreads();
+    if (t == 0) {
+      for (int k = 1; k < T; ++k) {
+        const double* r = sm[k * outs + o];
+        a0 += r[0]; a1 += r[1]; a2 += r[2]; a3 += r[3];
+      }
+    }
+  }
+  if (t == 0) {
+    const int e = q * 4, oc = e / W3_N, rem = e - oc * W3_N, tap = rem / W3_C, ci = rem - tap * W3_C;
+    const int oc0 = (pair / g.nci) * W3_C, ci0 = (pair % g.nci) * W3_C;
+    *reinterpret_cast<float4*>(dw + ((int64_t)(oc0 + oc) * 9 + tap) * g.Cin + ci0 + ci) =
+        make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+  }
+}
+
 // dw[flat] = sum over the per-block partials (fixed order, fp64); 64 consecutive entries per block
 __global__ __launch_bounds__(256) void conv3_wrw_fold(const float* __restrict__ part, int nparts, int64_t stride,
                                                       float* __restrict__ dw) {
@@ -791,7 +836,15 @@ static int conv3_wrw_gen_common(const void* x, const float* in_ab, const void* d
 #undef W3_GO
 #undef W3_GO2
   TSG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
+  // TSG_CONV_WRW_FOLD=2 (default) | 1: conv3_wrw_gen_fold2 (row lanes sized to the slot count) | the round-2 fold
+  static const bool fold2 = [] { const char* e = getenv("TSG_CONV_WRW_FOLD"); return !(e && e[0] == '1'); }();
+  if (fold2) {
+    const int T = g.bpp <= 8 ? 1 : g.bpp <= 16 ? 2 : g.bpp <= 32 ? 4 : g.bpp <= 64 ? 8 : 16;
+    const int64_t blocks = (int64_t)g.npairs * (W3_C * W3_N / 4) / (256 / T);
+    hipLaunchKernelGGL(conv3_wrw_gen_fold2, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, g, T, dw);
+  } else {
+    hipLaunchKernelGGL(conv3_wrw_gen_fold, dim3(g.npairs * W3_C * 9), dim3(256), 0, st, (const float*)ws, g, dw);
+  }
   TSG_CHECK_LAUNCH();
   return 0;
 }

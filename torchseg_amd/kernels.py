@@ -164,6 +164,37 @@ class HipKernels:
                                           bp.data_ptr(), int(relu), L.stream_ptr(x)), "tsg_bn_bwd_apply")
         return dx, dres
 
+    # ---- SyncBN block tail with the ReLU mask as one bit per element ------------
+    def bn_maskbits_supported(self, x, layout, Cc, HW):
+        return bool(self.lib.tsg_bn_maskbits_supported(L.dtype_code(x), layout, Cc, HW)) and x.data_ptr() % 16 == 0
+
+    def bn_apply_fwd_bits(self, x, residual, layout, N, Cc, HW, fp):
+        """relu(a x + b [+ residual]) -> (y, bits uint8 [N * HW * C / V]): bit j of byte (pixel * C + c) / V = (y > 0)"""
+        y = torch.empty_like(x)
+        V = 8 if x.dtype == torch.bfloat16 else 4
+        bits = torch.empty(N * HW * Cc // V, dtype=torch.uint8, device=x.device)
+        L.check(self.lib.tsg_bn_apply_fwd_maskbits(x.data_ptr(), L.ptr(residual), y.data_ptr(), bits.data_ptr(),
+                                                   L.dtype_code(x), layout, N, Cc, HW, fp.data_ptr(), L.stream_ptr(x)),
+                "tsg_bn_apply_fwd_maskbits")
+        return y, bits
+
+    def bn_bwd_reduce_bits(self, dy, x, bits, layout, N, Cc, HW, fp):
+        smax = self._num_partials(layout, N, Cc, HW)
+        partial = torch.empty((smax, 2, Cc), dtype=torch.float32, device=x.device)
+        rows = C.c_int(0)
+        L.check(self.lib.tsg_bn_bwd_reduce_maskbits(dy.data_ptr(), x.data_ptr(), bits.data_ptr(), L.dtype_code(x), layout, N,
+                                                    Cc, HW, fp.data_ptr(), partial.data_ptr(), C.byref(rows),
+                                                    L.stream_ptr(x)), "tsg_bn_bwd_reduce_maskbits")
+        return partial, rows.value
+
+    def bn_bwd_apply_bits(self, dy, x, bits, layout, N, Cc, HW, bp, want_dres):
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_dres else None
+        L.check(self.lib.tsg_bn_bwd_apply_maskbits(dy.data_ptr(), x.data_ptr(), bits.data_ptr(), dx.data_ptr(), L.ptr(dres),
+                                                   L.dtype_code(x), layout, N, Cc, HW, bp.data_ptr(), L.stream_ptr(x)),
+                "tsg_bn_bwd_apply_maskbits")
+        return dx, dres
+
     # ---- SyncBN, mixed layout (x NCHW, y/dy channels_last) -------------------
     def bn_mixed_supported(self, x):
         """4-D NCHW-contiguous activation that the stem kernels can take."""
@@ -1138,6 +1169,9 @@ _ALGO_BYTES = {
     "bn_apply_fwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]),
     "bn_bwd_reduce": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[2]),
     "bn_bwd_apply": lambda a, r: 3 * _nbytes(a[0]) + _nbytes(a[2]) + (_nbytes(a[0]) if a[9] else 0),
+    "bn_apply_fwd_bits": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[0]) // 16,
+    "bn_bwd_reduce_bits": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[2]),
+    "bn_bwd_apply_bits": lambda a, r: 3 * _nbytes(a[0]) + _nbytes(a[2]) + (_nbytes(a[0]) if a[8] else 0),
     "ohem_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "ohem_bwd": lambda a, r: 2 * _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
     "ohem_up_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 8 * a[1].numel(),
@@ -1279,7 +1313,8 @@ class KernelTimer:
     # kernel families of the bench line's `roofline` (the four bn_* labels are ONE family — SyncBN — and
     # the line must name the family with the largest total time, not the largest label)
     FAMILIES = {
-        "syncbn": ("bn_stats", "bn_apply_fwd", "bn_bwd_reduce", "bn_bwd_apply", "bn_apply_fwd_mixed", "bn_bwd_reduce_mixed",
+        "syncbn": ("bn_stats", "bn_apply_fwd", "bn_bwd_reduce", "bn_bwd_apply", "bn_apply_fwd_bits", "bn_bwd_reduce_bits",
+                   "bn_bwd_apply_bits", "bn_apply_fwd_mixed", "bn_bwd_reduce_mixed",
                    "bn_bwd_apply_mixed", "bn_relu_pool_fwd", "bn_relu_pool_bwd_reduce", "bn_relu_pool_bwd_apply"),
         "conv3x3_wrw": ("conv3x3_wrw",),
         "conv3x3_fwd_dgrad": ("conv3x3_gen_fwd", "conv3x3_c64_fwd", "conv3x3_c64_s2_dgrad", "conv3x3_s2_dgrad"),

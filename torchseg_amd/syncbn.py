@@ -172,6 +172,12 @@ def _backward_pack(kp, partial, S, C, n_local, invstd, fp, count_dev, use_batch_
     return kp.bn_bwd_coeffs(partial, S, C, float(n_local), None, use_batch_stats, invstd, fp, True, True)
 
 
+# TSG_BN_MASKBITS=1|0 (default 1, round 6): the block tail BN -> (+identity) -> ReLU keeps its ReLU mask as one bit per
+# element (tsg_bn_apply_fwd_maskbits) and its two backward kernels read that instead of the stored output: 2 of the 8
+# tensor passes of the layer's backward gone, same values.
+_MASKBITS = os.environ.get("TSG_BN_MASKBITS", "1") != "0"
+
+
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, mod, relu, use_batch_stats, group, hint=None):
@@ -191,13 +197,18 @@ class _SyncBNFn(torch.autograd.Function):
             fp = kp.bn_affine(mean, invstd, gamma, beta)
         mixed = (PREFER_CHANNELS_LAST_OUTPUT and residual is None and layout == K.L.NCHW
                  and kp.bn_mixed_supported(x))
+        need_y = relu and residual is not None
+        bits = None
         if mixed:
             y = kp.bn_apply_fwd_mixed(x, N, C, HW, fp, relu)
+        elif (need_y and _MASKBITS and hasattr(kp, "bn_apply_fwd_bits") and kp.bn_maskbits_supported(x, layout, C, HW)
+              and residual.data_ptr() % 16 == 0):
+            y, bits = kp.bn_apply_fwd_bits(x, residual, layout, N, C, HW, fp)
         else:
             y = kp.bn_apply_fwd(x, residual, layout, N, C, HW, fp, relu)
-        need_y = relu and residual is not None
-        ctx.save_for_backward(x, y if need_y else None, weight, bias, invstd, fp, count_dev)
+        ctx.save_for_backward(x, bits if bits is not None else (y if need_y else None), weight, bias, invstd, fp, count_dev)
         ctx.cfg = (layout, N, C, HW, relu, use_batch_stats, group, world, residual is not None, mixed)
+        ctx.bits = bits is not None
         return y
 
     @staticmethod
@@ -212,11 +223,18 @@ class _SyncBNFn(torch.autograd.Function):
             partial, S = kp.bn_bwd_reduce_mixed(dy, x, N, C, HW, fp, relu)
         else:
             dy = _like(dy, x)
-            partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, fp, relu)
+            if ctx.bits and dy.data_ptr() % 16:
+                dy = dy.clone(memory_format=torch.preserve_format)           # (a view at an odd offset: the bit-mask kernels take aligned tensors only)
+            if ctx.bits:                                          # y holds the one-bit-per-element ReLU mask
+                partial, S = kp.bn_bwd_reduce_bits(dy, x, y, layout, N, C, HW, fp)
+            else:
+                partial, S = kp.bn_bwd_reduce(dy, x, y, layout, N, C, HW, fp, relu)
         dgamma, dbeta, bp = _backward_pack(kp, partial, S, C, N * HW, invstd, fp, count_dev,
                                            use_batch_stats, group, world, x.device, parity=x.dtype == torch.float32)
         if mixed:
             dx, dres = kp.bn_bwd_apply_mixed(dy, x, N, C, HW, bp, relu), None
+        elif ctx.bits:
+            dx, dres = kp.bn_bwd_apply_bits(dy, x, y, layout, N, C, HW, bp, has_res)
         else:
             dx, dres = kp.bn_bwd_apply(dy, x, y, layout, N, C, HW, bp, relu, has_res)
         if weight is None:
