@@ -134,9 +134,11 @@ def test_reference_bisenet_bf16_takes_the_fused_kernels_and_equals_the_native_bu
     #     statistics, and every gradient except those two runs of the SAME builder do not reproduce either
     assert out["loss_ref"] == out["loss_nat"] == out["loss_nat0"] and out["kept_ref"] == out["kept_nat"], out
     assert out["bdiff"] == 0.0, out["bdiff"]
-    assert all(_vendor_wgrad(k) for k in out["noisy"]) and len(out["noisy"]) <= 6, out["noisy"]
-    assert set(out["differ"]) <= set(out["noisy"]), (out["differ"], out["noisy"])
-    assert all(v <= 5e-2 for v in out["rel"].values()), out["rel"]     # the vendor kernels' own run-to-run spread is ~1e-2
+    #     Round 6: the full-map 1x1 weight gradients left the vendor library's split-K atomics (torchseg_amd/pwconv.py): two
+    #     runs of the benched step now reproduce bit for bit, so nothing is exempted any more.
+    assert out["noisy"] == [], out["noisy"]
+    assert out["differ"] == [], (out["differ"], out["rel"])
+    assert "PointwiseConv2d" in out["classes"], out["classes"]
 
 
 def test_reference_bisenet_fp32_parity_mode_equals_the_native_builder(tmp_path):

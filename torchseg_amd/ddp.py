@@ -64,6 +64,9 @@ upsample overrides.  Controlled by env so train.py needs no edit:
   TSG_CAT=1|0           (default 1 on GPU: FeatureFusion's torch.cat([x1, x2], 1) on tsg_cat2_rows; pool.py)
   TSG_VEC_CONV=1|0      (default 1 on GPU: bias-free 1x1 convolutions applied to pooled [B, C, 1, 1] maps (channel attention,
                         global context) on tsg_conv1x1_vec_*: one launch forward, one backward, fp32 master weight; vecconv.py)
+  TSG_PW_CONV=1|0       (default 1 on GPU: the bias-free 1x1 convolutions of whole maps (ResNet shortcuts, SpatialPath.conv_1x1,
+                        FeatureFusion.conv_1x1) compute their weight gradient as a chunked batched GEMM folded in a fixed order —
+                        the vendor library's split-K atomics were the last run-to-run difference of the step; pwconv.py)
   TSG_FORK_MODULES=a,b  (default none; e.g. "spatial_path": direct sub-modules of an unchanged network.py that run on a side HIP
                         stream and are joined where their output is first used — BiSeNet's detail branch beside its context
                         path.  Box-dependent (+1.4 % / -0.2 %), hence opt-in; our own BiSeNet builder: TSG_FORK_SPATIAL=1; fusion.py)
@@ -421,6 +424,9 @@ class DistributedDataParallel(nn.Module):
             if _env_flag("TSG_VEC_CONV", True):
                 from .vecconv import install_pooled_conv
                 install_pooled_conv(self.module)                     # 1x1 convolutions of pooled [B, C, 1, 1] maps
+            if _env_flag("TSG_PW_CONV", True):
+                from .pwconv import install_pointwise_conv
+                install_pointwise_conv(self.module)                  # remaining full-map 1x1 layers: reproducible weight gradient
             if self.compute_dtype == torch.float32:
                 # fp32 = the parity mode: convolutions on the reference-accuracy kernels (exactconv.py: logits 1.3-1.9e-5
                 # from the float64 truth, the reference's CPU path 7-8e-5, the vendor library's fp32 kernels 5-6e-5)
