@@ -395,6 +395,12 @@ int tsg_conv3x3_gen_variant(int64_t B, int64_t H, int64_t W, int Cin, int Cout, 
 int tsg_conv3x3_s2_dgrad_supported(int dtype, int Cin, int Cout);
 int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* addend, int64_t B, int64_t H, int64_t W,
                          int Cin, int Cout, void* stream);
+/* The same with a COMPACT addend (round 6): addend_sub [B,OH,OW,C_in] bf16 on dy's grid — the gradient of x[:, :, ::2, ::2],
+ * i.e. of the block's 1x1 / stride-2 shortcut convolution (resnet.py:139-146) run as a stride-1 convolution of the
+ * sub-sampled map — is added at the even pixels of dx; the zero-filled full-size gradient the cuDNN backward-data call of
+ * that shortcut would write (and this epilogue read back) is never made. */
+int tsg_conv3x3_s2_dgrad_subadd(const void* dy, const void* wf, void* dx, const void* addend_sub, int64_t B, int64_t H,
+                                int64_t W, int Cin, int Cout, void* stream);
 int tsg_conv3x3_gen_fwd(const void* x, const void* wf, void* y, float* partial, const float* in_ab, const void* addend,
                         int64_t B, int64_t H, int64_t W, int Cin, int Cout, int BN, void* stream);
 

@@ -419,3 +419,76 @@ def test_shortcut_gradient_joins_the_stride2_data_gradient(cuda, monkeypatch):
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1:], res[False][1:]):
         assert (a - b).abs().max().item() <= 2.0 ** -6 * b.abs().max().item() + 1e-6
+
+
+# ---- round 6: the shortcut's gradient as a COMPACT addend (tsg_conv3x3_s2_dgrad_subadd) ---------------------------------
+@pytest.mark.parametrize("shape", S2_SHAPES)
+def test_stride2_data_gradient_with_compact_addend(cuda, shape):
+    """addend_sub [B, Cin, OH, OW] added at the even pixels of dx == the full-size addend that is zero everywhere else
+    (bit-equal: both compute bf16(bf16(conv) + a), and x + 0 = x), even and odd sizes, partial tiles."""
+    from torchseg_amd import kernels as K
+    kp = K.provider()
+    B, Cin, Cout, H, W = shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5).to(cuda).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, Cout, OH, OW, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    sub = torch.randn(B, Cin, OH, OW, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    full = torch.zeros(B, Cin, H, W, device=cuda, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    full[:, :, ::2, ::2] = sub
+    want = kp.conv3x3_s2_dgrad(dy, w, (H, W), addend=full)
+    got = kp.conv3x3_s2_dgrad(dy, w, (H, W), addend_sub=sub)
+    plain = kp.conv3x3_s2_dgrad(dy, w, (H, W))
+    # (-0 + 0 = +0: compare values, and the untouched pixels against the plain launch)
+    assert torch.equal(got.float(), want.float())
+    odd = torch.ones(H, W, dtype=torch.bool, device=cuda)
+    odd[::2, ::2] = False
+    assert torch.equal(got.float()[:, :, odd], plain.float()[:, :, odd])
+    with pytest.raises(ValueError):
+        kp.conv3x3_s2_dgrad(dy, w, (H, W), addend=full, addend_sub=sub)
+
+
+def test_shortcut_on_the_subsampled_map_equals_the_stride2_shortcut(cuda, monkeypatch):
+    """BasicBlock with a 1x1 / stride-2 shortcut: with the shortcut convolution on torchseg_amd.pwconv, conv1's node hands it
+    x[:, :, ::2, ::2] as a compact tensor, the shortcut runs as a stride-1 convolution of that, and its gradient joins the
+    stride-2 data gradient as a compact addend.  Against the same block with TSG_SKIP_SUBSAMPLE off (full-size alias,
+    vendor stride-2 shortcut): same mathematics, other kernels for the shortcut -> everything within bf16 rounding."""
+    import copy, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torchseg_amd", "furnace"))
+    from base_model.resnet import BasicBlock, _shortcut
+    from torchseg_amd import convwrw
+    from torchseg_amd.convwrw import install_conv_wrw
+    from torchseg_amd.pwconv import install_pointwise_conv
+    from torchseg_amd.syncbn import SyncBatchNorm
+    torch.manual_seed(19)
+    proto = BasicBlock(64, 128, 2, norm_layer=SyncBatchNorm, downsample=_shortcut(64, 128, 2, SyncBatchNorm, 1e-5, 0.1))
+    g = torch.Generator().manual_seed(20)
+    x0 = torch.randn(2, 64, 26, 38, generator=g)
+    dy0 = torch.randn(2, 128, 13, 19, generator=g)
+    res = {}
+    for subs in (True, False):
+        blk = copy.deepcopy(proto).to(cuda).to(memory_format=torch.channels_last)
+        install_conv_wrw(blk)
+        assert install_pointwise_conv(blk) == 1
+        blk.train()
+        kp = convwrw.K.provider()
+        calls = []
+        orig = kp.conv3x3_s2_dgrad
+
+        def spy(*a, **k):
+            calls.append("sub" if k.get("addend_sub") is not None else "full" if k.get("addend") is not None else "none")
+            return orig(*a, **k)
+        kp.conv3x3_s2_dgrad = spy
+        monkeypatch.setattr(convwrw, "_SKIP_SUB", subs)
+        try:
+            xin = x0.to(cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            x = xin * 1.0
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = blk(x)
+            out.backward(dy0.to(cuda).to(out.dtype).contiguous(memory_format=torch.channels_last))
+        finally:
+            del kp.conv3x3_s2_dgrad
+        assert calls == (["sub"] if subs else ["full"]), calls
+        res[subs] = [out.detach().float().cpu(), xin.grad.float().cpu()] + [p.grad.float().cpu() for p in blk.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 2.0 ** -6 * b.abs().max().item() + 1e-6

@@ -94,6 +94,7 @@ _PROTOS = {
     "tsg_conv3x3_gen_variant": (_i, [_i64, _i64, _i64, _i, _i, _i, _i]),
     "tsg_conv3x3_s2_dgrad_supported": (_i, [_i, _i, _i]),
     "tsg_conv3x3_s2_dgrad": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p]),
+    "tsg_conv3x3_s2_dgrad_subadd": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p]),
     "tsg_conv3x3_gen_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "tsg_stem_conv_fwd_stats": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_bn_relu_pool_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _p, _p]),

@@ -224,8 +224,13 @@ class _ConvWrwFn(torch.autograd.Function):
                 partial = x.new_empty(0, dtype=torch.float32)
             ctx.mark_non_differentiable(partial)
         # skip: x is returned as a further output for the block's skip connection, so that the gradient of that path
-        # arrives HERE (dskip) and is added in the epilogue of the data-gradient kernel instead of by autograd's own pass
-        outs = (y,) + ((partial,) if with_stats else ()) + ((x,) if skip else ())
+        # arrives HERE (dskip) and is added in the epilogue of the data-gradient kernel instead of by autograd's own pass.
+        # skip == 2 (round 6, stride 2): the further output is x[:, :, ::2, ::2] — what the block's 1x1 / stride-2 shortcut
+        # convolution reads — as a compact tensor; the shortcut then runs as a stride-1 convolution of it and its gradient
+        # comes back compact (tsg_conv3x3_s2_dgrad_subadd adds it at the even pixels of dx)
+        ctx.skip_sub = skip == 2
+        xs = x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last) if ctx.skip_sub else x
+        outs = (y,) + ((partial,) if with_stats else ()) + ((xs,) if skip else ())
         return outs if len(outs) > 1 else y
 
     @staticmethod
@@ -233,7 +238,16 @@ class _ConvWrwFn(torch.autograd.Function):
         x, wb = ctx.saved_tensors
         rest = rest[1:] if ctx.has_stats else rest         # drop the (non-differentiable) partial's slot
         dskip = rest[0] if rest else None
+        sub = None
+        if dskip is not None and getattr(ctx, "skip_sub", False):
+            sub, dskip = dskip, None                       # compact: on the grid of x[:, :, ::2, ::2]
+            if sub.dtype != torch.bfloat16:
+                sub = sub.to(torch.bfloat16)
+            sub = sub.contiguous(memory_format=torch.channels_last)
         if dy is None:                                     # only the skip path was used
+            if sub is not None:
+                dskip = torch.zeros_like(x)
+                dskip[:, :, ::2, ::2] = sub
             return dskip, None, None, None, None, None, None
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
@@ -243,7 +257,9 @@ class _ConvWrwFn(torch.autograd.Function):
         if ctx.need_dx:
             add = _skip_addend(dskip, x.shape) if ((ctx.own and ctx.stride == 1) or ctx.s2_gen) else None
             if ctx.s2_gen:
-                dx = K.provider().conv3x3_s2_dgrad(dy, wb if ctx.master is None else ctx.master, ctx.in_hw, addend=add)
+                dx = K.provider().conv3x3_s2_dgrad(dy, wb if ctx.master is None else ctx.master, ctx.in_hw, addend=add,
+                                                   addend_sub=sub)
+                sub = None
                 if add is not None:
                     dskip = None
             elif ctx.own and ctx.stride == 2:
@@ -262,6 +278,8 @@ class _ConvWrwFn(torch.autograd.Function):
                                                          [True, False, False])[0]
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
+            if sub is not None:                            # a data-gradient path without the compact addend
+                dx[:, :, ::2, ::2] += sub.to(dx.dtype)
         dw = wrw_on_side_stream(lambda: K.provider().conv3x3_wrw(x, dy, stride=ctx.stride), ctx.wparam, x, dy)
         return dx, dw.to(ctx.wdtype), None, None, None, None, None
 
@@ -378,7 +396,10 @@ class WrwConv2d(nn.Conv2d):
                                  and self.weight.is_contiguous(memory_format=torch.channels_last)
                                  and K.provider().conv3x3_s2_dgrad_supported(self.in_channels, self.out_channels))
                     stats = _C64_STATS and c64 and self.training
-                    out = _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, bool(fuse and own64), stats)
+                    sk = bool(fuse and own64)
+                    if sk and want_skip == 2 and self.stride == (2, 2) and not c64:
+                        sk = 2                             # compact sub-sampled alias (see _ConvWrwFn.forward)
+                    out = _ConvWrwFn.apply(xb, self.weight, wb, self.stride[0], wrt, sk, stats)
                     if not stats:
                         return out if (fuse and own64) else ret(out)
                     y, partial = out[0], out[1]
@@ -389,15 +410,22 @@ class WrwConv2d(nn.Conv2d):
         return ret(super().forward(x))
 
 
-def conv_with_skip(conv, x):
+# TSG_SKIP_SUBSAMPLE=1|0 (default 1, round 6): a stride-2 block hands its shortcut convolution x[:, :, ::2, ::2] as a compact
+# tensor (conv_with_skip(subsample=True)) instead of x
+_SKIP_SUB = _os.environ.get("TSG_SKIP_SUBSAMPLE", "1") != "0"
+
+
+def conv_with_skip(conv, x, subsample=False):
     """`conv(x)` for the first convolution of a residual block whose skip connection is x itself (stride 1) or starts from x
     (stride 2: the 1x1 shortcut convolution, resnet.py:139-146).  Returns (y, x_skip):
     x_skip is x routed through the convolution's autograd node when our kernels compute its data gradient (then the
     block must use x_skip for `out += residual`: the skip path's gradient is added in that kernel's epilogue), else None
-    (use x)."""
+    (use x).  subsample=True (stride 2 only): x_skip may come back as the COMPACT x[:, :, ::2, ::2] — recognisable by its
+    size — on which the 1x1 / stride-2 shortcut convolution is a stride-1 convolution; its gradient then returns compact
+    too and is added at the even pixels of dx (no zero-filled full-size gradient)."""
     if _FUSE_SKIP and isinstance(conv, WrwConv2d) and conv.stride in ((1, 1), (2, 2)) and isinstance(x, torch.Tensor) \
             and x.is_cuda and torch.is_grad_enabled():
-        return conv._forward(x, True)
+        return conv._forward(x, 2 if (subsample and _SKIP_SUB and conv.stride == (2, 2)) else True)
     return conv(x), None
 
 

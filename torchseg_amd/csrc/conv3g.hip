@@ -598,8 +598,13 @@ constexpr int D2_OS = 36;                                // epilogue staging: bf
 constexpr size_t D2_LDS = 2 * (D2_FBYTES + D2_PBYTES);   // 75,776 B: two blocks per CU
 static_assert(16 * 64 * D2_OS * 2 <= D2_LDS, "the dx tile is staged in the filter and patch buffers");
 
+// sub (round 6): the addend is COMPACT — [B, H, W, Cout] on dy's grid, the gradient of x[:, :, ::2, ::2] (the residual block's
+// 1x1 / stride-2 shortcut convolution, resnet.py:139-146, run as a stride-1 convolution of the sub-sampled map): it is added at
+// the even pixels of dx only, and the zero-filled full-size tensor the vendor library's stride-2 data gradient used to write
+// (and this epilogue to read back) never exists.
 __global__ __launch_bounds__(256, 2) void conv3s2d_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wf,
-                                                      bf16_t* __restrict__ dx, G3Geom g, const bf16_t* __restrict__ addend) {
+                                                      bf16_t* __restrict__ dx, G3Geom g, const bf16_t* __restrict__ addend,
+                                                      int sub) {
   // g: B; H, W = dy's size; Cin = the convolution's OUTPUT channels (the K of this product); Cout = dx channels;
   //    tiles over dy; nchunks = Cin / 32; noct = Cout / 32; prio carries dx's height | width << 16
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -707,15 +712,24 @@ __global__ __launch_bounds__(256, 2) void conv3s2d_k(const bf16_t* __restrict__ 
     // front of every store (64 -> 128 @ 256^2 with addend: 129 -> 110 us, profiles/r04_s2_dgrad.txt)
     const bool has_add = addend != nullptr;
     const int iw = 2 * b0 + (tid >> 2);                   // row k, column tid >> 2 of the 16 x 64 tile
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(addend + (int64_t)bimg * XH * XW * g.Cout), 0, XH * XW * g.Cout * 2, 0x00020000);
-    const int av0 = iw < XW ? ((2 * a0) * XW + iw) * g.Cout * 2 + oct * 64 + part * 16 : (int)0x80000000;
-    const int arow = XW * g.Cout * 2;
+    const __amdgpu_buffer_rsrc_t ra = sub
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)(addend + (int64_t)bimg * g.H * g.W * g.Cout), 0, g.H * g.W * g.Cout * 2, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(addend + (int64_t)bimg * XH * XW * g.Cout), 0, XH * XW * g.Cout * 2, 0x00020000);
+    // full-size addend: row k of the tile at av0 + k arow.  Compact addend: only even rows and even columns of dx have one,
+    // row k at (k >> 1) arow; everything else gets the out-of-range offset the buffer unit answers with zeros (o + 0 = o)
+    const int av0 = iw >= XW ? (int)0x80000000
+                  : !sub ? ((2 * a0) * XW + iw) * g.Cout * 2 + oct * 64 + part * 16
+                  : (iw & 1) ? (int)0x80000000 : (a0 * g.W + (iw >> 1)) * g.Cout * 2 + oct * 64 + part * 16;
+    const int arow = (sub ? g.W : XW) * g.Cout * 2;
+    auto aload = [&](int k) {                              // k = k4 + e, k4 a multiple of 4: parity of k = parity of e
+      return sub ? __builtin_amdgcn_raw_buffer_load_b128(ra, (k & 1) ? (int)0x80000000 : av0, (k >> 1) * arow, 0)
+                 : __builtin_amdgcn_raw_buffer_load_b128(ra, av0, k * arow, 0);
+    };
     g3_u32x4 adc[4], adn[4];
     __builtin_amdgcn_sched_barrier(0);                   // (after the staging stores: the accumulators' registers are free)
     if (has_add) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) adc[e] = __builtin_amdgcn_raw_buffer_load_b128(ra, av0, e * arow, 0);
+      for (int e = 0; e < 4; ++e) adc[e] = aload(e);
     }
     __syncthreads();
     {
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void conv3s2d_k(const bf16_t* __restrict__ 
       for (int k4 = 0; k4 < 16; k4 += 4) {
         if (has_add && k4 < 12) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) adn[e] = __builtin_amdgcn_raw_buffer_load_b128(ra, av0, (k4 + 4 + e) * arow, 0);
+          for (int e = 0; e < 4; ++e) adn[e] = aload(k4 + 4 + e);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -900,8 +914,8 @@ int tsg_conv3x3_s2_dgrad_supported(int dtype, int Cin, int Cout) {
   return dtype == TSG_BF16 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0;
 }
 
-int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* addend, int64_t B, int64_t H, int64_t W,
-                         int Cin, int Cout, void* stream) {
+static int s2_dgrad_common(const void* dy, const void* wf, void* dx, const void* addend, int sub, int64_t B, int64_t H, int64_t W,
+                           int Cin, int Cout, void* stream) {
   if (!dy || !wf || !dx) return TSG_E_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || H > 0xffff || W > 0xffff) return TSG_E_SHAPE;
   if (!aligned16(dy) || !aligned16(wf) || !aligned16(dx) || (addend && !aligned16(addend))) return TSG_E_ALIGN;
@@ -923,9 +937,21 @@ int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* a
   TSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2d_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)D2_LDS));
   hipLaunchKernelGGL(conv3s2d_k, dim3(g.nslots * g.noct), dim3(256), D2_LDS, (hipStream_t)stream, (const bf16_t*)dy,
-                     (const bf16_t*)wf, (bf16_t*)dx, g, (const bf16_t*)addend);
+                     (const bf16_t*)wf, (bf16_t*)dx, g, (const bf16_t*)addend, sub);
   TSG_CHECK_LAUNCH();
   return 0;
+}
+
+int tsg_conv3x3_s2_dgrad(const void* dy, const void* wf, void* dx, const void* addend, int64_t B, int64_t H, int64_t W,
+                         int Cin, int Cout, void* stream) {
+  return s2_dgrad_common(dy, wf, dx, addend, 0, B, H, W, Cin, Cout, stream);
+}
+
+/* the same with a COMPACT addend [B, OH, OW, Cin] (the gradient of x[:, :, ::2, ::2]): added at the even pixels of dx */
+int tsg_conv3x3_s2_dgrad_subadd(const void* dy, const void* wf, void* dx, const void* addend_sub, int64_t B, int64_t H,
+                                int64_t W, int Cin, int Cout, void* stream) {
+  if (!addend_sub) return TSG_E_NULL;
+  return s2_dgrad_common(dy, wf, dx, addend_sub, 1, B, H, W, Cin, Cout, stream);
 }
 
 /* which kernel tsg_conv3x3_gen_fwd runs for this problem: 0 = conv3g_fwd_k (8-row tiles), 1 = conv3h_fwd_k (16-row tiles,

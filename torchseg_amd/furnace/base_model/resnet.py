@@ -58,9 +58,16 @@ class BasicBlock(_Block):
                 residual = skip if skip is not None else x
             elif self.downsample is not None and self.stride == 2:
                 # the shortcut branch (1x1 / stride 2 convolution + BN) reads the alias: its gradient reaches conv1's
-                # node and joins the stride-2 data gradient in that kernel's epilogue
-                c1, skip = conv_with_skip(self.conv1, x)
-                residual = self._identity(skip if skip is not None else x)
+                # node and joins the stride-2 data gradient in that kernel's epilogue.  Where the shortcut convolution is
+                # torchseg_amd.pwconv's, the alias is the COMPACT x[:, :, ::2, ::2] and the shortcut a stride-1 convolution
+                # of it: its gradient comes back on the small grid and is added at the even pixels (no zero-filled map)
+                sc = self.downsample[0]
+                sub = type(sc).__name__ == "PointwiseConv2d" and sc.stride == (2, 2) and sc.takes(x)
+                c1, skip = conv_with_skip(self.conv1, x, subsample=sub)
+                if skip is not None and sub and skip.shape[2:] != x.shape[2:]:
+                    residual = norm_act(self.downsample[1], None, sc.forward_subsampled(skip))
+                else:
+                    residual = self._identity(skip if skip is not None else x)
             else:
                 c1 = self.conv1(x)
                 residual = self._identity(x)

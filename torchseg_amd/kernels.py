@@ -900,9 +900,10 @@ class HipKernels:
     def conv3x3_s2_dgrad_supported(self, Cin, Cout):
         return bool(self.lib.tsg_conv3x3_s2_dgrad_supported(L.BF16, Cin, Cout))
 
-    def conv3x3_s2_dgrad(self, dy, weight, in_hw, addend=None):
+    def conv3x3_s2_dgrad(self, dy, weight, in_hw, addend=None, addend_sub=None):
         """dy [B,Cout,OH,OW] bf16 channels_last, weight [Cout,Cin,3,3] channels_last (fp32 master or bf16) of a 3x3 / stride 2
-        / padding 1 convolution whose input was [B,Cin,H,W] = in_hw -> dx bf16 channels_last (+ addend, same shape)"""
+        / padding 1 convolution whose input was [B,Cin,H,W] = in_hw -> dx bf16 channels_last (+ addend, same shape;
+        or + addend_sub [B,Cin,OH,OW], the gradient of x[:, :, ::2, ::2], at the even pixels)"""
         if not dy.is_contiguous(memory_format=torch.channels_last) or dy.dtype != torch.bfloat16:
             raise ValueError("conv3x3_s2_dgrad expects a bf16 channels_last dy")
         B, Cout = dy.shape[0], dy.shape[1]
@@ -913,8 +914,16 @@ class HipKernels:
         if addend is not None and (tuple(addend.shape) != (B, Cin, H, W) or addend.dtype != torch.bfloat16
                                    or not addend.is_contiguous(memory_format=torch.channels_last)):
             raise ValueError("conv3x3_s2_dgrad: addend must be a bf16 channels_last tensor of dx's shape")
+        if addend_sub is not None and (addend is not None or tuple(addend_sub.shape) != (B, Cin, dy.shape[2], dy.shape[3])
+                                       or addend_sub.dtype != torch.bfloat16
+                                       or not addend_sub.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("conv3x3_s2_dgrad: addend_sub must be a bf16 channels_last [B, Cin, OH, OW] tensor (and the only addend)")
         wf, _ = self.conv3x3_gen_prep_filter(weight, 1, dy, bn=32)
         dx = torch.empty((B, Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+        if addend_sub is not None:
+            L.check(self.lib.tsg_conv3x3_s2_dgrad_subadd(dy.data_ptr(), wf.data_ptr(), dx.data_ptr(), addend_sub.data_ptr(), B, H,
+                                                         W, Cin, Cout, L.stream_ptr(dy)), "tsg_conv3x3_s2_dgrad_subadd")
+            return dx
         L.check(self.lib.tsg_conv3x3_s2_dgrad(dy.data_ptr(), wf.data_ptr(), dx.data_ptr(), L.ptr(addend), B, H, W, Cin, Cout,
                                               L.stream_ptr(dy)), "tsg_conv3x3_s2_dgrad")
         return dx

@@ -23,6 +23,8 @@ import torch.nn.functional as F
 ENABLED = os.environ.get("TSG_PW_CONV", "1") != "0"
 # TSG_PW_DGRAD_MM=1|0 (default 1): data gradient of the stride-1 layers as a GEMM on the [pixels, channels] views
 _DGRAD_MM = os.environ.get("TSG_PW_DGRAD_MM", "1") != "0"
+# TSG_PW_SUB_FWD_MM=1|0 (default 1): the shortcut convolution on the sub-sampled map (forward_subsampled) as a GEMM as well
+_SUB_FWD_MM = os.environ.get("TSG_PW_SUB_FWD_MM", "1") != "0"
 _MIN_CHUNK = 128        # rows of a chunk: below this the batched GEMM's tiles run half empty
 
 
@@ -56,14 +58,21 @@ def pointwise_wgrad(x, dy, stride):
 
 class _PointwiseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, stride, fwd_mm=False):
         from .convwrw import _SHADOW
         if _SHADOW and weight.is_leaf and weight.is_cuda:
             from .shadow import bank                   # bf16 copy kept fresh once per optimizer step (no cast launch per call)
             wb, _ = bank.get(weight)
         else:
             wb = weight.detach().to(torch.bfloat16)
-        y = F.conv2d(x, wb, None, stride, 0)
+        if fwd_mm and stride == 1:
+            # y [pixels, C_out] = x [pixels, C_in] w^T: the shortcut on the sub-sampled map has shapes the vendor library's
+            # tuned database does not hold (its immediate-mode pick for [16, 256, 32, 32] -> 512 was a split-K kernel with
+            # an fp32 result and a cast pass: 97 us for 4 GFLOP, profiles/r06_shortcut_on_subsampled_map.txt)
+            B, K, H, W = x.shape
+            y = torch.mm(_rows(x), wb.reshape(wb.shape[0], K).t()).view(B, H, W, wb.shape[0]).permute(0, 3, 1, 2)
+        else:
+            y = F.conv2d(x, wb, None, stride, 0)
         ctx.save_for_backward(x, wb)
         ctx.stride = stride
         ctx.wdtype = weight.dtype
@@ -87,20 +96,30 @@ class _PointwiseFn(torch.autograd.Function):
         dw = pointwise_wgrad(x, dy, st) if ctx.needs_input_grad[1] else None
         if dw is not None and dw.dtype != ctx.wdtype:
             dw = dw.to(ctx.wdtype)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class PointwiseConv2d(nn.Conv2d):
-    def forward(self, x):
-        if (ENABLED and x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] > 1 and torch.is_grad_enabled()
-                and self.weight.requires_grad and self.weight.dtype == torch.float32
+    def takes(self, x):
+        """would forward(x) run the functions of this module (rather than the stock convolution)?"""
+        return (ENABLED and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] > 1
+                and torch.is_grad_enabled() and self.weight.requires_grad and self.weight.dtype == torch.float32
                 and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and x.dtype == torch.float32
-                                                    and torch.get_autocast_dtype("cuda") == torch.bfloat16))):
+                                                    and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
+
+    def forward(self, x):
+        if self.takes(x):
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
             xb = xb.contiguous(memory_format=torch.channels_last)
             with torch.autocast("cuda", enabled=False):
                 return _PointwiseFn.apply(xb, self.weight, self.stride[0])
         return super().forward(x)
+
+    def forward_subsampled(self, xs):
+        """this (stride-s) convolution of x, given xs = x[:, :, ::s, ::s] as a compact bf16 channels_last tensor: a stride-1
+        convolution of xs (convwrw.conv_with_skip(subsample=True) hands a residual block's shortcut exactly that)"""
+        with torch.autocast("cuda", enabled=False):
+            return _PointwiseFn.apply(xs.contiguous(memory_format=torch.channels_last), self.weight, 1, _SUB_FWD_MM)
 
 
 def _eligible(m):
