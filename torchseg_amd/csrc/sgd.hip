@@ -274,21 +274,68 @@ __device__ __forceinline__ int64_t g3_frag_offset(int oc, int tap, int ci, int C
   return ((((int64_t)(tile * nch + (ci >> 4)) * 9 + tap) * ocb_n + ocb) * 64 + ln) * 8 + (ci & 7);
 }
 
+// map[block] = {entry, chunk | kind << 28}.  kind 0: 4096 SOURCE elements of the entry -> wb, wrt, wf0 (and wf1, when the host
+// asks for it there: TSG_SHADOW_WF1_PASS=0).  kind 1 (round 6): 4096 DESTINATION elements of wf1.  Walking the source, the data-
+// gradient image was written 2 bytes at a time, 16 bytes apart (consecutive c_in are consecutive LANES of a fragment, 8
+// consecutive c_out its 16 bytes): every store a partial line — the launch took 98 us for 52 MB of parameters.  Walking the
+// destination a thread builds one 16-byte vector from 8 loads w[o + j][tap][ci], each of which is coalesced ACROSS the lanes
+// (32 consecutive ci), and a wave stores 1 KB contiguous.
+constexpr int kShadowKindShift = 28;
+
 __global__ __launch_bounds__(256) void weight_shadow_k(const ShadowEntry* __restrict__ table, const int2* __restrict__ map) {
   const int2 m = map[blockIdx.x];
   const ShadowEntry e = table[m.x];
-  const int base = m.y * kSgdChunk;
+  const int kind = m.y >> kShadowKindShift, chunk = m.y & ((1 << kShadowKindShift) - 1);
+  const int base = chunk * kSgdChunk;
   const int end = base + kSgdChunk < e.n ? base + kSgdChunk : e.n;
   const int tapI = 9 * e.I;
-  const bool geo = e.wrt || e.wf0 || e.wf1;
+  if (kind == 1) {                                     // e.n = 9 O I elements of wf1, 8 per thread and round
+    const int nch = e.O >> 4, ocb_n = e.bn1 >> 5;
+    for (int d = base + threadIdx.x * 8; d < end; d += 256 * 8) {
+      const int ln = (d >> 3) & 63;
+      int rest = d >> 9;
+      const int ocb = rest % ocb_n; rest /= ocb_n;
+      const int tp = rest % 9; rest /= 9;
+      const int c16 = rest % nch, tile = rest / nch;
+      const int ci = tile * e.bn1 + ocb * 32 + (ln & 31);              // W'[ci][tp][o] = w[o][8 - tp][ci]
+      const int o0 = c16 * 16 + (ln >> 5) * 8;
+      const float* src = e.w + ((int64_t)o0 * 9 + (8 - tp)) * e.I + ci;
+      uint32_t pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        pk[j] = (uint32_t)f32_to_bf16(src[(int64_t)(2 * j) * tapI]) | ((uint32_t)f32_to_bf16(src[(int64_t)(2 * j + 1) * tapI]) << 16);
+      *reinterpret_cast<uint4*>(e.wf1 + d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    return;
+  }
+  if (kind == 2) {                                     // the FORWARD image by destination: W'[oc][tp][ci0 .. ci0 + 7] = w[oc][tp][ci0 ..]
+    const int nch = e.I >> 4, ocb_n = e.bn0 >> 5;
+    for (int d = base + threadIdx.x * 8; d < end; d += 256 * 8) {
+      const int ln = (d >> 3) & 63;
+      int rest = d >> 9;
+      const int ocb = rest % ocb_n; rest /= ocb_n;
+      const int tp = rest % 9; rest /= 9;
+      const int c16 = rest % nch, tile = rest / nch;
+      const int oc = tile * e.bn0 + ocb * 32 + (ln & 31), ci0 = c16 * 16 + (ln >> 5) * 8;
+      const float4* src = reinterpret_cast<const float4*>(e.w + ((int64_t)oc * 9 + tp) * e.I + ci0);
+      const float4 a = src[0], b = src[1];
+      *reinterpret_cast<uint4*>(e.wf0 + d) = make_uint4(
+          (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16), (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16),
+          (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16), (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16));
+    }
+    return;
+  }
+  const bool wf1_here = e.wf1 && (e.pad & 1) == 0;     // pad bit 0: wf1 has blocks of kind 1, bit 1: wf0 has blocks of kind 2
+  const bool wf0_here = e.wf0 && (e.pad & 2) == 0;
+  const bool geo = e.wrt || wf0_here || wf1_here;
   for (int i = base + threadIdx.x; i < end; i += 256) {
     const bf16_t v = f32_to_bf16(e.w[i]);
     if (e.wb) e.wb[i] = v;
     if (geo) {                                         // w is [O][3][3][I] (a channels_last 3x3 filter)
       const int o = i / tapI, r = i - o * tapI, tap = r / e.I, ci = r - tap * e.I;
       if (e.wrt) e.wrt[(ci * 9 + (8 - tap)) * e.O + o] = v;
-      if (e.wf0) e.wf0[g3_frag_offset(o, tap, ci, e.I, e.bn0)] = v;             // W' = w: C_out' = O, C_in' = I
-      if (e.wf1) e.wf1[g3_frag_offset(ci, 8 - tap, o, e.O, e.bn1)] = v;         // W'[ci][8 - tap][o] = w[o][tap][ci]
+      if (wf0_here) e.wf0[g3_frag_offset(o, tap, ci, e.I, e.bn0)] = v;          // W' = w: C_out' = O, C_in' = I
+      if (wf1_here) e.wf1[g3_frag_offset(ci, 8 - tap, o, e.O, e.bn1)] = v;      // W'[ci][8 - tap][o] = w[o][tap][ci]
     }
   }
 }

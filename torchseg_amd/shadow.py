@@ -18,6 +18,8 @@ import torch
 from . import kernels as K
 
 _CHUNK = 4096          # elements per block (kSgdChunk of csrc/sgd.hip)
+# TSG_SHADOW_WF1_PASS=1|0 (default 1, round 6): the data-gradient fragment image written by blocks that walk the destination
+_WF1_PASS = __import__("os").environ.get("TSG_SHADOW_WF1_PASS", "1") != "0"
 
 
 class _Entry(object):
@@ -91,11 +93,20 @@ class _Bank(object):
         for i, e in enumerate(ents):
             p = e.ref()
             f0, f1 = e.wf.get(0), e.wf.get(1)
+            # the data-gradient image in a pass of its own that walks the DESTINATION (csrc/sgd.hip weight_shadow_k, kind 1):
+            # needs whole 16-byte vectors of 8 c_out and whole 32-lane groups of c_in
+            own_pass = _WF1_PASS and f1 is not None and p.shape[0] % 16 == 0 and p.shape[1] % 32 == 0
+            own_fwd = _WF1_PASS and f0 is not None and p.shape[1] % 16 == 0 and p.shape[0] % 32 == 0
             tab[i] = (p.data_ptr(), e.wb.data_ptr(), 0 if e.wrt is None else e.wrt.data_ptr(),
                       0 if f0 is None else f0[0].data_ptr(), 0 if f1 is None else f1[0].data_ptr(), p.numel(),
-                      p.shape[0], p.shape[1] if p.dim() > 1 else 1, 0 if f0 is None else f0[1], 0 if f1 is None else f1[1], 0)
+                      p.shape[0], p.shape[1] if p.dim() > 1 else 1, 0 if f0 is None else f0[1], 0 if f1 is None else f1[1],
+                      (1 if own_pass else 0) | (2 if own_fwd else 0))
             nb = (p.numel() + _CHUNK - 1) // _CHUNK
             maps.append(np.stack([np.full(nb, i, dtype=np.int32), np.arange(nb, dtype=np.int32)], 1))
+            if own_pass:
+                maps.append(np.stack([np.full(nb, i, dtype=np.int32), np.arange(nb, dtype=np.int32) | (1 << 28)], 1))
+            if own_fwd:
+                maps.append(np.stack([np.full(nb, i, dtype=np.int32), np.arange(nb, dtype=np.int32) | (2 << 28)], 1))
         bmap = np.concatenate(maps, 0)
         table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
         return table, torch.from_numpy(np.ascontiguousarray(bmap)).to(device), ents
