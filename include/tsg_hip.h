@@ -213,6 +213,15 @@ int tsg_chanscale_fwd(const void* x, const void* s, void* y, int dtype, int layo
 int tsg_chanscale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds,
                       int dtype, int layout, int64_t N, int64_t C, int64_t HW,
                       int add_identity, void* ws, size_t ws_bytes, void* stream);
+/* The two halves of tsg_chanscale_bwd for a gate whose scale was computed FROM the pooled map it gates (AttentionRefinement /
+ * FeatureFusion, seg_oprs.py:192-238: `fm * se(gap(fm))`).  The map then has two gradients, the gate's dy s (+ dy) and the
+ * pooled branch's g[n, c] / HW, and the second depends on ds: autograd wrote the first (tsg_chanscale_bwd), and added the second
+ * in a pass of its own over the map.  _ds computes ds only (reads dy, x); _dx, called once g is known, writes
+ * dx = round(round(dy s (+ dy)) + gadd[n, c]) — the same bits — in one pass (reads dy).  NHWC, C % (16 / elem size) == 0. */
+int tsg_chanscale_bwd_ds(const void* dy, const void* x, void* ds, int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                         void* ws, size_t ws_bytes, void* stream);
+int tsg_chanscale_bwd_dx(const void* dy, const void* s, const void* gadd, void* dx, int dtype, int layout, int64_t N, int64_t C,
+                         int64_t HW, int add_identity, void* stream);
 
 /* Max pooling, channels_last — replaces ResNet's nn.MaxPool2d(kernel_size=3,
  * stride=2, padding=1) (furnace/base_model/resnet.py:132).  x [N, IH, IW, C],

@@ -154,3 +154,72 @@ def test_channel_concatenation_equals_torch_cat_forward_and_backward(cuda, shape
         assert torch.equal(u, v)
     n = torch.randn(2, 16, 4, 4, device=cuda)               # fp32 NCHW-contiguous: the stock path
     assert torch.equal(cat_channels(n, n), torch.cat([n, n], 1))
+
+
+# ---- round 6: a gate computed from the pooled map it gates (pool.gated_scale) ---------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 128, 24, 40), (3, 256, 16, 16), (2, 64, 33, 47), (1, 8, 5, 7)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("ident", [False, True])
+def test_gated_scale_equals_pool_branch_and_channel_scale(cuda, shape, dtype, ident, monkeypatch):
+    """`x * se(gap(x))` (+ x) with the linked autograd nodes (the gate's backward computes ds only, the pool node writes
+    dx = dy s (+ dy) + g / HW in one pass) against the plain composition, whose map gradient autograd sums in a pass of its
+    own: output, the map's gradient and the branch's parameter gradients are BIT-equal."""
+    from torchseg_amd import kernels as K, pool
+    kp = K.provider()
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x0 = torch.randn(shape, generator=g).to(dtype)
+    dy0 = torch.randn(shape, generator=g).to(dtype)
+    torch.manual_seed(4)
+    class Affine(torch.nn.Module):                      # (element-wise: a vendor convolution here is not run-to-run reproducible
+        def __init__(self):                             #  at shapes outside its tuned database, which fp32 equality would see)
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(1, C, 1, 1) * 0.5 + 1.0)
+            self.b = torch.nn.Parameter(torch.randn(1, C, 1, 1) * 0.3)
+
+        def forward(self, v):
+            return v * self.w + self.b
+
+    branch = torch.nn.Sequential(pool.GlobalAvgPool(1), Affine(), torch.nn.Sigmoid()).to(cuda).to(dtype)
+
+    def run(split):
+        monkeypatch.setattr(pool, "_GATE_SPLIT", split)
+        for p in branch.parameters():
+            p.grad = None
+        x = x0.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        cnt = K.CallCounter(kp)
+        try:
+            y = pool.gated_scale(x * 1.0 if False else x, branch, add_identity=ident)
+            y.backward(dy0.to(cuda).contiguous(memory_format=torch.channels_last))
+        finally:
+            calls = cnt.stop()
+        torch.cuda.synchronize()
+        return [y.detach(), x.grad] + [p.grad.clone() for p in branch.parameters()], calls
+
+    ref, c0 = run(False)
+    got, c1 = run(True)
+    assert c0.get("chanscale_bwd") == 1 and "chanscale_bwd_ds" not in c0
+    assert c1.get("chanscale_bwd_ds") == 1 and c1.get("chanscale_bwd_dx") == 1 and "chanscale_bwd" not in c1, c1
+    for name, a, b in zip(("y", "dx", "dw", "db"), got, ref):
+        assert torch.equal(a, b), name
+
+
+def test_gated_scale_falls_back_when_the_scale_does_not_come_from_the_pool(cuda):
+    """a branch that cuts the graph between the pooled vector and the scale (detach): the pool node will never run in the
+    backward pass, so the gate must write the map's gradient itself"""
+    from torchseg_amd import pool
+
+    class Cut(torch.nn.Module):
+        def forward(self, v):
+            return torch.sigmoid(v.detach() * 0.5 + self.w)
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1, 16, 1, 1))
+
+    branch = torch.nn.Sequential(pool.GlobalAvgPool(1), Cut()).to(cuda)
+    x = torch.randn(2, 16, 6, 10, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = pool.gated_scale(x, branch)
+    y.sum().backward()
+    s = torch.sigmoid(x.detach().mean((2, 3), keepdim=True) * 0.5)
+    assert torch.allclose(x.grad, s.expand_as(x), atol=1e-6) and branch[1].w.grad is not None

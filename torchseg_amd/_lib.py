@@ -65,6 +65,8 @@ _PROTOS = {
     "tsg_cat2_rows": (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "tsg_chanscale_fwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p]),
     "tsg_chanscale_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p, _sz, _p]),
+    "tsg_chanscale_bwd_ds": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_chanscale_bwd_dx": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p]),
     "tsg_maxpool_nhwc_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tsg_maxpool_nhwc_bwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tsg_stem_conv_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64]),

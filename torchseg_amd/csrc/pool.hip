@@ -162,6 +162,28 @@ __global__ __launch_bounds__(kT) void cs_fwd_nhwc(const T* __restrict__ x, const
   }
 }
 
+// dx = round(round(dy s (+ dy)) + gadd[n, c]): the gate's data gradient plus the pooled branch's (already divided by HW and
+// rounded to T on the host side) — bit for bit what tsg_chanscale_bwd's dx followed by the framework's `dx += expand(gadd)` gives
+template <typename T, int V, bool IDENT>
+__global__ __launch_bounds__(kT) void cs_dx_nhwc(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict__ gadd,
+                                                 T* __restrict__ dx, int64_t HW, int64_t C) {
+  const int64_t G = C / V, n = blockIdx.y, total = HW * G;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    const int64_t g = i % G;
+    PV<T, V> pd, ps, pg;
+    pd.load(dy + n * HW * C + i * V);
+    ps.load(s + n * C + g * V);
+    pg.load(gadd + n * C + g * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float t = IDENT ? fmaf(pd.v[j], ps.v[j], pd.v[j]) : pd.v[j] * ps.v[j];
+      const float tr = sizeof(T) == 2 ? __uint_as_float((uint32_t)f32_to_bf16(t) << 16) : t;     // the rounding of the stored dx
+      pd.v[j] = tr + pg.v[j];
+    }
+    pd.store(dx + n * HW * C + i * V);
+  }
+}
+
 template <typename T, int V, bool IDENT>
 __global__ __launch_bounds__(kT) void cs_fwd_nchw(const T* __restrict__ x, const T* __restrict__ s,
                                                   T* __restrict__ y, int64_t HW) {
@@ -176,7 +198,9 @@ __global__ __launch_bounds__(kT) void cs_fwd_nchw(const T* __restrict__ x, const
   }
 }
 
-template <typename T, int V, bool IDENT>
+// DX = false (round 6): only ds — the gate's gradient; dx is then written by cs_dx_nhwc once the pooled branch's gradient
+// is known (tsg_chanscale_bwd_ds / tsg_chanscale_bwd_dx), instead of being written here and re-read by a framework add
+template <typename T, int V, bool IDENT, bool DX = true>
 __global__ __launch_bounds__(kT) void cs_bwd_nhwc(const T* __restrict__ dy, const T* __restrict__ x,
                                                   const T* __restrict__ s, T* __restrict__ dx, int64_t HW,
                                                   int64_t C, int GT, int R, int64_t rpb, int S,
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(kT) void cs_bwd_nhwc(const T* __restrict__ dy, cons
               acc[j] = fmaf(pd.v[j], px.v[j], acc[j]);
               px.v[j] = IDENT ? fmaf(pd.v[j], ps.v[j], pd.v[j]) : pd.v[j] * ps.v[j];
             }
-            px.store(dx + base + rr * C);
+            if (DX) px.store(dx + base + rr * C);
           }
         }
       }
@@ -726,6 +750,61 @@ int tsg_chanscale_bwd(const void* dy, const void* x, const void* s, void* dx, vo
   return 0;
 }
 
+
+/* The two halves of tsg_chanscale_bwd for a gate whose scale was computed FROM the pooled map it gates (seg_oprs.py:192-238):
+ * _ds: ds[n, c] = sum_p dy x only (NHWC, vector path: C % (16 / elem) == 0, 16-byte aligned — TSG_E_LAYOUT / TSG_E_ALIGN
+ * otherwise); _dx: dx = dy s (+ dy) + gadd[n, c], gadd = the pooled branch's gradient per pixel, [N, C] of the tensor dtype. */
+int tsg_chanscale_bwd_ds(const void* dy, const void* x, void* ds, int dtype, int layout, int64_t N, int64_t C, int64_t HW,
+                         void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !ds || !ws) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  if (layout != TSG_NHWC) return TSG_E_LAYOUT;
+  if (ws_bytes < tsg_gap_ws_bytes(layout, N, C, HW)) return TSG_E_WS;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (C % V) return TSG_E_SHAPE;
+  if (!aligned16(x) || !aligned16(dy)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  GapGeom g = gap_geom(N, C, HW, V);
+  dim3 grid((unsigned)g.S, (unsigned)N);
+  const size_t sh = (size_t)g.R * g.gt * V * sizeof(float);
+  // (s is only read for dx: any valid pointer — x — stands in; IDENT does not matter)
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((cs_bwd_nhwc<float, 4, false, false>), grid, dim3(kT), sh, st, (const float*)dy, (const float*)x,
+                       (const float*)x, (float*)nullptr, HW, C, g.gt, g.R, g.rpb, g.S, (float*)ws);
+  else
+    hipLaunchKernelGGL((cs_bwd_nhwc<bf16_t, 8, false, false>), grid, dim3(kT), sh, st, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)x, (bf16_t*)nullptr, HW, C, g.gt, g.R, g.rpb, g.S, (float*)ws);
+  TSG_CHECK_LAUNCH();
+  const int64_t NC = N * C;
+  if (dtype == TSG_F32)
+    hipLaunchKernelGGL((gap_finish<float>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, 1.f, (float*)ds);
+  else
+    hipLaunchKernelGGL((gap_finish<bf16_t>), dim3(ceil_div_i(NC, kT)), dim3(kT), 0, st, (const float*)ws, g.S, NC, C, 1.f, (bf16_t*)ds);
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
+
+int tsg_chanscale_bwd_dx(const void* dy, const void* s, const void* gadd, void* dx, int dtype, int layout, int64_t N, int64_t C,
+                         int64_t HW, int add_identity, void* stream) {
+  if (!dy || !s || !gadd || !dx) return TSG_E_NULL;
+  if (dtype != TSG_F32 && dtype != TSG_BF16) return TSG_E_DTYPE;
+  if (N <= 0 || C <= 0 || HW <= 0) return TSG_E_SHAPE;
+  if (layout != TSG_NHWC) return TSG_E_LAYOUT;
+  const int V = dtype == TSG_BF16 ? 8 : 4;
+  if (C % V) return TSG_E_SHAPE;
+  if (!aligned16(dy) || !aligned16(dx) || !aligned16(s) || !aligned16(gadd)) return TSG_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t gx = (HW * (C / V) + kT - 1) / kT;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, (unsigned)N);
+#define GO(T, VV, I) hipLaunchKernelGGL((cs_dx_nhwc<T, VV, I>), grid, dim3(kT), 0, st, (const T*)dy, (const T*)s, (const T*)gadd, (T*)dx, HW, C)
+  if (dtype == TSG_F32) { if (add_identity) GO(float, 4, true); else GO(float, 4, false); }
+  else { if (add_identity) GO(bf16_t, 8, true); else GO(bf16_t, 8, false); }
+#undef GO
+  TSG_CHECK_LAUNCH();
+  return 0;
+}
 
 int tsg_maxpool_nhwc_fwd(const void* x, void* y, void* argmax_u8, int dtype, int64_t N, int C, int IH, int IW,
                          int OH, int OW, int K, int S, int P, void* stream) {

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from torchseg_amd import fusion as _fusion
-from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool, cat_channels, channel_scale
+from torchseg_amd.pool import GlobalAvgPool as _GlobalAvgPool, cat_channels, channel_scale, gated_scale
 from torchseg_amd.syncbn import SyncBatchNorm as _FusedBN
 
 
@@ -231,7 +231,7 @@ class AttentionRefinement(nn.Module):
     @_fusion.outside_mode
     def forward(self, x):
         fm = self.conv_3x3(x)
-        return channel_scale(fm, self.channel_attention(fm))
+        return gated_scale(fm, self.channel_attention)            # fm * fm_se (seg_oprs.py:209-210)
 
 
 class FeatureFusion(nn.Module):
@@ -252,4 +252,4 @@ class FeatureFusion(nn.Module):
     @_fusion.outside_mode
     def forward(self, x1, x2):
         fm = self.conv_1x1(cat_channels(x1, x2))           # torch.cat([x1, x2], dim=1) on HIP channels_last maps
-        return channel_scale(fm, self.channel_attention(fm), add_identity=True)
+        return gated_scale(fm, self.channel_attention, add_identity=True)    # fm + fm * fm_se (seg_oprs.py:236-237)

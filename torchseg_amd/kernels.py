@@ -292,6 +292,26 @@ class HipKernels:
                                            ws.numel(), L.stream_ptr(x)), "tsg_chanscale_bwd")
         return dx, ds
 
+    def chanscale_split_supported(self, x, layout, Cc):
+        """the two-phase backward of a gate (chanscale_bwd_ds / chanscale_bwd_dx): NHWC, whole 16-byte channel vectors"""
+        return layout == L.NHWC and Cc % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.data_ptr() % 16 == 0
+
+    def chanscale_bwd_ds(self, dy, x, layout, N, Cc, HW):
+        """ds [N, C] = sum over pixels of dy x (the gate's gradient) without writing dx"""
+        wsb = self.lib.tsg_gap_ws_bytes(layout, N, Cc, HW)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+        ds = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
+        L.check(self.lib.tsg_chanscale_bwd_ds(dy.data_ptr(), x.data_ptr(), ds.data_ptr(), L.dtype_code(x), layout, N, Cc, HW,
+                                              ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_chanscale_bwd_ds")
+        return ds
+
+    def chanscale_bwd_dx(self, dy, s, gadd, layout, N, Cc, HW, add_identity):
+        """dx = dy s (+ dy) + gadd[n, c] (gadd: [N, C] of dy's dtype)"""
+        dx = torch.empty_like(dy)
+        L.check(self.lib.tsg_chanscale_bwd_dx(dy.data_ptr(), s.data_ptr(), gadd.data_ptr(), dx.data_ptr(), L.dtype_code(dy), layout,
+                                              N, Cc, HW, int(add_identity), L.stream_ptr(dy)), "tsg_chanscale_bwd_dx")
+        return dx
+
     # ---- max pool (channels_last) ------------------------------------------------
     def maxpool_fwd(self, x, K_, S_, P_):
         """x channels_last-dense [N,C,IH,IW] -> (y channels_last, argmax uint8 [N,OH,OW,C])"""
@@ -1195,6 +1215,8 @@ _ALGO_BYTES = {
     "bn_bwd_apply_mixed": lambda a, r: 3 * _nbytes(a[0]),
     "chanscale_fwd": lambda a, r: 2 * _nbytes(a[0]),
     "chanscale_bwd": lambda a, r: 3 * _nbytes(a[0]),
+    "chanscale_bwd_ds": lambda a, r: 2 * _nbytes(a[0]),
+    "chanscale_bwd_dx": lambda a, r: 2 * _nbytes(a[0]),
     "maxpool_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r[0]) + _nbytes(r[1]),
     "maxpool_bwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(r),
     "gap_fwd": lambda a, r: _nbytes(a[0]),
