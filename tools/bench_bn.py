@@ -13,8 +13,9 @@ def timeit(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e-3
 shapes = [(16, 64, 512, 512), (16, 64, 256, 256), (16, 128, 128, 128), (16, 256, 64, 64), (16, 512, 32, 32), (16, 128, 1, 1)]
-for dtype in (torch.bfloat16, torch.float32):
-    for fmt in (torch.contiguous_format, torch.channels_last):
+only = os.environ.get("BENCH_BN_ONLY")          # "bf16nhwc": the benched dtype / layout only
+for dtype in ((torch.bfloat16,) if only else (torch.bfloat16, torch.float32)):
+    for fmt in ((torch.channels_last,) if only else (torch.contiguous_format, torch.channels_last)):
         for shp in shapes:
             N, C, H, W = shp
             x = torch.randn(shp, device=dev).to(dtype).contiguous(memory_format=fmt)

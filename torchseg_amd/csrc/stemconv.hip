@@ -238,8 +238,11 @@ __device__ __forceinline__ int plane_base(int q, int sg) {
 //   dy = a dv + Bc (xc - mean) + C2,  dv = relu'(a xc + b) * da      (tsg_bn_bwd_apply with the recomputed mask, bf16-rounded),
 // evaluated while the tile is staged from the gradient da w.r.t. the normalised activation and the stem's own output xc.
 // The image needs no gradient, so this weight gradient is the ONLY consumer of dy: the 0.5 GB tensor is never written.
+// __launch_bounds__(256, 3): SC_NPART = 3 x 256 persistent blocks must all be resident.  Left to itself the compiler gave
+// the BNB form 180 VGPRs = two blocks per CU, so a third of the blocks ran as a second round (400 -> 360 us at 16 x 1024^2,
+// round 6: profiles/r06_stem_wrw_bn_occupancy.txt); bounded it takes 160, spill-free.
 template <bool BNB>
-__global__ __launch_bounds__(256) void stem_wrw_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256, 3) void stem_wrw_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                   float* __restrict__ part, StemGeom g, const bf16_t* __restrict__ xc,
                                                   const float* __restrict__ bp) {
   __shared__ __attribute__((aligned(16))) bf16_t dyT[SC_OC * SC_DS];       // 17408 B: [oc][pixel of the tile]
