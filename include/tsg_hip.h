@@ -285,6 +285,31 @@ int tsg_bn_relu_pool_bwd_reduce(const void* dpool, const void* argmax_u8, const 
 int tsg_bn_relu_pool_bwd_apply(const void* dpool, const void* argmax_u8, const void* x, void* dx, int dtype,
                                int64_t N, int C, int IH, int IW, int OH, int OW, const float* bp, void* stream);
 
+/* The ResNet stem WITHOUT its activation (round 6) — replaces `x = self.maxpool(self.relu(self.bn1(self.conv1(x))))`
+ * (furnace/base_model/resnet.py:96-100,131-133) as a whole when conv1 is the 3 -> 64 7x7/2 convolution above: the
+ * convolution costs 79 GFLOP over a 100 MB image while its output is 537 MB at 16 x 1024^2, so every pass RE-EVALUATES the
+ * tile of y it needs (rounded to bf16 exactly as tsg_stem_conv_fwd stores it) instead of reading it:
+ *   tsg_stem_conv_stats             partial[S][2][64] of tsg_stem_conv_fwd_stats (S = tsg_stem_conv_stats_partials), y not written
+ *   tsg_stem_conv_bn_relu_pool_fwd  ypool [B,PH,PW,64] bf16 channels_last + argmax_u8 [B,PH,PW,64], PH = (OH-1)/2+1:
+ *                                   tsg_bn_relu_pool_fwd(tsg_stem_conv_fwd(x, w), fp) bit for bit
+ *   tsg_stem_conv_bn_relu_pool_bwd_reduce   partial[S][2][64] = {sum dy', sum dy' (y - mean)},
+ *                                   S = tsg_stem_pool_bwd_num_partials (the sums of tsg_bn_relu_pool_bwd_reduce in another order)
+ *   tsg_stem_conv_wrw_bn_pool       dw = tsg_stem_conv_wrw(x, tsg_bn_relu_pool_bwd_apply(dpool, argmax, y, bp)): the 537 MB
+ *                                   gradient is staged tile by tile into the weight gradient's LDS image, never stored;
+ *                                   xc = the stored stem output y [B,OH,OW,64] (read), or NULL (y re-evaluated)
+ * x, w, ws as for tsg_stem_conv_fwd; fp / bp the packs of tsg_bn_finalize / tsg_bn_bwd_coeffs for C = 64. */
+int tsg_stem_conv_stats(const void* x, const float* w, float* partial, int64_t B, int64_t H, int64_t W, void* ws,
+                        size_t ws_bytes, void* stream);
+int tsg_stem_conv_bn_relu_pool_fwd(const void* x, const float* w, const float* fp, void* ypool, void* argmax_u8,
+                                   int64_t B, int64_t H, int64_t W, void* ws, size_t ws_bytes, void* stream);
+int tsg_stem_pool_bwd_num_partials(int64_t B, int64_t H, int64_t W);
+int tsg_stem_conv_bn_relu_pool_bwd_reduce(const void* x, const float* w, const void* dpool, const void* argmax_u8,
+                                          const float* fp, float* partial, int64_t B, int64_t H, int64_t W, void* ws,
+                                          size_t ws_bytes, void* stream);
+int tsg_stem_conv_wrw_bn_pool(const void* x, const float* w, const void* xc, const void* dpool, const void* argmax_u8,
+                              const float* bp, float* dw, int64_t B, int64_t H, int64_t W, void* ws, size_t ws_bytes,
+                              void* stream);
+
 /* Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / padding 1 convolutions (ResNet-18 layer1:
  * BasicBlock.conv1 / conv2, furnace/base_model/resnet.py:24-29,36-53) — replaces the cuDNN
  * backward-filter call autograd makes for them.  x [B,H,W,64] and dy [B,H,W,64] bf16 channels_last;

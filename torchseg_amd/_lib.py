@@ -104,6 +104,11 @@ _PROTOS = {
     "tsg_bn_relu_pool_bwd_reduce": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _p, _p, _p]),
     "tsg_bn_relu_pool_bwd_apply": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "tsg_stem_conv_wrw": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_stem_conv_stats": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_stem_conv_bn_relu_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_stem_pool_bwd_num_partials": (_i, [_i64, _i64, _i64]),
+    "tsg_stem_conv_bn_relu_pool_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "tsg_stem_conv_wrw_bn_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "tsg_confusion_map": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p]),
     "tsg_confusion_logits": (_i, [_p, _i, _p, _i, _i64, _i, _i64, _i, _p, _p]),
     "tsg_sgd_multi_blockmap": (_i64, [_p, _i, _p, _i64]),

@@ -150,6 +150,11 @@ class ResNet(nn.Module):
             x = norm_act(c[4], c[5], x)
             x = c[6](x)
         else:
+            if x.is_cuda:
+                from torchseg_amd.syncbn import stem_bn_relu_maxpool
+                y = stem_bn_relu_maxpool(self.conv1, self.bn1, x, self.maxpool)   # the whole stem as one recomputing node
+                if y is not None:
+                    return y
             x = self.conv1(x)
         if x.is_cuda:
             from torchseg_amd.syncbn import bn_relu_maxpool

@@ -444,6 +444,68 @@ class HipKernels:
                                               W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_wrw_bn")
         return dw
 
+    # ---- the recomputing ResNet stem (round 6): conv1 -> bn1 -> relu -> maxpool without the stem activation ----
+    def stem_conv_stats(self, x, weight):
+        """-> partial fp32 [S,2,64] = {sum y, sum y^2} of y = stem_conv_fwd(x, weight), y not written"""
+        _require_contiguous(x, weight)
+        B, _, H, W = x.shape
+        S = self._count(("stem_stats", B, H, W), lambda: self.lib.tsg_stem_conv_stats_partials(B, H, W),
+                        "tsg_stem_conv_stats_partials")
+        partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_stats(x.data_ptr(), weight.data_ptr(), partial.data_ptr(), B, H, W, ws.data_ptr(),
+                                             ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_stats")
+        return partial
+
+    def stem_conv_bn_relu_pool_fwd(self, x, weight, fp):
+        """maxpool_3x3/2/1(relu(bn(stem_conv(x)))) -> (ypool [B,64,PH,PW] bf16 channels_last, argmax uint8 [B,PH,PW,64])"""
+        _require_contiguous(x, weight, fp)
+        B, _, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+        y = torch.empty((B, 64, PH, PW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((B, PH, PW, 64), dtype=torch.uint8, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_bn_relu_pool_fwd(x.data_ptr(), weight.data_ptr(), fp.data_ptr(), y.data_ptr(),
+                                                        idx.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), L.stream_ptr(x)),
+                "tsg_stem_conv_bn_relu_pool_fwd")
+        return y, idx
+
+    def stem_conv_bn_relu_pool_bwd_reduce(self, x, weight, dpool, idx, fp):
+        """-> (partial fp32 [S,2,64] = {sum dy', sum dy'(y-mean)}, S) with y recomputed and dy' gathered from dpool through idx"""
+        _require_contiguous(x, weight, fp)
+        if not dpool.is_contiguous(memory_format=torch.channels_last) or dpool.dtype != torch.bfloat16:
+            raise ValueError("stem_conv_bn_relu_pool_bwd_reduce expects a bf16 channels_last pooled gradient")
+        B, _, H, W = x.shape
+        S = self._count(("stem_pool", B, H, W), lambda: self.lib.tsg_stem_pool_bwd_num_partials(B, H, W),
+                        "tsg_stem_pool_bwd_num_partials")
+        partial = torch.empty((S, 2, 64), dtype=torch.float32, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_bn_relu_pool_bwd_reduce(x.data_ptr(), weight.data_ptr(), dpool.data_ptr(), idx.data_ptr(),
+                                                               fp.data_ptr(), partial.data_ptr(), B, H, W, ws.data_ptr(),
+                                                               ws.numel(), L.stream_ptr(x)),
+                "tsg_stem_conv_bn_relu_pool_bwd_reduce")
+        return partial, S
+
+    def stem_conv_wrw_bn_pool(self, x, weight, dpool, idx, bp, xc=None):
+        """dw fp32 [64,3,7,7] of the stem with dy = BN+ReLU+pool backward(dpool; idx, y, bp) staged on the fly; y = xc (the
+        stored stem output, bf16 channels_last) when given, re-evaluated from x otherwise"""
+        _require_contiguous(x, weight, bp)
+        if not dpool.is_contiguous(memory_format=torch.channels_last) or dpool.dtype != torch.bfloat16:
+            raise ValueError("stem_conv_wrw_bn_pool expects a bf16 channels_last pooled gradient")
+        if bp.dtype != torch.float32 or tuple(bp.shape) != (5, 64):
+            raise ValueError("stem_conv_wrw_bn_pool expects the [5, 64] fp32 backward pack")
+        B, _, H, W = x.shape
+        if xc is not None and (xc.dtype != torch.bfloat16 or not xc.is_contiguous(memory_format=torch.channels_last)
+                               or tuple(xc.shape) != (B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1)):
+            raise ValueError("stem_conv_wrw_bn_pool expects xc = the bf16 channels_last stem output")
+        dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device)
+        ws = self._stem_ws(x.device)
+        L.check(self.lib.tsg_stem_conv_wrw_bn_pool(x.data_ptr(), weight.data_ptr(), xc.data_ptr() if xc is not None else None,
+                                                   dpool.data_ptr(), idx.data_ptr(), bp.data_ptr(), dw.data_ptr(), B, H, W,
+                                                   ws.data_ptr(), ws.numel(), L.stream_ptr(x)), "tsg_stem_conv_wrw_bn_pool")
+        return dw
+
     # ---- OHEM / focal / upsample ------------------------------------------
     def ohem_fwd(self, logits, labels, ignore_label, thresh, min_kept, weight):
         """logits [B,C,H,W] contiguous, labels [B,H,W] -> (loss[1], nll[P], lse[P], sel[8] int32)"""
@@ -1227,6 +1289,12 @@ _ALGO_BYTES = {
     "bn_relu_pool_bwd_apply": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + 2 * _nbytes(a[2]),
     "stem_conv_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "stem_conv_wrw_bn": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]) + _nbytes(a[2]),
+    # the recomputing stem (round 6): the image, the pooled side arrays; y is never in memory
+    "stem_conv_stats": lambda a, r: _nbytes(a[0]),
+    "stem_conv_bn_relu_pool_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(r[0]) + _nbytes(r[1]),
+    "stem_conv_bn_relu_pool_bwd_reduce": lambda a, r: _nbytes(a[0]) + _nbytes(a[2]) + _nbytes(a[3]),
+    "stem_conv_wrw_bn_pool": lambda a, r, kw=None: (_nbytes(a[0]) + _nbytes(a[2]) + _nbytes(a[3])
+                                                    + (_nbytes((kw or {}).get("xc")) if (kw or {}).get("xc") is not None else 0)),
     "conv3x3_wrw": lambda a, r: _nbytes(a[0]) + _nbytes(a[1]),
     "conv3x3_c64_fwd": lambda a, r, kw=None: _nbytes(a[0]) + _nbytes(r) + _bsum_bytes(kw),
     "conv3x3_gen_fwd": lambda a, r: _nbytes(a[0]) + _nbytes(a[1][0]) + _nbytes(r[0] if isinstance(r, tuple) else r),
@@ -1247,7 +1315,17 @@ _ALGO_FLOPS = {
     "stem_conv_fwd_stats": lambda a, r: 2 * 147 * r.numel(),
     "stem_conv_wrw": lambda a, r: 2 * 147 * a[1].numel(),
     "stem_conv_wrw_bn": lambda a, r: 2 * 147 * a[1].numel(),
+    # y elements = 64 x OH x OW per image; the weight gradient evaluates the convolution AND its gradient product
+    "stem_conv_stats": lambda a, r: 2 * 147 * _stem_y_numel(a[0]),
+    "stem_conv_bn_relu_pool_fwd": lambda a, r: 2 * 147 * _stem_y_numel(a[0]),
+    "stem_conv_bn_relu_pool_bwd_reduce": lambda a, r: 2 * 147 * _stem_y_numel(a[0]),
+    "stem_conv_wrw_bn_pool": lambda a, r: 2 * 2 * 147 * _stem_y_numel(a[0]),
 }
+
+
+def _stem_y_numel(x):
+    B, _, H, W = x.shape
+    return B * 64 * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 
 
@@ -1350,7 +1428,8 @@ class KernelTimer:
         "conv3x3_wrw": ("conv3x3_wrw",),
         "conv3x3_fwd_dgrad": ("conv3x3_gen_fwd", "conv3x3_c64_fwd", "conv3x3_c64_s2_dgrad", "conv3x3_s2_dgrad"),
         "fused_heads": ("ohem_up_fwd", "ohem_up_bwd", "ohem_fwd", "ohem_bwd"),
-        "stem": ("stem_conv_fwd", "stem_conv_fwd_stats", "stem_conv_wrw", "stem_conv_wrw_bn"),
+        "stem": ("stem_conv_fwd", "stem_conv_fwd_stats", "stem_conv_wrw", "stem_conv_wrw_bn", "stem_conv_stats",
+                 "stem_conv_bn_relu_pool_fwd", "stem_conv_bn_relu_pool_bwd_reduce", "stem_conv_wrw_bn_pool"),
         "upsample": ("upsample_fwd", "upsample_presum_fwd", "upsample_bwd", "upsample_fwd_nhwc", "upsample_bwd_nhwc"),
     }
 

@@ -288,6 +288,116 @@ class _BnReluPoolFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+class _StemConvBnReluPoolFn(torch.autograd.Function):
+    """maxpool_3x3/2/1(relu(bn(conv7x7/2(img)))) — the whole ResNet stem (resnet.py:96-100,131-133) as ONE node, so that the
+    gradient of the 537 MB stem activation never exists: the weight gradient gathers it from the pooled gradient, applies the
+    BatchNorm backward and stages it tile by tile (tsg_stem_conv_wrw_bn_pool).  `full`: the activation itself is not stored either — statistics pass, fused forward and backward sums re-evaluate
+    the convolution too (csrc/stemconv.hip, round 6; measured slower: the stem convolution is issue-bound, 140 us per
+    evaluation).  img bf16 [B,3,H,W] contiguous, no gradient."""
+
+    @staticmethod
+    def forward(ctx, img, w_stem, weight, bias, mod, use_batch_stats, group, full):
+        kp = K.provider()
+        B, _, H, W = img.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        N, C, HW = B, 64, OH * OW
+        world = _world(group) if use_batch_stats else 1
+        count_dev = None
+        gamma = weight.float() if weight is not None else None
+        beta = bias.float() if bias is not None else None
+        xc = None
+        if use_batch_stats:
+            if full:
+                partial = kp.stem_conv_stats(img, w_stem)
+            else:
+                xc, partial = kp.stem_conv_fwd_stats(img, w_stem)
+            invstd, fp, count_dev = _batch_statistics(kp, img, 1, N, C, HW, mod, gamma, beta, group, world, partial)
+        else:
+            mean = mod.running_mean.float()
+            invstd = torch.rsqrt(mod.running_var.float() + mod.eps)
+            fp = kp.bn_affine(mean, invstd, gamma, beta)
+            if not full:
+                xc = kp.stem_conv_fwd(img, w_stem)
+        if full:
+            y, idx = kp.stem_conv_bn_relu_pool_fwd(img, w_stem, fp)
+        else:
+            y, idx = kp.bn_relu_pool_fwd(xc, fp)
+        ctx.save_for_backward(img, w_stem, idx, weight, bias, invstd, fp, count_dev, xc)
+        ctx.cfg = (N, C, HW, use_batch_stats, group, world)
+        ctx.wparam = w_stem
+        return y
+
+    @staticmethod
+    def backward(ctx, dpool):
+        kp = K.provider()
+        img, w_stem, idx, weight, bias, invstd, fp, count_dev, xc = ctx.saved_tensors
+        N, C, HW, use_batch_stats, group, world = ctx.cfg
+        if dpool.dtype != torch.bfloat16:
+            dpool = dpool.to(torch.bfloat16)
+        dpool = dpool.contiguous(memory_format=torch.channels_last)
+        if xc is None:
+            partial, S = kp.stem_conv_bn_relu_pool_bwd_reduce(img, w_stem, dpool, idx, fp)
+        else:
+            partial, S = kp.bn_relu_pool_bwd_reduce(dpool, idx, xc, fp)
+        dgamma, dbeta, bp = _backward_pack(kp, partial, S, C, N * HW, invstd, fp, count_dev,
+                                           use_batch_stats, group, world, img.device, parity=False)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            from .convwrw import wrw_on_side_stream          # nothing but the optimizer waits for a stem's weight gradient
+            # y re-evaluated from the image (xc=None) unless TSG_STEM_WRW_READS_Y=1: reading the 537 MB back measured slower
+            # than the 22 MFMAs per tile that remake it (profiles/r06_stem_without_its_gradient.txt)
+            yy = xc if _STEM_WRW_READS_Y else None
+            dw = wrw_on_side_stream(lambda: kp.stem_conv_wrw_bn_pool(img, w_stem, dpool, idx, bp, xc=yy), ctx.wparam,
+                                    img, dpool, idx, bp, yy)
+        if weight is None:
+            dgamma = dbeta = None
+        else:
+            dgamma = dgamma.to(weight.dtype)
+            dbeta = dbeta.to(bias.dtype) if bias is not None else None
+        return None, dw, dgamma, dbeta, None, None, None, None
+
+
+# TSG_STEM_RECOMPUTE=2|1|0 (default 2): the ResNet stem as the one node above.  2: the stem activation is stored (forward and
+# backward sums read it) but its GRADIENT never is; 1: nothing of the stem is stored (every pass re-evaluates the
+# convolution: 1.05 ms against 0.94 ms, kept as evidence); 0: the three modules with their own nodes.
+_STEM_RECOMPUTE = int(os.environ.get("TSG_STEM_RECOMPUTE", "2"))
+_STEM_WRW_READS_Y = os.environ.get("TSG_STEM_WRW_READS_Y", "0") == "1"
+
+
+def stem_bn_relu_maxpool(conv, bn, img, pool):
+    """`pool(relu(bn(conv(img))))` (furnace/base_model/resnet.py:96-100,131-133) as the recomputing node when `conv` is our
+    3 -> 64 7x7/2 StemConv2d on the bf16 path, `bn` our SyncBatchNorm(64), `pool` MaxPool2d(3, 2, 1) and `img` an image that
+    needs no gradient; None otherwise (the caller then runs the modules one by one)."""
+    from .stemconv import StemConv2d, _as_bf16_image, _wants_bf16
+
+    def one(v):
+        return v[0] if isinstance(v, (tuple, list)) and len(set(v)) == 1 else v
+    if not (_STEM_RECOMPUTE > 0 and _FUSE_STEM_POOL and isinstance(conv, StemConv2d) and isinstance(bn, SyncBatchNorm)
+            and isinstance(pool, torch.nn.MaxPool2d) and isinstance(img, torch.Tensor) and img.is_cuda and img.dim() == 4
+            and not img.requires_grad and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.padding_mode == "zeros" and bn.num_features == 64 and bn.momentum is not None
+            and _wants_bf16(img)
+            and not (conv._forward_hooks or conv._forward_pre_hooks or bn._forward_hooks or bn._forward_pre_hooks
+                     or pool._forward_hooks or pool._forward_pre_hooks)):
+        return None
+    if (one(pool.kernel_size), one(pool.stride), one(pool.padding), one(pool.dilation)) != (3, 2, 1, 1) \
+            or pool.ceil_mode or pool.return_indices:
+        return None
+    kp = K.provider()
+    if not hasattr(kp, "stem_conv_bn_relu_pool_fwd"):
+        return None
+    xb = _as_bf16_image(img)
+    w_stem = conv.weight if conv.weight.is_contiguous() else conv.weight.contiguous()
+    if not kp.stem_conv_supported(xb, w_stem, conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups):
+        return None
+    if ((xb.shape[2] - 1) // 2 + 1) < 1 or ((xb.shape[3] - 1) // 2 + 1) < 1:
+        return None
+    use_batch_stats = bn.training or not bn.track_running_stats
+    with torch.autocast("cuda", enabled=False):
+        return _StemConvBnReluPoolFn.apply(xb, w_stem, bn.weight, bn.bias, bn, use_batch_stats, bn.process_group,
+                                           _STEM_RECOMPUTE == 1)
+
+
 _FUSE_STEM_POOL = os.environ.get("TSG_FUSE_STEM_POOL", "1") != "0"
 
 
