@@ -245,6 +245,8 @@ def fork_post_hook(mod, args, out):
         return None
     cur, side = st
     torch.cuda.set_stream(cur)
+    if isinstance(out, _Deferred):                      # its kernels go to `cur`, its operands were made on `side`
+        cur.wait_stream(side)
     out = _unwrap(out)
     if isinstance(out, torch.Tensor):
         import weakref
@@ -468,6 +470,13 @@ class FuseMode(TorchFunctionMode):
             self._hook.remove()
             self._hook = None
         out = super().__exit__(*exc)
+        if exc[0] is not None and _FORK_STACK:           # an exception inside a forked module: its post-hook never ran
+            for st in _FORK_STACK:
+                if st is not None:
+                    torch.cuda.set_stream(st[0])
+                    st[0].wait_stream(st[1])
+                    break
+            del _FORK_STACK[:]
         if _FORKED and MODE_DEPTH <= 0:                  # never consumed inside the forward: join before anybody else can
             for ref, side, cur in list(_FORKED.values()):
                 cur.wait_stream(side)

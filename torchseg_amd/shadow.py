@@ -9,7 +9,9 @@ Freshness: a shadow is valid for the version counter its parameter had when it w
 parameter through torch (load_state_dict, an eager optimizer, init functions) bumps that counter, and the next `get`
 refreshes.  FusedSGD updates parameters from its own kernel, which torch does not see — it therefore calls
 `after_external_update()` at the end of every step (also inside a captured graph, where the refresh launch is captured with
-the step)."""
+the step).  NOT seen: in-place writes through `.data` (`p.data.mul_()`, `p.data.copy_()`, an EMA swap) — torch does not bump
+the version counter for them.  Code that updates parameters that way must call
+`torchseg_amd.shadow.after_external_update(device)` afterwards, or run with TSG_WEIGHT_SHADOW=0."""
 import weakref
 
 import numpy as np
