@@ -780,6 +780,21 @@ int tsg_conv1x1_vec_supported(int B, int Cin, int Cout);
 int tsg_conv1x1_vec_fwd(const void* x, const float* w, void* y, int B, int Cin, int Cout, void* stream);
 int tsg_conv1x1_vec_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int B, int Cin, int Cout,
                         void* stream);
+/* The whole pooled layer in one launch per direction (round 6): convolution -> [BatchNorm over the batch] -> [ReLU | sigmoid]
+ * — `ConvBnRelu(C_in, C_out, 1, 1, 0, has_bn, has_relu)` on a [B, C, 1, 1] map and the `nn.Sigmoid()` that ends the attention
+ * branches (seg_oprs.py:199-205, :222-231; bisenet network.py:34-39).  bnmode 0 none / 1 batch statistics (running_mean /
+ * running_var / num_batches_tracked updated when given: momentum, unbiased variance, syncbn.py:86-98) / 2 running statistics;
+ * act 0 none / 1 ReLU / 2 sigmoid.  out: the layer's output bf16 [B, C_out]; yc: the convolution's output (bf16, what the
+ * unfused path stores between convolution and BatchNorm; bnmode != 0); stats fp32 [4][C_out] = {a = gamma invstd,
+ * b = beta - mean a, mean, invstd}.  Arithmetic and rounding points of tsg_conv1x1_vec_fwd -> tsg_bn_stats -> tsg_bn_finalize
+ * -> tsg_bn_apply_fwd -> at::sigmoid (the B-term sums directly in fp64).  Backward: dout = gradient w.r.t. out;
+ * dx (may be NULL), dw fp32, dgamma / dbeta fp32 [C_out] (bnmode != 0; may be NULL). */
+int tsg_conv1x1_vec_bnact_fwd(const void* x, const float* w, void* out, void* yc, float* stats, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                              float eps, float momentum, int bnmode, int act, int B, int Cin, int Cout, void* stream);
+int tsg_conv1x1_vec_bnact_bwd(const void* dout, const void* out, const void* yc, const float* stats, const void* x,
+                              const float* w, void* dx, float* dw, float* dgamma, float* dbeta, int bnmode, int act, int B,
+                              int Cin, int Cout, void* stream);
 
 /* ------------------------------------------------------------------------
  * DFN's border labels — replaces, on the GPU, lines 24-29 of model/dfn/cityscapes.dfn.R101_v1c/dataloader.py

@@ -171,6 +171,8 @@ _PROTOS = {
     "tsg_conv1x1_vec_supported": (_i, [_i, _i, _i]),
     "tsg_conv1x1_vec_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tsg_conv1x1_vec_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "tsg_conv1x1_vec_bnact_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _i, _i, _i, _p]),
+    "tsg_conv1x1_vec_bnact_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tsg_cls_head_supported": (_i, [_i, _i, _i, _i64]),
     "tsg_cls_head_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _p]),
     "tsg_cls_head_dgrad": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _p]),

@@ -47,6 +47,11 @@ class _ConvNormAct(nn.Module):
 
     @_fusion.outside_mode
     def forward(self, x):
+        if isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[2] == 1 and x.shape[3] == 1 and x.is_cuda:
+            from torchseg_amd.vecconv import pooled_layer
+            y = pooled_layer(self, x)                   # a pooled map: convolution + BatchNorm + ReLU as one launch
+            if y is not None:
+                return y
         mode = _fusion.CHAIN_ACTIVE
         if mode or isinstance(x, _fusion.PendingCbr):
             return self._forward_chain(x, mode)

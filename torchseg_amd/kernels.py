@@ -735,6 +735,37 @@ class HipKernels:
                 "tsg_conv1x1_vec_fwd")
         return y
 
+    def conv1x1_vec_bnact_fwd(self, x, weight, bnmode, act, gamma=None, beta=None, running_mean=None, running_var=None,
+                              num_batches_tracked=None, eps=1e-5, momentum=0.1):
+        """The pooled layer conv1x1 -> [BatchNorm over the batch] -> [ReLU | sigmoid] in one launch: x [B,Cin,1,1] bf16 ->
+        (out [B,Cout,1,1] bf16, yc = the convolution's output [B,Cout] bf16 or None, stats fp32 [4,Cout] or None)"""
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = weight.shape[0]
+        x, w = self._rows(x), self._rows(weight)
+        out = torch.empty((B, Cout, 1, 1), dtype=torch.bfloat16, device=x.device)
+        yc = torch.empty((B, Cout), dtype=torch.bfloat16, device=x.device) if bnmode else None
+        stats = torch.empty((4, Cout), dtype=torch.float32, device=x.device) if bnmode else None
+        L.check(self.lib.tsg_conv1x1_vec_bnact_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), L.ptr(yc), L.ptr(stats),
+                                                   L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var),
+                                                   L.ptr(num_batches_tracked), float(eps), float(momentum), int(bnmode),
+                                                   int(act), B, Cin, Cout, L.stream_ptr(x)), "tsg_conv1x1_vec_bnact_fwd")
+        return out, yc, stats
+
+    def conv1x1_vec_bnact_bwd(self, dout, out, yc, stats, x, weight, bnmode, act, need_dx=True):
+        """-> (dx bf16 [B,Cin,1,1] or None, dw fp32 like weight, dgamma, dbeta fp32 [Cout] or None)"""
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = weight.shape[0]
+        dout, out, x, w = self._rows(dout), self._rows(out), self._rows(x), self._rows(weight)
+        dx = torch.empty((B, Cin, 1, 1), dtype=torch.bfloat16, device=x.device) if need_dx else None
+        dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=x.device) if bnmode else None
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=x.device) if bnmode else None
+        L.check(self.lib.tsg_conv1x1_vec_bnact_bwd(dout.data_ptr(), out.data_ptr(), L.ptr(yc), L.ptr(stats), x.data_ptr(),
+                                                   w.data_ptr(), L.ptr(dx), dw.data_ptr(), L.ptr(dgamma), L.ptr(dbeta),
+                                                   int(bnmode), int(act), B, Cin, Cout, L.stream_ptr(x)),
+                "tsg_conv1x1_vec_bnact_bwd")
+        return dx, dw, dgamma, dbeta
+
     def conv1x1_vec_bwd(self, dy, x, weight, need_dx=True):
         """dy [B,Cout,1,1] bf16, x [B,Cin,1,1] bf16, weight fp32 -> (dx bf16 [B,Cin,1,1] or None, dw fp32 like weight)"""
         B, Cin = x.shape[0], x.shape[1]

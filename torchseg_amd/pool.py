@@ -19,6 +19,16 @@ _GAP_BWD_EXPAND = _os.environ.get("TSG_GAP_BWD_EXPAND", "1") != "0"
 _CAT = _os.environ.get("TSG_CAT", "1") != "0"
 
 
+def _scaled_pooled_gradient(dout, N, C, HW, dtype):
+    """dout / HW in `dtype`: the value of `(dout.float() * (1 / HW)).to(dtype)` — float product, one rounding — in ONE launch
+    when dout already has that dtype (a bf16 tensor times a Python scalar is evaluated in float and rounded once).  Under
+    graph replay every launch costs >= 4.8 us whatever it does; this triplet ran five times per step."""
+    d = dout.reshape(N, C)
+    if d.dtype == dtype:
+        return d * (1.0 / HW)
+    return (d.float() * (1.0 / HW)).to(dtype)
+
+
 class _GapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -44,7 +54,7 @@ class _GapFn(torch.autograd.Function):
             # + C values per sample instead of two full tensors, and gap_bwd's write of the full map disappears
             # (round 4: 4 launches + a third of 9 adds' traffic per BiSeNet step).  A consumer that needs a dense tensor
             # materialises it exactly as before.
-            g = (dout.reshape(N, C).float() * (1.0 / HW)).to(x.dtype)
+            g = _scaled_pooled_gradient(dout, N, C, HW, x.dtype)
             return g.view(N, C, 1, 1).expand(N, C, x.shape[2], x.shape[3])
         dout = dout.reshape(N, C).to(x.dtype).contiguous()
         return kp.gap_bwd(dout, x, layout, N, C, HW)
@@ -178,7 +188,7 @@ class _GapLinkedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         layout, N, C, HW, dtype, H, W = ctx.cfg
-        g = (dout.reshape(N, C).float() * (1.0 / HW)).to(dtype)            # what _GapFn.backward hands autograd, per pixel
+        g = _scaled_pooled_gradient(dout, N, C, HW, dtype)                 # what _GapFn.backward hands autograd, per pixel
         pend, ctx.link.pending = ctx.link.pending, None
         if pend is None:                                                   # the gate did not take part in this backward pass
             return g.view(N, C, 1, 1).expand(N, C, H, W), None
@@ -230,6 +240,26 @@ def _reaches(fn, target, limit=64):
     return False
 
 
+def _run_pooled_branch(mods, s):
+    """the modules of a squeeze-excite branch behind its pool, one after the other — except that a ConvBnRelu directly followed
+    by nn.Sigmoid runs with the sigmoid inside its fused pooled-layer launch (vecconv.pooled_layer) when that applies"""
+    from .vecconv import pooled_layer
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if (i + 1 < len(mods) and type(mods[i + 1]) is nn.Sigmoid and not mods[i + 1]._forward_hooks
+                and not mods[i + 1]._forward_pre_hooks and hasattr(m, "conv") and hasattr(m, "has_bn")
+                and isinstance(s, torch.Tensor)):
+            y = pooled_layer(m, s, sigmoid_after=True)
+            if y is not None:
+                s = y
+                i += 2
+                continue
+        s = m(s)
+        i += 1
+    return s
+
+
 def gated_scale(x, branch, add_identity=False):
     """`x * branch(x)` (+ x) where `branch` is an nn.Sequential that starts with a global average pool (seg_oprs.py:199-205,
     222-231): with the linked autograd nodes described above when x is a channels_last HIP map that needs a gradient, the
@@ -247,9 +277,7 @@ def gated_scale(x, branch, add_identity=False):
         return channel_scale(x, branch(x), add_identity)
     link = _GateLink()
     pooled = _GapLinkedFn.apply(x, link)
-    s = pooled
-    for m in mods[1:]:
-        s = m(s)
+    s = _run_pooled_branch(mods[1:], pooled)
     if not (isinstance(s, torch.Tensor) and s.requires_grad and s.grad_fn is not None and pooled.grad_fn is not None
             and s.numel() == x.shape[0] * x.shape[1] and _reaches(s.grad_fn, pooled.grad_fn)):
         return channel_scale(x, s, add_identity)       # (the pool node then hands autograd its broadcast view, as before)

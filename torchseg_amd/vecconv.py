@@ -46,6 +46,90 @@ class PooledConv2d(nn.Conv2d):
         return super().forward(x)
 
 
+# TSG_POOLED_LAYER=1|0 (default 1, round 6): a ConvBnRelu on a pooled [B, C, 1, 1] map — convolution, BatchNorm over the batch,
+# ReLU, and the nn.Sigmoid that ends an attention branch — as ONE launch per direction (tsg_conv1x1_vec_bnact_*).  Under graph
+# replay every launch costs >= 4.8 us; these layers ran 9-10 launches each for 16 x C numbers.
+POOLED_LAYER = os.environ.get("TSG_POOLED_LAYER", "1") != "0"
+
+
+class _PooledLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, bnmode, act):
+        kp = K.provider()
+        if bnmode:
+            track = bn.track_running_stats
+            out, yc, stats = kp.conv1x1_vec_bnact_fwd(
+                x, weight, bnmode, act, gamma.float() if gamma is not None else None,
+                beta.float() if beta is not None else None,
+                bn.running_mean if track else None, bn.running_var if track else None,
+                bn.num_batches_tracked if (track and bnmode == 1) else None, bn.eps,
+                0.0 if bn.momentum is None else bn.momentum)
+        else:
+            out, yc, stats = kp.conv1x1_vec_bnact_fwd(x, weight, 0, act)
+        ctx.save_for_backward(x, weight, out, yc, stats, gamma, beta)
+        ctx.cfg = (bnmode, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out, yc, stats, gamma, beta = ctx.saved_tensors
+        bnmode, act = ctx.cfg
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        dx, dw, dgamma, dbeta = K.provider().conv1x1_vec_bnact_bwd(dout, out, yc, stats, x, weight, bnmode, act,
+                                                                   need_dx=ctx.needs_input_grad[0])
+        if gamma is None or not bnmode:
+            dgamma = None
+        else:
+            dgamma = dgamma.to(gamma.dtype)
+        if beta is None or not bnmode:
+            dbeta = None
+        else:
+            dbeta = dbeta.to(beta.dtype)
+        return dx, dw, dgamma, dbeta, None, None, None
+
+
+def pooled_layer(m, x, sigmoid_after=False):
+    """`m(x)` (and `torch.sigmoid` of it) for a ConvBnRelu-like module `m` (attributes conv, has_bn [bn], has_relu) on a pooled
+    [B, C, 1, 1] HIP map as one fused node, or None when anything about it is not the plain case (then the caller runs the
+    modules): conv a PooledConv2d, bn our single-process SyncBatchNorm, no hooks, bf16 path."""
+    if not (POOLED_LAYER and ENABLED and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.shape[2] == 1
+            and x.shape[3] == 1):
+        return None
+    conv = getattr(m, "conv", None)
+    if not isinstance(conv, PooledConv2d) or conv.weight.dtype != torch.float32:
+        return None
+    has_bn, has_relu = bool(getattr(m, "has_bn", False)), bool(getattr(m, "has_relu", False))
+    if has_relu and sigmoid_after:
+        return None
+    if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and x.dtype == torch.float32
+                                          and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return None
+    if m._forward_hooks or m._forward_pre_hooks or conv._forward_hooks or conv._forward_pre_hooks:
+        return None
+    bn, bnmode = None, 0
+    if has_bn:
+        from .syncbn import SyncBatchNorm, _world
+        bn = m.bn
+        if not isinstance(bn, SyncBatchNorm) or bn._forward_hooks or bn._forward_pre_hooks \
+                or bn.num_features != conv.out_channels:
+            return None
+        use_batch_stats = bn.training or not bn.track_running_stats
+        if use_batch_stats and (_world(bn.process_group) != 1 or x.shape[0] < 2 or bn.momentum is None):
+            return None                                # statistics cross ranks / the stock path raises its own error
+        bnmode = 1 if use_batch_stats else 2
+        if has_relu and (m.relu._forward_hooks or m.relu._forward_pre_hooks):
+            return None
+    xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    kp = K.provider()
+    if not (hasattr(kp, "conv1x1_vec_bnact_fwd") and kp.conv1x1_vec_supported(xb, conv.weight)):
+        return None
+    act = 2 if sigmoid_after else (1 if has_relu else 0)
+    with torch.autocast("cuda", enabled=False):
+        return _PooledLayerFn.apply(xb, conv.weight, bn.weight if bn is not None else None,
+                                    bn.bias if bn is not None else None, bn, bnmode, act)
+
+
 def _eligible(m):
     return (isinstance(m, nn.Conv2d) and type(m).__name__ == "Conv2d" and m.kernel_size == (1, 1) and m.stride == (1, 1)
             and m.padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None
