@@ -47,7 +47,10 @@ def _backward_any_layout(dy, IH, IW):
             dy = dy.contiguous()
             lay = K.bn_layout(dy)
         layout, N, C, HW = lay
-        return (kp.gap_fwd(dy, layout, N, C, HW).float() * float(HW)).to(dy.dtype).view(N, C, 1, 1)
+        g = kp.gap_fwd(dy, layout, N, C, HW)
+        # mean x HW, float product and one rounding — a bf16 tensor times a Python scalar is exactly that in ONE launch
+        g = g * float(HW) if g.dtype == dy.dtype and g.dtype != torch.float32 else (g.float() * float(HW)).to(dy.dtype)
+        return g.view(N, C, 1, 1)
     if _is_cl_dense(dy) and _vec_ok(dy):
         return kp.upsample_bwd_nhwc(dy, IH, IW)
     if dy.dim() == 4 and dy.stride(1) == 1 and dy.shape[1] > 1 and _vec_ok(dy):
