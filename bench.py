@@ -579,6 +579,9 @@ def main():
                          "(the step is one linear graph: host cost 0.2 ms instead of 11-13 ms per step), 0 whenever "
                          "gradients are reduced (N > 1, TSG_FORCE_COLLECTIVES) or the optimizer is torch's; falls back to "
                          "eager, and says so in config.hip_graph_fallback, if the capture fails")
+    ap.add_argument("--mode-probe", type=int, default=6,
+                    help="with the default --graph (-1) on one GPU: time this many replayed and this many eagerly launched steps "
+                         "after the capture and run the timed region in the faster mode (config.mode_probe); 0 = always replay")
     ap.add_argument("--forced-steps", type=int, default=10,
                     help="after everything else (rank 0, N = 1): time this many steps of the N > 1 CODE PATH on one rank "
                          "(TSG_FORCE_COLLECTIVES=1 in a process of its own: SyncBN exchanges + gradient buckets through "
@@ -647,9 +650,11 @@ def main():
     ensure_furnace_on_path()
     from engine.lr_policy import PolyLR
 
+    auto_mode = args.graph < 0
     if args.graph < 0:
         args.graph = 2 if (world == 1 and not force_coll and args.optimizer == "fused") else 0
     use_graph = bool(args.graph)
+    mode_probe = None
     graph_fallback = None
     model, opt, base_lr = build_model(device, args.batch, args.size, ProbOhemCrossEntropy2d, SyncBatchNorm,
                                       seed=12345 if world == 1 else local_rank,       # train.py:37-40
@@ -715,11 +720,38 @@ def main():
                 for it in range(2):
                     loss = train_step(model, opt, batch, pol, n_eager + it, world)
                 sync()
+        replay = graphed is not None
+        if graphed is not None and auto_mode and args.mode_probe > 0:
+            # The replayed graph is ONE stream: host cost 0.2 ms, no overlap.  The eager step forks the weight gradients and the
+            # two auxiliary heads onto side streams (VALU-bound criteria beside matrix-core-bound convolutions: +2-4 %) but needs
+            # the host to enqueue ~400 launches in less than the GPU takes for them — which holds on some boxes and not on
+            # others (host 9-13 ms against a 12.2-13 ms step).  Same kernels, same arithmetic either way: time both, keep the faster.
+            def _time(fn, n):
+                sync()
+                t = time.perf_counter()
+                for i in range(n):
+                    fn(i)
+                sync()
+                return (time.perf_counter() - t) / n * 1e3
+
+            def _replayed(i):
+                set_lr(opt, pol, n_eager + 2 + i)
+                graphed()
+
+            for i in range(2):
+                train_step(model, opt, batch, pol, n_eager + 2 + i, world)
+            ms_e = _time(lambda i: train_step(model, opt, batch, pol, n_eager + 4 + i, world), args.mode_probe)
+            ms_g = _time(_replayed, args.mode_probe)
+            replay = ms_g <= ms_e * 1.005
+            mode_probe = {"replayed_ms_per_step": round(ms_g, 3), "eager_ms_per_step": round(ms_e, 3), "steps": args.mode_probe,
+                          "chosen": "replay" if replay else "eager",
+                          "note": "timed region = the faster of hipGraph replay (one stream) and eager launches (weight gradients "
+                                  "and auxiliary heads on side streams); same kernels and results"}
         if graphed is None and dominant is not None:
             timer = K.KernelTimer(K.provider(), names=[dominant])
         t0 = time.perf_counter()
         for it in range(args.steps):
-            if graphed is not None:
+            if replay:
                 set_lr(opt, pol, args.warmup + it)
                 loss = graphed()
             else:
@@ -880,7 +912,8 @@ def main():
                        "labels": args.labels, "labels_i64": i64_rec,
                        "global_batch": global_batch, "per_rank_batch": args.batch, "parallelism": f"dp{world}",
                        "channels_last": model.channels_last, "final_loss": round(final_loss, 4),
-                       "hip_graph": bool(use_graph), "hip_graph_mode": int(args.graph) if use_graph else 0,
+                       "hip_graph": bool(use_graph and replay), "hip_graph_mode": int(args.graph) if (use_graph and replay) else 0,
+                       "mode_probe": mode_probe,
                        "hip_graph_fallback": graph_fallback, "eager_steps": eager_rec,
                        "forced_collectives": None, "optimizer": args.optimizer},
         }
@@ -893,8 +926,9 @@ def main():
             if timer is not roof_probe:
                 out["roofline"]["timed_region"] = timer.roofline(HBM_PEAK_GBS, os.path.join(ROOT, "profiles"))
                 out["roofline"]["timed_region"]["sampled"] = (
-                    "4 eagerly launched steps right behind the replayed region (the launches of a replayed hipGraph cannot be "
-                    "bracketed from the host; same kernels, same stream, same process)" if use_graph else
+                    "4 eagerly launched steps right behind the timed region (the launches of a replayed hipGraph cannot be "
+                    "bracketed from the host, and an eager timed region is left unbracketed: two event records per launch cost GPU "
+                    "time; same kernels, same process)" if use_graph else
                     "every 5th timed step; bracketed steps (and the instrumented warm-up step) keep the weight gradients on "
                     "the compute stream")
             out["kernels_last_warmup_step"] = all_kernels

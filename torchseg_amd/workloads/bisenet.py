@@ -23,15 +23,29 @@ import os as _os
 # backward).  Measured +1.4 % on two boxes and -0.2 % on a third once the weight gradients had their own side stream
 # (profiles/r05_small_ab.txt): opt-in.  The unchanged network.py gets the same through TSG_FORK_MODULES=spatial_path (ddp.py).
 _FORK_SPATIAL = _os.environ.get("TSG_FORK_SPATIAL", "0") == "1"
+# TSG_FORK_IN_GRAPH=1: keep the fork while the step is being captured into a hipGraph (ONE fork / join per direction)
+_FORK_IN_GRAPH = _os.environ.get("TSG_FORK_IN_GRAPH", "0") == "1"
+# TSG_FORK_HEADS=1|0 (default 1, round 6): the two auxiliary heads + their criteria on side streams of their own beside the main
+# head (they share nothing: network.py:103-108).  A fused head is VALU-bound (tsg_ohem_up_fwd / _bwd: 100-160 us with HBM and the
+# matrix cores idle), the 3x3 convolution in front of it is matrix-core bound: run side by side they fill each other's gaps —
+# eager step 1 247-1 258 -> 1 280-1 282 img/s on one box, 1 285 -> 1 315 on another (gpurun_out/r6b_call9/10.txt).  Eager launches
+# in a single process only: inside a captured hipGraph the same fork is SLOWER (1 268 -> 1 230: the runtime replays a graph with
+# parallel branches node by node), and with a process group the exchanges of three streams would interleave.
+_FORK_HEADS = _os.environ.get("TSG_FORK_HEADS", "1") == "1"
 _SIDE = {}
 
 
-def _side_stream(device):
+def _side_stream(device, which=0):
     import torch
-    s = _SIDE.get(device)
+    s = _SIDE.get((device, which))
     if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device=device)
+        s = _SIDE[(device, which)] = torch.cuda.Stream(device=device)
     return s
+
+
+def _single_process():
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def _cbr(cin, cout, k, s, p, norm_layer, relu=True):
@@ -102,7 +116,7 @@ class BiSeNet(nn.Module):
     def features(self, data):
         """-> [1/16 aux fm, 1/8 aux fm, fused 1/8 fm] (network.py:75-101)."""
         fork = None
-        if data.is_cuda and _FORK_SPATIAL and not torch.cuda.is_current_stream_capturing():
+        if data.is_cuda and _FORK_SPATIAL and (_FORK_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
             # the two paths share nothing until the fusion module: the detail branch (large maps: HBM-bound BatchNorm passes
             # and stems) runs on a side stream beside the context path's deep layers (small maps: matrix-core bound, too few
             # tiles to fill the chip on their own); autograd replays each node on its forward stream, so the backward
@@ -130,6 +144,22 @@ class BiSeNet(nn.Module):
     def forward(self, data, label=None):
         f16, f8, fused = self.features(data)
         if self.is_training:
+            if (data.is_cuda and _FORK_HEADS and (_FORK_IN_GRAPH or not torch.cuda.is_current_stream_capturing())
+                    and _single_process()):
+                cur = torch.cuda.current_stream(data.device)
+                aux = []
+                for which, (head, fm) in enumerate(((self.heads[0], f16), (self.heads[1], f8))):
+                    side = _side_stream(data.device, 1 + which)
+                    side.wait_stream(cur)
+                    fm.record_stream(side)
+                    label.record_stream(side)
+                    with torch.cuda.stream(side):
+                        aux.append(self.criterion(head(fm), label))
+                main = self.criterion(self.heads[-1](fused), label)
+                for which, l in enumerate(aux):
+                    cur.wait_stream(_side_stream(data.device, 1 + which))
+                    l.record_stream(cur)
+                return main + aux[0] + aux[1]                  # network.py:108
             aux0 = self.criterion(self.heads[0](f16), label)
             aux1 = self.criterion(self.heads[1](f8), label)
             main = self.criterion(self.heads[-1](fused), label)
