@@ -44,8 +44,10 @@ def _side_stream(device, which=0):
 
 
 def _single_process():
+    """no process group at all: with one (even of a single rank: TSG_FORCE_COLLECTIVES) the SyncBN exchanges of three streams
+    would be issued on one communicator concurrently"""
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    return not (dist.is_available() and dist.is_initialized())
 
 
 def _cbr(cin, cout, k, s, p, norm_layer, relu=True):
