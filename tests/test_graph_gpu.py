@@ -66,3 +66,44 @@ def test_graph_replay_trajectory_equals_eager(cuda, mode, fused, fork):
     # gradients through the 1x1-map BN layers); at the bench shape graph and eager agree to 1e-3 over 50 steps
     assert np.allclose(graph, eager, rtol=2e-2, atol=0), (graph, eager)
     assert graph[-1] < graph[0]
+
+
+def test_auxiliary_heads_on_side_streams_change_nothing(cuda):
+    """workloads/bisenet.py TSG_FORK_HEADS (round 6, the eager default): the two auxiliary heads and their criteria on side
+    streams of their own — forward and, through autograd, backward.  The kernels and their inputs are the same, only the stream
+    differs: loss and EVERY gradient equal the unforked step bit for bit (the weight-gradient side stream is on in both).  At
+    the BENCHED shape: at untuned shapes the vendor library's stride-2 forward is not reproducible between two plain runs
+    either (tests/test_dropin_gpu.py), which the first pair of runs here re-checks."""
+    import bench
+    from torchseg_amd.ddp import DistributedDataParallel
+    from torchseg_amd.losses import ProbOhemCrossEntropy2d
+    from torchseg_amd.syncbn import SyncBatchNorm
+    from torchseg_amd.workloads import bisenet as wb
+    B, S = 16, 1024
+    res = []
+    old = wb._FORK_HEADS
+    try:
+        for fork in (False, False, True):
+            wb._FORK_HEADS = fork
+            model, opt, base_lr = bench.build_model(cuda, B, S, ProbOhemCrossEntropy2d, SyncBatchNorm, fused_sgd=True)
+            model = DistributedDataParallel(model, compute_dtype=torch.bfloat16)
+            model.train()
+            imgs, gts = bench.synthetic_batch(cuda, B, S)
+            losses = []
+            for it in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = model(imgs, gts)
+                loss.backward()
+                torch.cuda.synchronize()
+                losses.append(loss.item())
+                grads = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+                opt.step()
+            res.append((losses, grads))
+            del model, opt
+            torch.cuda.empty_cache()
+    finally:
+        wb._FORK_HEADS = old
+    plain0, plain1, forked = res
+    assert plain0[0] == plain1[0] and all(torch.equal(a, b) for a, b in zip(plain0[1], plain1[1])), "two plain runs differ"
+    assert forked[0] == plain0[0], (forked[0], plain0[0])
+    assert len(forked[1]) == len(plain0[1]) and all(torch.equal(a, b) for a, b in zip(forked[1], plain0[1]))
