@@ -163,13 +163,16 @@ def serial_kernels(on=True):
     would contain the kernel it shares the chip with, and the per-kernel roofline figures would be those of a time-shared
     GPU (round 5: SyncBN 0.60 -> 0.47 of the HBM peak, weight gradients 0.28 -> 0.15 of the MFMA peak, their sum > the step)."""
     from torchseg_amd import convwrw
-    old = convwrw._WRW_STREAM
+    from torchseg_amd.workloads import bisenet as _wb
+    old, old_heads = convwrw._WRW_STREAM, _wb._FORK_HEADS
     if on:
         convwrw._WRW_STREAM = False
+        _wb._FORK_HEADS = False                        # (round 6) the auxiliary heads' side streams likewise
     try:
         yield
     finally:
         convwrw._WRW_STREAM = old
+        _wb._FORK_HEADS = old_heads
 
 
 def step_body(model, opt, batch, world, with_optimizer=True):
