@@ -229,6 +229,77 @@ class GraphedStep(object):
         return self.loss
 
 
+class SegmentedStep(object):
+    """The same step as FIVE linear hipGraphs instead of one: trunk forward | the three heads (forward + criterion + backward,
+    each on a stream of its own, replayed side by side) | trunk backward + optimizer.  A captured graph with parallel BRANCHES is
+    replayed node by node by the runtime (slower than the single-stream graph), but linear graphs launched on
+    different streams overlap like eager launches do: the VALU-bound fused heads run beside each other's matrix-core-bound
+    convolutions, at a host cost of five graph launches.  The autograd graph is cut at the heads' inputs (detached leaves whose
+    gradients are handed to `torch.autograd.backward` of the trunk): every kernel and every operand is the one the whole-step
+    graph runs, so losses and gradients are the same bit for bit.  Our own BiSeNet builder only (features() / heads)."""
+
+    @staticmethod
+    def applies(model, world):
+        net = getattr(model, "module", model)
+        return (world == 1 and not dist.is_initialized() and hasattr(net, "features") and hasattr(net, "heads")
+                and len(getattr(net, "heads", ())) == 3 and getattr(net, "is_training", False)
+                and not getattr(model, "fuse_chain", False))
+
+    def __init__(self, model, opt, batch):
+        from torchseg_amd.workloads import bisenet as wb
+        net = model.module
+        data, label = batch
+        dev = data.device
+        self.opt = opt
+        self.s0 = GraphedStep.capture_stream()
+        self.sides = [wb._side_stream(dev, 1), wb._side_stream(dev, 2)]
+        self.gA, self.gB, self.gM = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.gH = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        pool0 = torch.cuda.graph_pool_handle()
+        cdt = getattr(model, "compute_dtype", torch.bfloat16)
+        ac = lambda: torch.autocast("cuda", dtype=cdt)
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.gA, pool=pool0, stream=self.s0):
+            opt.zero_grad()
+            with ac():
+                feats = net.features(data)
+            leaves = [t.detach().requires_grad_(True) for t in feats]
+        self.keep = [feats, leaves]
+        losses = [None, None, None]
+        for i, side in enumerate(self.sides):              # auxiliary heads: graphs (and memory pools) of their own
+            side.wait_stream(self.s0)
+            with torch.cuda.graph(self.gH[i], stream=side):
+                with ac():
+                    losses[i] = net.criterion(net.heads[i](leaves[i]), label)
+                losses[i].backward()
+        with torch.cuda.graph(self.gM, pool=pool0, stream=self.s0):
+            with ac():
+                losses[2] = net.criterion(net.heads[-1](leaves[2]), label)
+            losses[2].backward()
+        for side in self.sides:
+            self.s0.wait_stream(side)
+        with torch.cuda.graph(self.gB, pool=pool0, stream=self.s0):
+            torch.autograd.backward(list(feats), [l.grad for l in leaves])
+            self.loss = losses[2].detach() + losses[0].detach() + losses[1].detach()
+            opt.step()
+        self.keep.append(losses)
+
+    def __call__(self):
+        s0 = self.s0
+        with torch.cuda.stream(s0):
+            self.gA.replay()
+        for side, g in zip(self.sides, self.gH):
+            side.wait_stream(s0)
+            with torch.cuda.stream(side):
+                g.replay()
+        with torch.cuda.stream(s0):
+            self.gM.replay()
+            for side in self.sides:
+                s0.wait_stream(side)
+            self.gB.replay()
+        return self.loss
+
+
 def _cpu_leg(size, batch, cores, budget_s, max_steps, config="bisenet", warm=True):
     """img/s of the oracle network (1 untimed warm-up step, then steps until `budget_s` or `max_steps`)."""
     from oracle.focal_ref import SigmoidFocalLoss as OracleFocal
@@ -724,6 +795,21 @@ def main():
                     loss = train_step(model, opt, batch, pol, n_eager + it, world)
                 sync()
         replay = graphed is not None
+        segmented = None
+        if graphed is not None and auto_mode and args.mode_probe > 0 and os.environ.get("TSG_SEGMENTED_GRAPH", "1") != "0" \
+                and SegmentedStep.applies(model, world):
+            try:
+                segmented = SegmentedStep(model, opt, batch)
+                for it in range(2):
+                    set_lr(opt, pol, n_eager + it)
+                    lseg = segmented()
+                sync()
+                if not bool(torch.isfinite(lseg.detach()).all()):
+                    raise RuntimeError("non-finite loss after two segmented replays")
+            except Exception as e:                                         # noqa: BLE001 - the other two modes are always there
+                graph_fallback = "segmented: %s: %s" % (type(e).__name__, str(e)[:160])
+                segmented = None
+                torch.cuda.synchronize()
         if graphed is not None and auto_mode and args.mode_probe > 0:
             # The replayed graph is ONE stream: host cost 0.2 ms, no overlap.  The eager step forks the weight gradients and the
             # two auxiliary heads onto side streams (VALU-bound criteria beside matrix-core-bound convolutions: +2-4 %) but needs
@@ -745,11 +831,22 @@ def main():
                 train_step(model, opt, batch, pol, n_eager + 2 + i, world)
             ms_e = _time(lambda i: train_step(model, opt, batch, pol, n_eager + 4 + i, world), args.mode_probe)
             ms_g = _time(_replayed, args.mode_probe)
+            ms_s, ms_whole = None, ms_g
+            if segmented is not None:
+                def _seg(i):
+                    set_lr(opt, pol, n_eager + 2 + i)
+                    segmented()
+                ms_s = _time(_seg, args.mode_probe)
+                if ms_s < ms_g:                            # the five-graph form of the replayed step takes its place
+                    graphed, ms_g = segmented, ms_s
             replay = ms_g <= ms_e * 1.005
             mode_probe = {"replayed_ms_per_step": round(ms_g, 3), "eager_ms_per_step": round(ms_e, 3), "steps": args.mode_probe,
-                          "chosen": "replay" if replay else "eager",
-                          "note": "timed region = the faster of hipGraph replay (one stream) and eager launches (weight gradients "
-                                  "and auxiliary heads on side streams); same kernels and results"}
+                          "whole_graph_ms_per_step": round(ms_whole, 3),
+                          "segmented_ms_per_step": None if ms_s is None else round(ms_s, 3),
+                          "chosen": ("replay" if graphed is not segmented else "segmented replay") if replay else "eager",
+                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (trunk / three heads "
+                                  "/ trunk backward as five linear graphs, the heads side by side) and eager launches (weight "
+                                  "gradients and auxiliary heads on side streams); same kernels and results"}
         if graphed is None and dominant is not None:
             timer = K.KernelTimer(K.provider(), names=[dominant])
         t0 = time.perf_counter()

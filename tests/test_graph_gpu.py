@@ -107,3 +107,49 @@ def test_auxiliary_heads_on_side_streams_change_nothing(cuda):
     assert plain0[0] == plain1[0] and all(torch.equal(a, b) for a, b in zip(plain0[1], plain1[1])), "two plain runs differ"
     assert forked[0] == plain0[0], (forked[0], plain0[0])
     assert len(forked[1]) == len(plain0[1]) and all(torch.equal(a, b) for a, b in zip(forked[1], plain0[1]))
+
+
+def test_five_linear_graphs_replay_the_same_trajectory_as_one(cuda):
+    """bench.SegmentedStep (round 6): trunk forward | three heads side by side | trunk backward + optimizer as five linear
+    hipGraphs, the autograd graph cut at the heads' inputs — against bench.GraphedStep (one graph) at the benched shape, same
+    seed, 6 optimizer steps each: the same kernels on the same operands, so the losses agree bit for bit."""
+    import bench
+    from torchseg_amd.ddp import DistributedDataParallel
+    from torchseg_amd.losses import ProbOhemCrossEntropy2d
+    from torchseg_amd.syncbn import SyncBatchNorm
+    from torchseg_amd.workloads import ensure_furnace_on_path
+    ensure_furnace_on_path()
+    from engine.lr_policy import PolyLR
+    B, S, warm, steps = 16, 1024, 3, 6
+    out = {}
+    for seg in (False, True):
+        model, opt, base_lr = bench.build_model(cuda, B, S, ProbOhemCrossEntropy2d, SyncBatchNorm, fused_sgd=True)
+        model = DistributedDataParallel(model, compute_dtype=torch.bfloat16)
+        model.train()
+        batch = bench.synthetic_batch(cuda, B, S)
+        pol = PolyLR(base_lr, 0.9, 1000)
+        stream = bench.GraphedStep.capture_stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        losses = []
+        with torch.cuda.stream(stream):
+            for it in range(warm):
+                bench.train_step(model, opt, batch, pol, it, 1)
+            torch.cuda.synchronize()
+            if seg:
+                assert bench.SegmentedStep.applies(model, 1)
+                step = bench.SegmentedStep(model, opt, batch)
+            else:
+                step = bench.GraphedStep(model, opt, batch, 1, opt_inside=True)
+            for it in range(steps):
+                bench.set_lr(opt, pol, warm + it)
+                loss = step()
+                torch.cuda.synchronize()
+                losses.append(loss.item())
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        out[seg] = losses
+        del step, model, opt
+        torch.cuda.empty_cache()
+    print("one graph  ", out[False], "\nfive graphs", out[True])
+    assert np.isfinite(out[True]).all()
+    assert out[True] == out[False], (out[True], out[False])
