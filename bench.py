@@ -164,15 +164,17 @@ def serial_kernels(on=True):
     GPU (round 5: SyncBN 0.60 -> 0.47 of the HBM peak, weight gradients 0.28 -> 0.15 of the MFMA peak, their sum > the step)."""
     from torchseg_amd import convwrw
     from torchseg_amd.workloads import bisenet as _wb
-    old, old_heads = convwrw._WRW_STREAM, _wb._FORK_HEADS
+    old, old_heads, old_sp = convwrw._WRW_STREAM, _wb._FORK_HEADS, _wb._FORK_SPATIAL
     if on:
         convwrw._WRW_STREAM = False
-        _wb._FORK_HEADS = False                        # (round 6) the auxiliary heads' side streams likewise
+        _wb._FORK_HEADS = False                        # (round 6) the auxiliary heads' and the detail branch's side streams likewise
+        _wb._FORK_SPATIAL = False
     try:
         yield
     finally:
         convwrw._WRW_STREAM = old
         _wb._FORK_HEADS = old_heads
+        _wb._FORK_SPATIAL = old_sp
 
 
 def step_body(model, opt, batch, world, with_optimizer=True):

@@ -81,10 +81,11 @@ def test_auxiliary_heads_on_side_streams_change_nothing(cuda):
     from torchseg_amd.workloads import bisenet as wb
     B, S = 16, 1024
     res = []
-    old = wb._FORK_HEADS
+    old = (wb._FORK_HEADS, wb._FORK_SPATIAL, wb._FORK_SPATIAL_MODE)
     try:
         for fork in (False, False, True):
-            wb._FORK_HEADS = fork
+            wb._FORK_HEADS = wb._FORK_SPATIAL = fork       # the detail branch behind layer1 on head 0's stream as well
+            wb._FORK_SPATIAL_MODE = 2 if fork else 0
             model, opt, base_lr = bench.build_model(cuda, B, S, ProbOhemCrossEntropy2d, SyncBatchNorm, fused_sgd=True)
             model = DistributedDataParallel(model, compute_dtype=torch.bfloat16)
             model.train()
@@ -102,7 +103,7 @@ def test_auxiliary_heads_on_side_streams_change_nothing(cuda):
             del model, opt
             torch.cuda.empty_cache()
     finally:
-        wb._FORK_HEADS = old
+        wb._FORK_HEADS, wb._FORK_SPATIAL, wb._FORK_SPATIAL_MODE = old
     plain0, plain1, forked = res
     assert plain0[0] == plain1[0] and all(torch.equal(a, b) for a, b in zip(plain0[1], plain1[1])), "two plain runs differ"
     assert forked[0] == plain0[0], (forked[0], plain0[0])

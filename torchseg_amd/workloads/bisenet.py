@@ -19,10 +19,15 @@ from seg_opr.seg_oprs import AttentionRefinement, ConvBnRelu, FeatureFusion, cbr
 
 
 import os as _os
-# TSG_FORK_SPATIAL=0|1 (default 0): SpatialPath on a side HIP stream beside the context path (forward and, through autograd,
-# backward).  Measured +1.4 % on two boxes and -0.2 % on a third once the weight gradients had their own side stream
-# (profiles/r05_small_ab.txt): opt-in.  The unchanged network.py gets the same through TSG_FORK_MODULES=spatial_path (ddp.py).
-_FORK_SPATIAL = _os.environ.get("TSG_FORK_SPATIAL", "0") == "1"
+# TSG_FORK_SPATIAL=2|3|1|0 (default 2, round 6): SpatialPath on a side HIP stream beside the context path (forward and, through
+# autograd, backward) — 1: from the start (round 5: +1.4 % / -0.2 %, the context path's stem and layer1 are as HBM-bound as the
+# detail branch); 2 / 3: started behind the context path's layer1 / layer2, beside the matrix-core-bound deep layers: eager
+# 12.43-12.62 -> 12.20-12.29 ms (gpurun_out/r6b_call14.txt).  The stream is auxiliary head 0's: HIP maps a process's streams onto
+# four hardware queues (compute, weight gradients, two heads) and a fifth stream shares one of them — which is why the fork
+# measured nothing while it had a stream of its own.  Eager launches only (see TSG_FORK_HEADS); the unchanged network.py gets the
+# early fork through TSG_FORK_MODULES=spatial_path (ddp.py).
+_FORK_SPATIAL_MODE = int(_os.environ.get("TSG_FORK_SPATIAL", "2"))     # 1: from the start; 2: behind the context path's layer1
+_FORK_SPATIAL = _FORK_SPATIAL_MODE > 0
 # TSG_FORK_IN_GRAPH=1: keep the fork while the step is being captured into a hipGraph (ONE fork / join per direction)
 _FORK_IN_GRAPH = _os.environ.get("TSG_FORK_IN_GRAPH", "0") == "1"
 # TSG_FORK_HEADS=1|0 (default 1, round 6): the two auxiliary heads + their criteria on side streams of their own beside the main
@@ -118,20 +123,40 @@ class BiSeNet(nn.Module):
     def features(self, data):
         """-> [1/16 aux fm, 1/8 aux fm, fused 1/8 fm] (network.py:75-101)."""
         fork = None
-        if data.is_cuda and _FORK_SPATIAL and (_FORK_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
+        late = _FORK_SPATIAL_MODE >= 2
+        can_fork = (data.is_cuda and _FORK_SPATIAL and (_FORK_IN_GRAPH or not torch.cuda.is_current_stream_capturing())
+                    and _single_process())
+
+        def run_spatial():
             # the two paths share nothing until the fusion module: the detail branch (large maps: HBM-bound BatchNorm passes
-            # and stems) runs on a side stream beside the context path's deep layers (small maps: matrix-core bound, too few
-            # tiles to fill the chip on their own); autograd replays each node on its forward stream, so the backward
-            # overlaps the same way
+            # and stems) on a side stream beside the context path's deep layers (small maps: matrix-core bound, too few tiles
+            # to fill the chip on their own); autograd replays each node on its forward stream, so the backward overlaps the
+            # same way.  The stream is auxiliary head 0's (idle until the heads): a FIFTH stream would share a hardware queue.
             cur = torch.cuda.current_stream(data.device)
-            fork = _side_stream(data.device)
-            fork.wait_stream(cur)
-            data.record_stream(fork)
-            with torch.cuda.stream(fork):
-                spatial_out = self.spatial_path(data)
+            side = _side_stream(data.device, 1)
+            side.wait_stream(cur)
+            data.record_stream(side)
+            with torch.cuda.stream(side):
+                out = self.spatial_path(data)
+            return out, cur, side
+
+        if can_fork and not late:
+            spatial_out, cur, fork = run_spatial()
+        if can_fork and late:
+            # the context path's stem and layer1 are HBM-bound like the detail branch: start the branch behind them
+            cp = self.context_path
+            c2 = cp.layer1(cp._stem(data))
+            if _FORK_SPATIAL_MODE == 2:
+                spatial_out, cur, fork = run_spatial()
+            c3 = cp.layer2(c2)
+            if _FORK_SPATIAL_MODE == 3:
+                spatial_out, cur, fork = run_spatial()
+            c4 = cp.layer3(c3)
+            c5 = cp.layer4(c4)
         else:
-            spatial_out = self.spatial_path(data)
-        c2, c3, c4, c5 = self.context_path(data)
+            if fork is None:
+                spatial_out = self.spatial_path(data)
+            c2, c3, c4, c5 = self.context_path(data)
         last_fm = _up(self.global_context(c5), size=c5.shape[2:])
         outs = []
         for fm, nxt, arm, refine in zip((c5, c4), (c4, c3), self.arms, self.refines):
