@@ -232,18 +232,20 @@ class GraphedStep(object):
 
 
 class SegmentedStep(object):
-    """The same step as FIVE linear hipGraphs instead of one: trunk forward | the three heads (forward + criterion + backward,
-    each on a stream of its own, replayed side by side) | trunk backward + optimizer.  A captured graph with parallel BRANCHES is
-    replayed node by node by the runtime (slower than the single-stream graph), but linear graphs launched on
-    different streams overlap like eager launches do: the VALU-bound fused heads run beside each other's matrix-core-bound
-    convolutions, at a host cost of five graph launches.  The autograd graph is cut at the heads' inputs (detached leaves whose
-    gradients are handed to `torch.autograd.backward` of the trunk): every kernel and every operand is the one the whole-step
-    graph runs, so losses and gradients are the same bit for bit.  Our own BiSeNet builder only (features() / heads)."""
+    """The same step as ELEVEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
+    overlaps under replay too (a captured graph with parallel BRANCHES is replayed node by node by the runtime and is slower than
+    the single-stream graph; linear graphs on different streams overlap like eager launches):
+        s0: context head | context tail ............. | fusion | main head (fwd+loss+bwd) | fusion bwd | context bwd | optimizer
+        s1:              | detail branch (SpatialPath) |        | aux head 0               |            | detail bwd  |
+        s2:                                                     | aux head 1               |
+    The autograd graph is cut at the heads' and the fusion module's inputs (detached leaves whose gradients are handed to
+    `torch.autograd.backward` of the segment in front): every kernel and every operand is the one the one-graph step runs, so
+    losses and gradients are the same bit for bit.  Our own BiSeNet builder only (context_head / context_tail / heads)."""
 
     @staticmethod
     def applies(model, world):
         net = getattr(model, "module", model)
-        return (world == 1 and not dist.is_initialized() and hasattr(net, "features") and hasattr(net, "heads")
+        return (world == 1 and not dist.is_initialized() and hasattr(net, "context_tail") and hasattr(net, "heads")
                 and len(getattr(net, "heads", ())) == 3 and getattr(net, "is_training", False)
                 and not getattr(model, "fuse_chain", False))
 
@@ -253,52 +255,89 @@ class SegmentedStep(object):
         data, label = batch
         dev = data.device
         self.opt = opt
-        self.s0 = GraphedStep.capture_stream()
-        self.sides = [wb._side_stream(dev, 1), wb._side_stream(dev, 2)]
-        self.gA, self.gB, self.gM = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        self.gH = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        pool0 = torch.cuda.graph_pool_handle()
+        s0 = self.s0 = GraphedStep.capture_stream()
+        s1, s2 = self.s1, self.s2 = wb._side_stream(dev, 1), wb._side_stream(dev, 2)
+        G = torch.cuda.CUDAGraph
+        self.g = {k: G() for k in ("a1", "sp", "a2", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx", "opt")}
+        g = self.g
+        p0, p1 = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()      # s0's graphs / s1's graphs share a pool each
         cdt = getattr(model, "compute_dtype", torch.bfloat16)
         ac = lambda: torch.autocast("cuda", dtype=cdt)
+        leaf = lambda t: t.detach().requires_grad_(True)
         opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.gA, pool=pool0, stream=self.s0):
+        with torch.cuda.graph(g["a1"], pool=p0, stream=s0):
             opt.zero_grad()
             with ac():
-                feats = net.features(data)
-            leaves = [t.detach().requires_grad_(True) for t in feats]
-        self.keep = [feats, leaves]
+                c2 = net.context_head(data)
+        s1.wait_stream(s0)
+        with torch.cuda.graph(g["sp"], pool=p1, stream=s1):
+            with ac():
+                sp = net.spatial_path(data)
+        with torch.cuda.graph(g["a2"], pool=p0, stream=s0):
+            with ac():
+                f16, f8 = net.context_tail(c2)
+        s0.wait_stream(s1)
+        with torch.cuda.graph(g["ffm"], pool=p0, stream=s0):
+            sp_l, f8_ffm = leaf(sp), leaf(f8)
+            with ac():
+                fused = net.ffm(sp_l, f8_ffm)
+            leaves = [leaf(f16), leaf(f8), leaf(fused)]
         losses = [None, None, None]
-        for i, side in enumerate(self.sides):              # auxiliary heads: graphs (and memory pools) of their own
-            side.wait_stream(self.s0)
-            with torch.cuda.graph(self.gH[i], stream=side):
+        for i, (side, key, pool) in enumerate(((s1, "h0", p1), (s2, "h1", None))):
+            side.wait_stream(s0)
+            with torch.cuda.graph(g[key], pool=pool, stream=side):
                 with ac():
                     losses[i] = net.criterion(net.heads[i](leaves[i]), label)
                 losses[i].backward()
-        with torch.cuda.graph(self.gM, pool=pool0, stream=self.s0):
+        with torch.cuda.graph(g["hm"], pool=p0, stream=s0):
             with ac():
                 losses[2] = net.criterion(net.heads[-1](leaves[2]), label)
             losses[2].backward()
-        for side in self.sides:
-            self.s0.wait_stream(side)
-        with torch.cuda.graph(self.gB, pool=pool0, stream=self.s0):
-            torch.autograd.backward(list(feats), [l.grad for l in leaves])
+        with torch.cuda.graph(g["bffm"], pool=p0, stream=s0):
+            torch.autograd.backward([fused], [leaves[2].grad])
+        s0.wait_stream(s1)
+        s0.wait_stream(s2)
+        s1.wait_stream(s0)
+        with torch.cuda.graph(g["bsp"], pool=p1, stream=s1):
+            torch.autograd.backward([sp], [sp_l.grad])
+        with torch.cuda.graph(g["bctx"], pool=p0, stream=s0):
+            torch.autograd.backward([f16, f8, f8], [leaves[0].grad, leaves[1].grad, f8_ffm.grad])
+        s0.wait_stream(s1)
+        with torch.cuda.graph(g["opt"], pool=p0, stream=s0):
             self.loss = losses[2].detach() + losses[0].detach() + losses[1].detach()
             opt.step()
-        self.keep.append(losses)
+        self.keep = [c2, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses]
 
     def __call__(self):
-        s0 = self.s0
-        with torch.cuda.stream(s0):
-            self.gA.replay()
-        for side, g in zip(self.sides, self.gH):
-            side.wait_stream(s0)
-            with torch.cuda.stream(side):
-                g.replay()
-        with torch.cuda.stream(s0):
-            self.gM.replay()
-            for side in self.sides:
-                s0.wait_stream(side)
-            self.gB.replay()
+        g, s0, s1, s2 = self.g, self.s0, self.s1, self.s2
+        cs = torch.cuda.stream
+        with cs(s0):
+            g["a1"].replay()
+        s1.wait_stream(s0)
+        with cs(s1):
+            g["sp"].replay()
+        with cs(s0):
+            g["a2"].replay()
+            s0.wait_stream(s1)
+            g["ffm"].replay()
+        s1.wait_stream(s0)
+        s2.wait_stream(s0)
+        with cs(s1):
+            g["h0"].replay()
+        with cs(s2):
+            g["h1"].replay()
+        with cs(s0):
+            g["hm"].replay()
+            g["bffm"].replay()
+            s0.wait_stream(s1)                           # aux head 0's gradient (and s1 is free for the detail branch's backward)
+            s0.wait_stream(s2)
+        s1.wait_stream(s0)
+        with cs(s1):
+            g["bsp"].replay()
+        with cs(s0):
+            g["bctx"].replay()
+            s0.wait_stream(s1)
+            g["opt"].replay()
         return self.loss
 
 
@@ -846,9 +885,10 @@ def main():
                           "whole_graph_ms_per_step": round(ms_whole, 3),
                           "segmented_ms_per_step": None if ms_s is None else round(ms_s, 3),
                           "chosen": ("replay" if graphed is not segmented else "segmented replay") if replay else "eager",
-                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (trunk / three heads "
-                                  "/ trunk backward as five linear graphs, the heads side by side) and eager launches (weight "
-                                  "gradients and auxiliary heads on side streams); same kernels and results"}
+                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (eleven linear graphs "
+                                  "on three streams: detail branch beside the context path, the three heads side by side) and "
+                                  "eager launches (weight gradients, auxiliary heads and detail branch on side streams); same "
+                                  "kernels and results"}
         if graphed is None and dominant is not None:
             timer = K.KernelTimer(K.provider(), names=[dominant])
         t0 = time.perf_counter()

@@ -110,8 +110,8 @@ def test_auxiliary_heads_on_side_streams_change_nothing(cuda):
     assert len(forked[1]) == len(plain0[1]) and all(torch.equal(a, b) for a, b in zip(forked[1], plain0[1]))
 
 
-def test_five_linear_graphs_replay_the_same_trajectory_as_one(cuda):
-    """bench.SegmentedStep (round 6): trunk forward | three heads side by side | trunk backward + optimizer as five linear
+def test_segmented_replay_follows_the_same_trajectory_as_one_graph(cuda):
+    """bench.SegmentedStep (round 6): the step as eleven linear
     hipGraphs, the autograd graph cut at the heads' inputs — against bench.GraphedStep (one graph) at the benched shape, same
     seed, 6 optimizer steps each: the same kernels on the same operands, so the losses agree bit for bit."""
     import bench

@@ -145,27 +145,44 @@ class BiSeNet(nn.Module):
         if can_fork and late:
             # the context path's stem and layer1 are HBM-bound like the detail branch: start the branch behind them
             cp = self.context_path
-            c2 = cp.layer1(cp._stem(data))
+            c2 = self.context_head(data)
             if _FORK_SPATIAL_MODE == 2:
                 spatial_out, cur, fork = run_spatial()
-            c3 = cp.layer2(c2)
-            if _FORK_SPATIAL_MODE == 3:
+                outs = self.context_tail(c2)
+            else:
+                c3 = cp.layer2(c2)
                 spatial_out, cur, fork = run_spatial()
-            c4 = cp.layer3(c3)
-            c5 = cp.layer4(c4)
+                outs = self.context_tail(c2, c3)
         else:
             if fork is None:
                 spatial_out = self.spatial_path(data)
-            c2, c3, c4, c5 = self.context_path(data)
+            outs = self.context_tail(None, None, self.context_path(data))
+        if fork is not None:
+            cur.wait_stream(fork)
+            spatial_out.record_stream(cur)
+        outs.append(self.ffm(spatial_out, outs[-1]))
+        return outs
+
+    def context_head(self, data):
+        """stem + layer1 of the context path (what bench.SegmentedStep and the late fork above run in front of the detail branch)"""
+        cp = self.context_path
+        return cp.layer1(cp._stem(data))
+
+    def context_tail(self, c2, c3=None, blocks=None):
+        """layer2 .. layer4, global context, the two attention-refinement stages -> [1/16 fm, 1/8 fm] (network.py:76-99)"""
+        if blocks is None:
+            cp = self.context_path
+            if c3 is None:
+                c3 = cp.layer2(c2)
+            c4 = cp.layer3(c3)
+            c5 = cp.layer4(c4)
+        else:
+            c2, c3, c4, c5 = blocks
         last_fm = _up(self.global_context(c5), size=c5.shape[2:])
         outs = []
         for fm, nxt, arm, refine in zip((c5, c4), (c4, c3), self.arms, self.refines):
             last_fm = refine(add_then_upsample(arm(fm), last_fm, nxt.shape[2:]))   # network.py:91-95
             outs.append(last_fm)
-        if fork is not None:
-            cur.wait_stream(fork)
-            spatial_out.record_stream(cur)
-        outs.append(self.ffm(spatial_out, last_fm))
         return outs
 
     def forward(self, data, label=None):
