@@ -232,12 +232,12 @@ class GraphedStep(object):
 
 
 class SegmentedStep(object):
-    """The same step as ELEVEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
+    """The same step as THIRTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
     overlaps under replay too (a captured graph with parallel BRANCHES is replayed node by node by the runtime and is slower than
     the single-stream graph; linear graphs on different streams overlap like eager launches):
-        s0: context head | context tail ............. | fusion | main head (fwd+loss+bwd) | fusion bwd | context bwd | optimizer
-        s1:              | detail branch (SpatialPath) |        | aux head 0               |            | detail bwd  |
-        s2:                                                     | aux head 1               |
+        s0: context head | context tail ............. | fusion | main head (fwd+loss+bwd) | fusion bwd | context bwd, deep half | shallow half | optimizer
+        s1:              | detail branch (SpatialPath) |        | aux head 0               |            | detail-branch backward ...........  |
+        s2:                                                     | aux head 1               |                                     | deep half's weight gradients |
     The autograd graph is cut at the heads' and the fusion module's inputs (detached leaves whose gradients are handed to
     `torch.autograd.backward` of the segment in front): every kernel and every operand is the one the one-graph step runs, so
     losses and gradients are the same bit for bit.  Our own BiSeNet builder only (context_head / context_tail / heads)."""
@@ -258,12 +258,16 @@ class SegmentedStep(object):
         s0 = self.s0 = GraphedStep.capture_stream()
         s1, s2 = self.s1, self.s2 = wb._side_stream(dev, 1), wb._side_stream(dev, 2)
         G = torch.cuda.CUDAGraph
-        self.g = {k: G() for k in ("a1", "sp", "a2", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx", "opt")}
+        self.g = {k: G() for k in ("a1", "sp", "a2", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx_a", "wa", "bctx_b", "opt")}
         g = self.g
-        p0, p1 = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()      # s0's graphs / s1's graphs share a pool each
+        p0, p1, p2 = (torch.cuda.graph_pool_handle() for _ in range(3))             # one memory pool per stream's graphs
+        from torchseg_amd import convwrw
         cdt = getattr(model, "compute_dtype", torch.bfloat16)
         ac = lambda: torch.autocast("cuda", dtype=cdt)
         leaf = lambda t: t.detach().requires_grad_(True)
+        from torchseg_amd import kernels as K
+        K.provider().presize_scratch((s1, s2), dev)      # no scratch buffer may move between two captures on one stream
+        torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(g["a1"], pool=p0, stream=s0):
             opt.zero_grad()
@@ -275,7 +279,9 @@ class SegmentedStep(object):
                 sp = net.spatial_path(data)
         with torch.cuda.graph(g["a2"], pool=p0, stream=s0):
             with ac():
-                f16, f8 = net.context_tail(c2)
+                c3 = net.context_path.layer2(c2)
+                c3_l = leaf(c3)                          # the context backward is cut here: see bctx_a / wa / bctx_b below
+                f16, f8 = net.context_tail(c2, c3_l)
         s0.wait_stream(s1)
         with torch.cuda.graph(g["ffm"], pool=p0, stream=s0):
             sp_l, f8_ffm = leaf(sp), leaf(f8)
@@ -283,7 +289,7 @@ class SegmentedStep(object):
                 fused = net.ffm(sp_l, f8_ffm)
             leaves = [leaf(f16), leaf(f8), leaf(fused)]
         losses = [None, None, None]
-        for i, (side, key, pool) in enumerate(((s1, "h0", p1), (s2, "h1", None))):
+        for i, (side, key, pool) in enumerate(((s1, "h0", p1), (s2, "h1", p2))):
             side.wait_stream(s0)
             with torch.cuda.graph(g[key], pool=pool, stream=side):
                 with ac():
@@ -300,13 +306,28 @@ class SegmentedStep(object):
         s1.wait_stream(s0)
         with torch.cuda.graph(g["bsp"], pool=p1, stream=s1):
             torch.autograd.backward([sp], [sp_l.grad])
-        with torch.cuda.graph(g["bctx"], pool=p0, stream=s0):
-            torch.autograd.backward([f16, f8, f8], [leaves[0].grad, leaves[1].grad, f8_ffm.grad])
+        # context backward, deep half (layer3 / layer4, attention refinement: matrix-core bound).  Its twelve 3x3 weight gradients
+        # are not launched here: convwrw hands autograd their result tensors and lists the launches, which become a graph of
+        # their own (wa) replayed on s2 beside the shallow half (layer2 / layer1 / stem: HBM-bound passes over the large maps)
+        convwrw._DEFER = []
+        try:
+            with torch.cuda.graph(g["bctx_a"], pool=p0, stream=s0):
+                torch.autograd.backward([f16, f8, f8], [leaves[0].grad, leaves[1].grad, f8_ffm.grad])
+            deferred = convwrw._DEFER
+        finally:
+            convwrw._DEFER = None
+        s2.wait_stream(s0)
+        with torch.cuda.graph(g["wa"], pool=p2, stream=s2):
+            for fn, _ops, _buf in deferred:
+                fn()
+        with torch.cuda.graph(g["bctx_b"], pool=p0, stream=s0):
+            torch.autograd.backward([c3], [c3_l.grad])
         s0.wait_stream(s1)
+        s0.wait_stream(s2)
         with torch.cuda.graph(g["opt"], pool=p0, stream=s0):
             self.loss = losses[2].detach() + losses[0].detach() + losses[1].detach()
             opt.step()
-        self.keep = [c2, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses]
+        self.keep = [c2, c3, c3_l, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses, deferred]   # deferred: its operands are read by wa
 
     def __call__(self):
         g, s0, s1, s2 = self.g, self.s0, self.s1, self.s2
@@ -335,8 +356,14 @@ class SegmentedStep(object):
         with cs(s1):
             g["bsp"].replay()
         with cs(s0):
-            g["bctx"].replay()
+            g["bctx_a"].replay()
+        s2.wait_stream(s0)
+        with cs(s2):
+            g["wa"].replay()
+        with cs(s0):
+            g["bctx_b"].replay()
             s0.wait_stream(s1)
+            s0.wait_stream(s2)
             g["opt"].replay()
         return self.loss
 

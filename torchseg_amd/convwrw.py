@@ -129,7 +129,13 @@ def _kept_as_gradient(out, param):
     return all(a == b for a, b, n in zip(out.stride(), param.stride(), out.shape) if n != 1)
 
 
-def wrw_on_side_stream(fn, param, *operands):
+# A list while a caller wants the 3x3 weight gradients LAUNCHED LATER (bench.SegmentedStep: captured into a graph of their own that
+# replays on another stream beside the rest of the backward pass): wrw_on_side_stream then hands autograd the (still unwritten)
+# result tensor and appends the launch to the list.  The caller runs the list and keeps it alive as long as the operands are read.
+_DEFER = None
+
+
+def wrw_on_side_stream(fn, param, *operands, defer_out=None):
     """`fn()` (launches a weight-gradient kernel, returns its result tensor) on the side stream of the operands' device.
     `param`: the parameter the result is the gradient of.  Only a parameter WITHOUT a gradient takes the side stream:
     autograd's AccumulateGrad then just keeps the tensor; with a gradient already there (accumulation over several backward
@@ -139,6 +145,13 @@ def wrw_on_side_stream(fn, param, *operands):
     results on the compute stream — so a parameter that already has a side-stream result in this pass (`_wrw_pending`,
     cleared by the end-of-backward join) makes the compute stream wait for the side stream and computes the second one
     there.  A post-accumulate-grad hook that is not the DDP reducer's would read p.grad before the join."""
+    if _DEFER is not None and defer_out is not None:
+        Cout, Cin = defer_out
+        buf = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=operands[0].device, memory_format=torch.channels_last)
+        _DEFER.append((lambda: fn(out=buf), operands, buf))
+        # an ALIAS of its own: AccumulateGrad keeps an incoming gradient only when nobody else holds that tensor object, and
+        # clones it otherwise — the copy would be taken here, before the deferred launch has written anything
+        return buf.detach()
     if not _WRW_STREAM or not operands[0].is_cuda or param is None or not param.is_leaf or param.grad is not None \
             or param.dtype != torch.float32 or param._backward_hooks or _foreign_grad_hooks(param) \
             or (torch.cuda.is_current_stream_capturing() and not _WRW_IN_GRAPH):
@@ -280,7 +293,8 @@ class _ConvWrwFn(torch.autograd.Function):
                 dx = dx + dskip.to(dx.dtype)
             if sub is not None:                            # a data-gradient path without the compact addend
                 dx[:, :, ::2, ::2] += sub.to(dx.dtype)
-        dw = wrw_on_side_stream(lambda: K.provider().conv3x3_wrw(x, dy, stride=ctx.stride), ctx.wparam, x, dy)
+        dw = wrw_on_side_stream(lambda out=None: K.provider().conv3x3_wrw(x, dy, stride=ctx.stride, out=out), ctx.wparam, x, dy,
+                                defer_out=(dy.shape[1], x.shape[1]))
         return dx, dw.to(ctx.wdtype), None, None, None, None, None
 
 
@@ -340,7 +354,8 @@ class _ConvGenFn(torch.autograd.Function):
                 dx = F.conv2d(dy, kp.conv3x3_weight_rot180_t(weight.detach().to(torch.bfloat16)), None, 1, 1)
             if dskip is not None:
                 dx = dx + dskip.to(dx.dtype)
-        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=1), weight, x, dy)
+        dw = wrw_on_side_stream(lambda out=None: kp.conv3x3_wrw(x, dy, stride=1, out=out), weight, x, dy,
+                                defer_out=(dy.shape[1], x.shape[1]))
         return dx, dw.to(weight.dtype), None, None
 
 
@@ -499,7 +514,8 @@ class _BnReluConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp), ctx.wparam, x, dy, fp)
+        dw = wrw_on_side_stream(lambda out=None: kp.conv3x3_wrw(x, dy, stride=stride, in_ab=fp, out=out), ctx.wparam, x, dy, fp,
+                                defer_out=(dy.shape[1], x.shape[1]))
         if gen:                                                  # wb is the fp32 master weight here
             da = kp.conv3x3_gen_fwd(dy, kp.conv3x3_gen_prep_filter(wb, 1, dy), wb.shape[1])
             partial, Sn = kp.bn_bwd_reduce(da, x, None, layout, N, C, HW, fp, True)
@@ -560,7 +576,8 @@ class _StemBnReluConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = wrw_on_side_stream(lambda: kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp), ctx.wparam, xc, dy, fp)
+        dw = wrw_on_side_stream(lambda out=None: kp.conv3x3_wrw(xc, dy, stride=stride, in_ab=fp, out=out), ctx.wparam, xc, dy, fp,
+                                defer_out=(dy.shape[1], xc.shape[1]))
         rot = ctx.wrt if ctx.wrt is not None else kp.conv3x3_weight_rot180_t(wb)
         da, partial, Sn = _c64_dgrad_and_bn_sums(kp, dy, rot, xc, fp, stride, layout, N, C, HW)
         dgamma, dbeta, bp = S._backward_pack(kp, partial, Sn, C, N * HW, invstd, fp, count_dev, use_batch_stats, group,

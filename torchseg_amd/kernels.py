@@ -383,10 +383,27 @@ class HipKernels:
         pool = self.__dict__.setdefault("_scratch_bufs", {})
         ws = pool.get(key)
         if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                # a captured hipGraph may have recorded the predecessor's address (round 6: a graph captured on a side stream
+                # whose scratch a LATER capture on that stream outgrew replayed into freed memory): predecessors are kept
+                self.__dict__.setdefault("_scratch_retired", []).append(ws)
             ws = pool[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
             ws.record_stream(st)                  # allocated under whatever stream torch considers current: a grown
             #                                       buffer's predecessor must outlive the kernel still using it
         return ws
+
+    def presize_scratch(self, streams, dev):
+        """Give every stream in `streams` scratch buffers as large as the largest any stream has per kernel family, so that no
+        buffer grows (= moves) between two graph captures on one stream (bench.SegmentedStep)."""
+        pool = self.__dict__.setdefault("_scratch_bufs", {})
+        need = {}
+        for (name, di, _sid), ws in list(pool.items()):
+            if di == dev.index:
+                need[name] = max(need.get(name, 0), ws.numel())
+        for st in streams:
+            with torch.cuda.stream(st):
+                for name, n in need.items():
+                    self._scratch(name, n, dev)
 
     def _stem_ws(self, dev):
         return self._scratch("stem", self.lib.tsg_stem_conv_ws_bytes(), dev)
@@ -1070,7 +1087,7 @@ class HipKernels:
         return bool(self.lib.tsg_conv3x3_wrw_gen_supported(L.dtype_code(x), x.shape[1], weight.shape[0], weight.shape[2],
                                                            weight.shape[3], stride, padding, dilation, groups))
 
-    def conv3x3_wrw(self, x, dy, variant=None, stride=1, in_ab=None):
+    def conv3x3_wrw(self, x, dy, variant=None, stride=1, in_ab=None, out=None):
         """x [B,Cin,Hin,Win], dy [B,Cout,OH,OW] bf16 channels_last (Cin, Cout multiples of 64; 3x3, padding 1, stride 1 or
         2) -> dw fp32 [Cout,Cin,3,3] channels_last.  The pair-tiled kernel ("gen") computes every shape; 64 -> 64 / stride 1 can
         also take the single-pair kernels (variant "tr", or "v1" = the transposed-staging kernel; TSG_CONV_WRW_IMPL)."""
@@ -1090,7 +1107,11 @@ class HipKernels:
         Cout = dy.shape[1]
         if tuple(dy.shape) != (B, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1):
             raise ValueError("conv3x3_wrw: dy does not have the output shape of a 3x3 / padding 1 / stride %d convolution of x" % stride)
-        dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        dw = out if out is not None else \
+            torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if out is not None and (tuple(out.shape) != (Cout, Cin, 3, 3) or out.dtype != torch.float32
+                                or not out.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("conv3x3_wrw: out must be an fp32 channels_last [Cout, Cin, 3, 3] tensor")
         if Cin == 64 and Cout == 64 and stride == 1 and variant != "gen":
             fn = self.lib.tsg_conv3x3_wrw_tr if variant == "tr" else self.lib.tsg_conv3x3_wrw
             ws = self._scratch("c3", self.lib.tsg_conv3x3_wrw_ws_bytes(), x.device)
