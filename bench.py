@@ -232,12 +232,12 @@ class GraphedStep(object):
 
 
 class SegmentedStep(object):
-    """The same step as THIRTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
+    """The same step as FIFTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
     overlaps under replay too (a captured graph with parallel BRANCHES is replayed node by node by the runtime and is slower than
     the single-stream graph; linear graphs on different streams overlap like eager launches):
-        s0: context head | context tail ............. | fusion | main head (fwd+loss+bwd) | fusion bwd | context bwd, deep half | shallow half | optimizer
-        s1:              | detail branch (SpatialPath) |        | aux head 0               |            | detail-branch backward ...........  |
-        s2:                                                     | aux head 1               |                                     | deep half's weight gradients |
+        s0: stem + layer1 | context tail ............ | fusion | main head (fwd+loss+bwd) | fusion bwd | layer2..4 bwd | layer1 bwd        | stem bwd          | optimizer
+        s1:               | detail branch (SpatialPath) |      | aux head 0               |            | detail-branch backward .............................. |
+        s2:                                                    | aux head 1               |                            | layer2..4 weight grads | layer1 weight grads |
     The autograd graph is cut at the heads' and the fusion module's inputs (detached leaves whose gradients are handed to
     `torch.autograd.backward` of the segment in front): every kernel and every operand is the one the one-graph step runs, so
     losses and gradients are the same bit for bit.  Our own BiSeNet builder only (context_head / context_tail / heads)."""
@@ -258,7 +258,7 @@ class SegmentedStep(object):
         s0 = self.s0 = GraphedStep.capture_stream()
         s1, s2 = self.s1, self.s2 = wb._side_stream(dev, 1), wb._side_stream(dev, 2)
         G = torch.cuda.CUDAGraph
-        self.g = {k: G() for k in ("a1", "sp", "a2", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx_a", "wa", "bctx_b", "opt")}
+        self.g = {k: G() for k in ("a1", "sp", "a2", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx_a", "wa", "bctx_b", "wb", "bctx_c", "opt")}
         g = self.g
         p0, p1, p2 = (torch.cuda.graph_pool_handle() for _ in range(3))             # one memory pool per stream's graphs
         from torchseg_amd import convwrw
@@ -269,19 +269,21 @@ class SegmentedStep(object):
         K.provider().presize_scratch((s1, s2), dev)      # no scratch buffer may move between two captures on one stream
         torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
+        cp = net.context_path
         with torch.cuda.graph(g["a1"], pool=p0, stream=s0):
             opt.zero_grad()
             with ac():
-                c2 = net.context_head(data)
+                x1 = cp._stem(data)
+                x1_l = leaf(x1)                          # cuts of the context backward: stem | layer1 | layer2 .. (below)
+                c2 = cp.layer1(x1_l)
+                c2_l = leaf(c2)
         s1.wait_stream(s0)
         with torch.cuda.graph(g["sp"], pool=p1, stream=s1):
             with ac():
                 sp = net.spatial_path(data)
         with torch.cuda.graph(g["a2"], pool=p0, stream=s0):
             with ac():
-                c3 = net.context_path.layer2(c2)
-                c3_l = leaf(c3)                          # the context backward is cut here: see bctx_a / wa / bctx_b below
-                f16, f8 = net.context_tail(c2, c3_l)
+                f16, f8 = net.context_tail(c2_l)
         s0.wait_stream(s1)
         with torch.cuda.graph(g["ffm"], pool=p0, stream=s0):
             sp_l, f8_ffm = leaf(sp), leaf(f8)
@@ -306,28 +308,37 @@ class SegmentedStep(object):
         s1.wait_stream(s0)
         with torch.cuda.graph(g["bsp"], pool=p1, stream=s1):
             torch.autograd.backward([sp], [sp_l.grad])
-        # context backward, deep half (layer3 / layer4, attention refinement: matrix-core bound).  Its twelve 3x3 weight gradients
-        # are not launched here: convwrw hands autograd their result tensors and lists the launches, which become a graph of
-        # their own (wa) replayed on s2 beside the shallow half (layer2 / layer1 / stem: HBM-bound passes over the large maps)
-        convwrw._DEFER = []
-        try:
-            with torch.cuda.graph(g["bctx_a"], pool=p0, stream=s0):
-                torch.autograd.backward([f16, f8, f8], [leaves[0].grad, leaves[1].grad, f8_ffm.grad])
-            deferred = convwrw._DEFER
-        finally:
-            convwrw._DEFER = None
-        s2.wait_stream(s0)
-        with torch.cuda.graph(g["wa"], pool=p2, stream=s2):
-            for fn, _ops, _buf in deferred:
-                fn()
-        with torch.cuda.graph(g["bctx_b"], pool=p0, stream=s0):
-            torch.autograd.backward([c3], [c3_l.grad])
+        # Context backward in three parts: layer2 .. layer4 + attention refinement | layer1 | stem.  The 3x3 weight gradients of
+        # the first two parts are not launched in place: convwrw hands autograd their result tensors and lists the launches,
+        # which become graphs of their own (wa, wb) replayed on s2 beside the NEXT part — matrix-core-bound weight gradients
+        # beside the HBM-bound passes over the large maps of layer1 and the stem.
+        def deferred_backward(key, roots, grads):
+            convwrw._DEFER = []
+            try:
+                with torch.cuda.graph(g[key], pool=p0, stream=s0):
+                    torch.autograd.backward(roots, grads)
+                return convwrw._DEFER
+            finally:
+                convwrw._DEFER = None
+
+        def launches(key, lst):
+            s2.wait_stream(s0)
+            with torch.cuda.graph(g[key], pool=p2, stream=s2):
+                for fn, _ops, _buf in lst:
+                    fn()
+
+        d_a = deferred_backward("bctx_a", [f16, f8, f8], [leaves[0].grad, leaves[1].grad, f8_ffm.grad])
+        launches("wa", d_a)
+        d_b = deferred_backward("bctx_b", [c2], [c2_l.grad])
+        launches("wb", d_b)
+        with torch.cuda.graph(g["bctx_c"], pool=p0, stream=s0):
+            torch.autograd.backward([x1], [x1_l.grad])
         s0.wait_stream(s1)
         s0.wait_stream(s2)
         with torch.cuda.graph(g["opt"], pool=p0, stream=s0):
             self.loss = losses[2].detach() + losses[0].detach() + losses[1].detach()
             opt.step()
-        self.keep = [c2, c3, c3_l, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses, deferred]   # deferred: its operands are read by wa
+        self.keep = [x1, x1_l, c2, c2_l, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses, d_a, d_b]   # d_a / d_b: operands read by wa / wb
 
     def __call__(self):
         g, s0, s1, s2 = self.g, self.s0, self.s1, self.s2
@@ -362,6 +373,11 @@ class SegmentedStep(object):
             g["wa"].replay()
         with cs(s0):
             g["bctx_b"].replay()
+        s2.wait_stream(s0)
+        with cs(s2):
+            g["wb"].replay()
+        with cs(s0):
+            g["bctx_c"].replay()
             s0.wait_stream(s1)
             s0.wait_stream(s2)
             g["opt"].replay()
@@ -912,8 +928,8 @@ def main():
                           "whole_graph_ms_per_step": round(ms_whole, 3),
                           "segmented_ms_per_step": None if ms_s is None else round(ms_s, 3),
                           "chosen": ("replay" if graphed is not segmented else "segmented replay") if replay else "eager",
-                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (eleven linear graphs "
-                                  "on three streams: detail branch beside the context path, the three heads side by side) and "
+                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (fifteen linear graphs "
+                                  "on three streams: detail branch, heads and deferred weight gradients beside the context path) and "
                                   "eager launches (weight gradients, auxiliary heads and detail branch on side streams); same "
                                   "kernels and results"}
         if graphed is None and dominant is not None:
