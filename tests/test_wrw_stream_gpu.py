@@ -70,14 +70,14 @@ def test_side_stream_is_taken_only_for_parameters_without_a_gradient(cuda, monke
     ptrs = {}
     real = convwrw.wrw_on_side_stream
 
-    def spy(fn, param, *ops):
+    def spy(fn, param, *ops, **kw):
         cur = torch.cuda.current_stream(ops[0].device)
         seen = {}
 
-        def wrapped():
+        def wrapped(**fkw):
             seen["s"] = torch.cuda.current_stream(ops[0].device)
-            return fn()
-        out = real(wrapped, param, *ops)
+            return fn(**fkw)
+        out = real(wrapped, param, *ops, **kw)
         calls["side" if seen["s"] != cur else "main"] += 1
         ptrs[id(param)] = out.data_ptr()
         return out
