@@ -258,7 +258,7 @@ class SegmentedStep(object):
         s0 = self.s0 = GraphedStep.capture_stream()
         s1, s2 = self.s1, self.s2 = wb._side_stream(dev, 1), wb._side_stream(dev, 2)
         G = torch.cuda.CUDAGraph
-        self.g = {k: G() for k in ("a1", "sp", "a2", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx_a", "wa", "bctx_b", "wb", "bctx_c", "opt")}
+        self.g = {k: G() for k in ("a1", "sp", "a2", "a2b", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx_a", "wa", "opt_a", "bctx_b", "wb", "bctx_c", "opt")}
         g = self.g
         p0, p1, p2 = (torch.cuda.graph_pool_handle() for _ in range(3))             # one memory pool per stream's graphs
         from torchseg_amd import convwrw
@@ -270,6 +270,15 @@ class SegmentedStep(object):
         torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
         cp = net.context_path
+        self.early_opt = os.environ.get("TSG_SEG_EARLY_OPT", "0") == "1" and hasattr(opt, "prepare")
+        late_ids = {id(p) for m in ([m for n, m in cp.named_children() if n not in ("layer2", "layer3", "layer4")]
+                                    + [net.spatial_path]) for p in m.parameters()}
+        params = [p for grp in opt.param_groups for p in grp["params"]]
+        early, late = [p for p in params if id(p) not in late_ids], [p for p in params if id(p) in late_ids]
+        if self.early_opt:                               # (see below) block maps / shadow tables: not under capture
+            opt.prepare(only=early)
+            opt.prepare(only=late)
+            torch.cuda.synchronize()
         with torch.cuda.graph(g["a1"], pool=p0, stream=s0):
             opt.zero_grad()
             with ac():
@@ -281,22 +290,47 @@ class SegmentedStep(object):
         with torch.cuda.graph(g["sp"], pool=p1, stream=s1):
             with ac():
                 sp = net.spatial_path(data)
-        with torch.cuda.graph(g["a2"], pool=p0, stream=s0):
-            with ac():
-                f16, f8 = net.context_tail(c2_l)
-        s0.wait_stream(s1)
+        # TSG_SEG_EARLY_HEADS=1|0 (default 1): an auxiliary head starts as soon as ITS feature map exists — head 0 on s2 behind
+        # the first attention-refinement stage (beside the second stage and the fusion module), head 1 on s1 behind the second
+        # (beside the fusion module) — instead of all three behind the fusion module: the fused head kernels are VALU-bound
+        # and three of them side by side contend for the same unit, next to matrix-core / HBM-bound kernels they do not
+        # (12.01 -> 11.97 ms in six interleaved pairs, gpurun_out/r6c_call2.txt: - 0.3 %, bit-equal trajectory)
+        self.early_heads = os.environ.get("TSG_SEG_EARLY_HEADS", "1") != "0"
+        losses = [None, None, None]
+
+        def aux_head(i, side, key, pool, fm_leaf):
+            side.wait_stream(s0)
+            with torch.cuda.graph(g[key], pool=pool, stream=side):
+                with ac():
+                    losses[i] = net.criterion(net.heads[i](fm_leaf), label)
+                losses[i].backward()
+
+        if self.early_heads:
+            with torch.cuda.graph(g["a2"], pool=p0, stream=s0):
+                with ac():
+                    f16, c3, c4 = net.context_tail_first(c2_l)
+            l16 = leaf(f16)
+            aux_head(0, s2, "h0", p2, l16)
+            with torch.cuda.graph(g["a2b"], pool=p0, stream=s0):
+                with ac():
+                    f8 = net.context_tail_second(f16, c3, c4)
+            l8 = leaf(f8)
+            s1.wait_stream(s0)
+            s0.wait_stream(s1)
+            aux_head(1, s1, "h1", p1, l8)
+        else:
+            with torch.cuda.graph(g["a2"], pool=p0, stream=s0):
+                with ac():
+                    f16, f8 = net.context_tail(c2_l)
+            s0.wait_stream(s1)
         with torch.cuda.graph(g["ffm"], pool=p0, stream=s0):
             sp_l, f8_ffm = leaf(sp), leaf(f8)
             with ac():
                 fused = net.ffm(sp_l, f8_ffm)
-            leaves = [leaf(f16), leaf(f8), leaf(fused)]
-        losses = [None, None, None]
-        for i, (side, key, pool) in enumerate(((s1, "h0", p1), (s2, "h1", p2))):
-            side.wait_stream(s0)
-            with torch.cuda.graph(g[key], pool=pool, stream=side):
-                with ac():
-                    losses[i] = net.criterion(net.heads[i](leaves[i]), label)
-                losses[i].backward()
+            leaves = [l16, l8, leaf(fused)] if self.early_heads else [leaf(f16), leaf(f8), leaf(fused)]
+        if not self.early_heads:
+            aux_head(0, s1, "h0", p1, leaves[0])
+            aux_head(1, s2, "h1", p2, leaves[1])
         with torch.cuda.graph(g["hm"], pool=p0, stream=s0):
             with ac():
                 losses[2] = net.criterion(net.heads[-1](leaves[2]), label)
@@ -329,6 +363,15 @@ class SegmentedStep(object):
 
         d_a = deferred_backward("bctx_a", [f16, f8, f8], [leaves[0].grad, leaves[1].grad, f8_ffm.grad])
         launches("wa", d_a)
+        # TSG_SEG_EARLY_OPT=1 (default 0): the optimizer in two parts — behind wa every gradient but those of the context
+        # path's stem and layer1 and of the detail branch is final, and nothing that still runs reads those parameters or
+        # their bf16 shadows, so their update (97 % of the elements: the two HBM-bound launches that close the step alone)
+        # can go on s2 beside the layer1 / stem backward.  Bit-equal trajectory, and measured NEUTRAL (12.02 vs 12.01 ms in
+        # three interleaved pairs, gpurun_out/r6c_call2.txt): the update's 0.5 GB beside the HBM-bound layer1 passes slows
+        # those by what it saves at the end.  Left opt-in.
+        if self.early_opt:
+            with torch.cuda.graph(g["opt_a"], pool=p2, stream=s2):
+                opt.step(only=early)
         d_b = deferred_backward("bctx_b", [c2], [c2_l.grad])
         launches("wb", d_b)
         with torch.cuda.graph(g["bctx_c"], pool=p0, stream=s0):
@@ -337,7 +380,10 @@ class SegmentedStep(object):
         s0.wait_stream(s2)
         with torch.cuda.graph(g["opt"], pool=p0, stream=s0):
             self.loss = losses[2].detach() + losses[0].detach() + losses[1].detach()
-            opt.step()
+            if self.early_opt:
+                opt.step(only=late)
+            else:
+                opt.step()
         self.keep = [x1, x1_l, c2, c2_l, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses, d_a, d_b]   # d_a / d_b: operands read by wa / wb
 
     def __call__(self):
@@ -348,16 +394,31 @@ class SegmentedStep(object):
         s1.wait_stream(s0)
         with cs(s1):
             g["sp"].replay()
-        with cs(s0):
-            g["a2"].replay()
-            s0.wait_stream(s1)
-            g["ffm"].replay()
-        s1.wait_stream(s0)
-        s2.wait_stream(s0)
-        with cs(s1):
-            g["h0"].replay()
-        with cs(s2):
-            g["h1"].replay()
+        if self.early_heads:
+            with cs(s0):
+                g["a2"].replay()
+            s2.wait_stream(s0)
+            with cs(s2):
+                g["h0"].replay()
+            with cs(s0):
+                g["a2b"].replay()
+            s0.wait_stream(s1)                           # the detail branch (before head 1 is queued behind it on s1)
+            s1.wait_stream(s0)
+            with cs(s1):
+                g["h1"].replay()
+            with cs(s0):
+                g["ffm"].replay()
+        else:
+            with cs(s0):
+                g["a2"].replay()
+                s0.wait_stream(s1)
+                g["ffm"].replay()
+            s1.wait_stream(s0)
+            s2.wait_stream(s0)
+            with cs(s1):
+                g["h0"].replay()
+            with cs(s2):
+                g["h1"].replay()
         with cs(s0):
             g["hm"].replay()
             g["bffm"].replay()
@@ -371,6 +432,8 @@ class SegmentedStep(object):
         s2.wait_stream(s0)
         with cs(s2):
             g["wa"].replay()
+            if self.early_opt:
+                g["opt_a"].replay()
         with cs(s0):
             g["bctx_b"].replay()
         s2.wait_stream(s0)

@@ -43,6 +43,46 @@ def test_fused_sgd_matches_torch(cuda):
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6, msg=n)
 
 
+def test_fused_sgd_step_in_two_parts_equals_one_call(cuda):
+    """FusedSGD.step(only=...) (bench.SegmentedStep's early optimizer graph): two calls over disjoint parameter subsets =
+    the one-call step bit for bit — parameters, momentum buffers, and the bf16 weight shadows the update refreshes (a
+    subset refresh rewrites the shadows of its parameters and leaves the others alone)."""
+    from torchseg_amd import shadow
+    from torchseg_amd.optim import FusedSGD
+    torch.manual_seed(3)
+    ws = [torch.randn(32, 16, 3, 3, device=cuda).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    bs = [torch.randn(32, device=cuda) for _ in range(3)]
+    gs = [torch.randn_like(t) for t in ws + bs]
+
+    def run(split):
+        ps = [nn.Parameter(t.clone(memory_format=torch.preserve_format)) for t in ws + bs]
+        opt = FusedSGD([dict(params=ps[:3], lr=0.05), dict(params=ps[3:], lr=0.5, weight_decay=0.0)], lr=0.05,
+                       momentum=0.9, weight_decay=5e-4)
+        shadows = [shadow.bank.get(p, want_rot=True) for p in ps[:3]]
+        for it in range(3):
+            for p, g in zip(ps, gs):
+                p.grad = g * (it + 1)
+            if split:
+                early = [ps[0], ps[2], ps[4]]
+                opt.step(only=early)
+                w0_stale = shadows[1][0].clone()
+                opt.step(only=[p for p in ps if all(p is not q for q in early)])
+                if it == 0:
+                    assert not torch.equal(w0_stale, shadows[1][0]), "the second part refreshes its own shadows"
+            else:
+                opt.step()
+        torch.cuda.synchronize()
+        return ([p.detach().clone() for p in ps], [opt.state[p]["momentum_buffer"].clone() for p in ps],
+                [(a.clone(), b.clone()) for a, b in shadows])
+
+    one, two = run(False), run(True)
+    for a, b in zip(one[0] + one[1], two[0] + two[1]):
+        assert torch.equal(a, b)
+    for (a0, a1), (b0, b1), p in zip(one[2], two[2], one[0]):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
+        assert torch.equal(a0, p.to(torch.bfloat16))
+
+
 def test_fused_sgd_under_hip_graph_follows_lr(cuda):
     from torchseg_amd.optim import FusedSGD
     p_eager = torch.randn(1000, device=cuda)

@@ -58,9 +58,45 @@ class FusedSGD(torch.optim.Optimizer):
         if p is not None:
             self._sync_lr(p.device)
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def prepare(self, only=None):
+        """Build, OUTSIDE a captured graph, the static tables a later `step(only=...)` over the same subset launches with
+        (block maps, the weight-shadow table: host -> device copies, which stream capture refuses).  Every parameter of
+        the subset that requires a gradient is assumed to have one at step time."""
         kp = K.provider()
+        ids = None if only is None else {id(p) for p in only}
+        chosen = [(p, gi) for gi, g in enumerate(self.param_groups) for p in g["params"]
+                  if p.requires_grad and (ids is None or id(p) in ids)]
+        if not chosen:
+            return
+        dev = chosen[0][0].device
+        self._sync_lr(dev)
+        for c0 in range(0, len(chosen), kp.SGD_MAX_SEGS):
+            self._plan(c0, chosen[c0:c0 + kp.SGD_MAX_SEGS], dev)
+        if dev.type == "cuda" and ids is not None:
+            from . import shadow
+            shadow.bank.prepare_subset(dev, [p for p, _ in chosen])
+
+    def _plan(self, c0, chunk, device):
+        """(numel, group index, block map) of the launch over `chunk` = [(parameter, group index)]: static per model"""
+        import numpy as np
+        numel = tuple(p.numel() for p, _ in chunk)
+        groups = tuple(gi for _, gi in chunk)
+        key = (c0, numel, groups, len(self.param_groups))   # the plan stores the group of every segment
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = (np.array(numel, dtype=np.int64), np.array(groups, dtype=np.int32),
+                    K.provider().sgd_multi_blockmap(numel, device))
+            self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def step(self, closure=None, only=None):
+        """`only`: an iterable of parameters — update just these (bench.SegmentedStep: the parameters whose gradients are
+        final after the first part of the context backward step early, on a side stream beside the rest of the backward;
+        a second call with the remaining parameters closes the step).  The update is per element, so a step taken in
+        several calls over disjoint subsets equals the one-call step bit for bit."""
+        kp = K.provider()
+        only_ids = None if only is None else {id(p) for p in only}
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         first = next((p for g in self.param_groups for p in g["params"]), None)
         if first is None:
@@ -77,7 +113,7 @@ class FusedSGD(torch.optim.Optimizer):
             if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
                 raise K.L.TsgError("FusedSGD implements dampening=0, nesterov=False, maximize=False only")
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only_ids is not None and id(p) not in only_ids):
                     continue
                 st = self.state[p]
                 if p.dtype != torch.float32:
@@ -109,18 +145,11 @@ class FusedSGD(torch.optim.Optimizer):
         cap = kp.SGD_MAX_SEGS
         for c0 in range(0, len(segs), cap):
             chunk = segs[c0:c0 + cap]
-            numel = tuple(t[0].numel() for t in chunk)
-            groups = tuple(t[3] for t in chunk)
-            key = (c0, numel, groups, len(self.param_groups))   # the plan stores the group of every segment
-            plan = self._plans.get(key)
-            if plan is None:                        # static per model: sizes, groups, block map
-                plan = (np.array(numel, dtype=np.int64), np.array(groups, dtype=np.int32),
-                        kp.sgd_multi_blockmap(numel, first.device))
-                self._plans[key] = plan
+            plan = self._plan(c0, [(t[0], t[3]) for t in chunk], first.device)
             ptrs = np.array([[t[0].data_ptr() for t in chunk], [t[1].data_ptr() for t in chunk],
                              [t[2].data_ptr() for t in chunk]], dtype=np.uint64)
             kp.sgd_multi_step_dev(ptrs, plan[0], plan[1], self._lr_dev, mom, wd, plan[2])
         if first.is_cuda:
             from . import shadow                     # the kernel above changed parameters behind torch's back
-            shadow.after_external_update(first.device)
+            shadow.after_external_update(first.device, None if only_ids is None else [t[0] for t in segs])
         return None

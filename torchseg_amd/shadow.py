@@ -46,6 +46,7 @@ class _Bank(object):
     def __init__(self):
         self.entries = {}            # (data_ptr, shape, stride) of the parameter -> _Entry
         self._table = None           # (device table, block map, n_entries)
+        self._subtables = {}         # parameter subset (sorted storage keys) -> the same, for refresh_subset
 
     def _prune(self):
         dead = [k for k, e in self.entries.items() if e.ref() is None]
@@ -53,6 +54,7 @@ class _Bank(object):
             del self.entries[k]
         if dead:
             self._table = None
+            self._subtables = {}
 
     @staticmethod
     def _key(param):
@@ -67,6 +69,7 @@ class _Bank(object):
                 e.add_rot(param)
                 e.version = -1
                 self._table = None
+                self._subtables = {}
             return e
         if param.dtype != torch.float32 or not param.is_cuda:
             raise K.L.TsgError("weight shadows are kept for fp32 parameters on the GPU")
@@ -77,6 +80,7 @@ class _Bank(object):
         self._prune()
         e = self.entries[self._key(param)] = _Entry(param, want_rot)
         self._table = None
+        self._subtables = {}
         return e
 
     @staticmethod
@@ -85,8 +89,9 @@ class _Bank(object):
                 and param.is_contiguous(memory_format=torch.channels_last)):
             raise K.L.TsgError("the rotated / fragment-order shadows need a channels_last [O, I, 3, 3] filter")
 
-    def _build(self, device):
-        ents = [e for e in self.entries.values() if e.ref() is not None and e.wb.device == device]
+    def _build(self, device, ents=None):
+        if ents is None:
+            ents = [e for e in self.entries.values() if e.ref() is not None and e.wb.device == device]
         dt = np.dtype([("w", "<u8"), ("wb", "<u8"), ("wrt", "<u8"), ("wf0", "<u8"), ("wf1", "<u8"), ("n", "<i4"), ("O", "<i4"),
                        ("I", "<i4"), ("bn0", "<i4"), ("bn1", "<i4"), ("pad", "<i4")])
         assert dt.itemsize == K.provider().lib.tsg_weight_shadow_entry_bytes()
@@ -133,6 +138,41 @@ class _Bank(object):
             if p is not None:
                 e.version = p._version
 
+    def _subset_table(self, device, params):
+        self._prune()
+        ents = []
+        for p in params:
+            e = self.entries.get(self._key(p))
+            if e is not None and e.ref() is not None and e.wb.device == device:
+                ents.append(e)
+        if not ents:
+            return None
+        key = tuple(sorted(id(e) for e in ents))
+        t = self._subtables.get(key)
+        if t is None or t[0].device != device or any(e.ref() is None or e.ref().data_ptr() != ptr for e, ptr in t[3]):
+            table, bmap, ents = self._build(device, ents)
+            t = self._subtables[key] = (table, bmap, ents, [(e, e.ref().data_ptr()) for e in ents])
+        return t
+
+    def prepare_subset(self, device, params):
+        """Build the table refresh_subset(params) launches with (a host -> device copy: not allowed under stream capture)."""
+        self._subset_table(device, params)
+
+    def refresh_subset(self, device, params):
+        """refresh_all for the shadows of `params` only (one launch; parameters without a shadow are skipped): an optimizer
+        step taken in parts (FusedSGD.step(only=...)) rewrites what it changed and nothing else."""
+        t = self._subset_table(device, params)
+        if t is None:
+            return
+        table, bmap, ents = t[0], t[1], t[2]
+        L = K.L
+        L.check(K.provider().lib.tsg_weight_shadow_refresh(table.data_ptr(), bmap.data_ptr(), bmap.shape[0],
+                                                           L.stream_ptr(table)), "tsg_weight_shadow_refresh")
+        for e in ents:
+            p = e.ref()
+            if p is not None:
+                e.version = p._version
+
     def get(self, param, want_rot=False):
         """(bf16 filter, rotated / transposed bf16 filter or None) of `param`, refreshed if the parameter changed."""
         e = self.register(param, want_rot)
@@ -156,6 +196,7 @@ class _Bank(object):
             e.wf[mode] = (torch.empty(9 * O * I, dtype=torch.bfloat16, device=param.device), bn)
             e.version = -1
             self._table = None
+            self._subtables = {}
         if e.version != param._version:
             self.refresh_all(param.device)
         return e.wf[mode][0]
@@ -164,7 +205,11 @@ class _Bank(object):
 bank = _Bank()
 
 
-def after_external_update(device):
-    """Called by an optimizer that writes parameters without torch noticing (FusedSGD): all shadows are rewritten."""
+def after_external_update(device, params=None):
+    """Called by an optimizer that writes parameters without torch noticing (FusedSGD): all shadows are rewritten, or
+    those of `params` when the optimizer says which parameters it touched."""
     if bank.entries:
-        bank.refresh_all(device)
+        if params is None:
+            bank.refresh_all(device)
+        else:
+            bank.refresh_subset(device, params)

@@ -178,12 +178,25 @@ class BiSeNet(nn.Module):
             c5 = cp.layer4(c4)
         else:
             c2, c3, c4, c5 = blocks
-        last_fm = _up(self.global_context(c5), size=c5.shape[2:])
-        outs = []
-        for fm, nxt, arm, refine in zip((c5, c4), (c4, c3), self.arms, self.refines):
-            last_fm = refine(add_then_upsample(arm(fm), last_fm, nxt.shape[2:]))   # network.py:91-95
-            outs.append(last_fm)
-        return outs
+        f16 = self._refine_stage(0, c5, _up(self.global_context(c5), size=c5.shape[2:]), c4)
+        return [f16, self._refine_stage(1, c4, f16, c3)]
+
+    def _refine_stage(self, k, fm, last_fm, nxt):
+        """one pass of network.py:91-95: refine(upsample(arm(fm) + last_fm)) at the resolution of `nxt`"""
+        return self.refines[k](add_then_upsample(self.arms[k](fm), last_fm, nxt.shape[2:]))
+
+    def context_tail_first(self, c2):
+        """context_tail up to the 1/16 feature map, which auxiliary head 0 needs and nothing else of the forward waits for
+        (bench.SegmentedStep starts that head beside the second stage) -> (1/16 fm, c3, c4)"""
+        cp = self.context_path
+        c3 = cp.layer2(c2)
+        c4 = cp.layer3(c3)
+        c5 = cp.layer4(c4)
+        return self._refine_stage(0, c5, _up(self.global_context(c5), size=c5.shape[2:]), c4), c3, c4
+
+    def context_tail_second(self, f16, c3, c4):
+        """the second attention-refinement stage -> 1/8 fm"""
+        return self._refine_stage(1, c4, f16, c3)
 
     def forward(self, data, label=None):
         f16, f8, fused = self.features(data)
