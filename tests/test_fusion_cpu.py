@@ -334,6 +334,40 @@ def test_pending_conv_bn_relu_is_a_real_tensor_for_everything_else(standin, monk
     assert int(net.conv_3x3_1.bn.num_batches_tracked) == 1
 
 
+def test_a_conv_bn_relu_nested_in_one_of_our_modules_does_not_defer(standin, monkeypatch):
+    """chains are a pattern of network.py level.  A 64-output ConvBnRelu called INSIDE another forward that runs
+    with torch-function dispatch disabled (fusion.outside_mode: AttentionRefinement, FeatureFusion, ResNet, the criteria)
+    returns a real tensor there — a PendingCbr would reach code that cannot see it for what it is."""
+    from torchseg_amd import fusion
+    monkeypatch.setattr(fusion, "_on_device", lambda t: True)
+    net = _spatial_path()
+    seen = {}
+
+    class Outer(nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        @fusion.outside_mode
+        def forward(self, x):
+            y = self.inner(x)
+            seen["type"] = type(y)
+            seen["chain"] = fusion.CHAIN_ACTIVE
+            return y * 2.0
+
+    outer = Outer(net.conv_7x7)
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    before = dict(fusion.stats)
+    with fusion.FuseMode(loss=False, add_up=False, chain=True) as mode:
+        got = outer(x)
+        assert fusion.CHAIN_ACTIVE is mode                       # restored for network.py level
+        top = net.conv_7x7(x)
+        assert isinstance(top, fusion.PendingCbr)                # ... where the same module still defers
+    assert seen["type"] is torch.Tensor and seen["chain"] is False
+    assert fusion.stats["cbr_deferred"] - before["cbr_deferred"] == 1
+    torch.testing.assert_close(got, net.conv_7x7(x) * 2.0, rtol=0, atol=0)
+
+
 def test_a_conv_bn_relu_output_consumed_twice_is_reported(standin, monkeypatch):
     from torchseg_amd import fusion
     monkeypatch.setattr(fusion, "_on_device", lambda t: True)

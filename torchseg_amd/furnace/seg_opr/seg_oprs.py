@@ -45,7 +45,7 @@ class _ConvNormAct(nn.Module):
 
     tsg_accepts_pending = True     # fusion.FuseMode's forward pre-hook leaves a PendingCbr argument to us
 
-    @_fusion.outside_mode
+    @_fusion.outside_mode(keeps_chain=True)
     def forward(self, x):
         if isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[2] == 1 and x.shape[3] == 1 and x.is_cuda:
             from torchseg_amd.vecconv import pooled_layer

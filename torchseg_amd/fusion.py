@@ -188,24 +188,38 @@ CHAIN_ACTIVE = False       # set while a FuseMode(chain=True) is entered: ConvBn
 MODE_DEPTH = 0             # FuseModes entered: `outside_mode` forwards step out of torch-function dispatch while it is > 0
 
 
-def outside_mode(fn):
+def outside_mode(fn=None, keeps_chain=False):
     """Decorator for the forward of OUR furnace modules (ResNet, ConvBnRelu, AttentionRefinement, FeatureFusion, the
     criteria): nothing inside them is a call pattern FuseMode has to see — the patterns live in the reference's network.py —
     but the mode is consulted for every torch call they make (tensor attributes and the allocations inside the kernel
     wrappers included: ~5 000 per BiSeNet forward, ~0.4 us each).  While a FuseMode is entered the wrapped forward runs
     under torch._C.DisableTorchFunction(); deferred arguments have been materialised by the mode's forward pre-hook before
-    that.  Without a FuseMode (our own builders, evaluation) the wrapper costs one global read."""
+    that.  Without a FuseMode (our own builders, evaluation) the wrapper costs one global read.
+
+    keeps_chain (ConvBnRelu.forward only): the module is itself a link of a ConvBnRelu chain and reads CHAIN_ACTIVE.  Every
+    other wrapped forward clears it for its duration: a 64-output ConvBnRelu NESTED in one of our modules must not hand a
+    PendingCbr to code that runs with torch-function dispatch disabled (channel_scale, an autograd.Function.apply — the
+    non-tensor argument would drop the gradient or raise) — chains are a pattern of network.py level."""
     import functools
 
-    @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        if MODE_DEPTH <= 0:
-            return fn(*args, **kwargs)
-        if kwargs:                                       # the mode's forward pre-hook sees positional arguments only
-            kwargs = {k: (v.materialize() if isinstance(v, (PendingCbr, DeferredSum)) else v) for k, v in kwargs.items()}
-        with torch._C.DisableTorchFunction():
-            return fn(*args, **kwargs)
-    return wrapper
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            global CHAIN_ACTIVE
+            if MODE_DEPTH <= 0:
+                return fn(*args, **kwargs)
+            if kwargs:                                   # the mode's forward pre-hook sees positional arguments only
+                kwargs = {k: (v.materialize() if isinstance(v, (PendingCbr, DeferredSum)) else v) for k, v in kwargs.items()}
+            chain = CHAIN_ACTIVE
+            if not keeps_chain:
+                CHAIN_ACTIVE = False
+            try:
+                with torch._C.DisableTorchFunction():
+                    return fn(*args, **kwargs)
+            finally:
+                CHAIN_ACTIVE = chain
+        return wrapper
+    return deco if fn is None else deco(fn)
 
 
 # ---- a sub-module of the wrapped model on a side stream (TSG_FORK_MODULES, opt-in) --------------------------------
