@@ -294,7 +294,7 @@ class SegmentedStep(object):
         # the first attention-refinement stage (beside the second stage and the fusion module), head 1 on s1 behind the second
         # (beside the fusion module) — instead of all three behind the fusion module: the fused head kernels are VALU-bound
         # and three of them side by side contend for the same unit, next to matrix-core / HBM-bound kernels they do not
-        # (12.01 -> 11.97 ms in six interleaved pairs, gpurun_out/r6c_call2.txt: - 0.3 %, bit-equal trajectory)
+        # (12.01 -> 11.97 ms in six interleaved pairs, profiles/r06_segmented_early_heads_early_optimizer_ab.txt: - 0.3 %, bit-equal trajectory)
         self.early_heads = os.environ.get("TSG_SEG_EARLY_HEADS", "1") != "0"
         losses = [None, None, None]
 
@@ -367,7 +367,7 @@ class SegmentedStep(object):
         # path's stem and layer1 and of the detail branch is final, and nothing that still runs reads those parameters or
         # their bf16 shadows, so their update (97 % of the elements: the two HBM-bound launches that close the step alone)
         # can go on s2 beside the layer1 / stem backward.  Bit-equal trajectory, and measured NEUTRAL (12.02 vs 12.01 ms in
-        # three interleaved pairs, gpurun_out/r6c_call2.txt): the update's 0.5 GB beside the HBM-bound layer1 passes slows
+        # three interleaved pairs, profiles/r06_segmented_early_heads_early_optimizer_ab.txt): the update's 0.5 GB beside the HBM-bound layer1 passes slows
         # those by what it saves at the end.  Left opt-in.
         if self.early_opt:
             with torch.cuda.graph(g["opt_a"], pool=p2, stream=s2):
