@@ -331,12 +331,19 @@ class SegmentedStep(object):
         if not self.early_heads:
             aux_head(0, s1, "h0", p1, leaves[0])
             aux_head(1, s2, "h1", p2, leaves[1])
+        # main head and the fusion module's backward: consecutive on s0 with no other stream waiting in between — ONE graph
+        # (a graph boundary on the critical path is 7-30 us with no kernel on any queue, profiles/r06_segmented_replay_timeline.txt);
+        # TSG_SEG_MERGE=0 keeps them apart
+        self.merge = os.environ.get("TSG_SEG_MERGE", "1") != "0"
         with torch.cuda.graph(g["hm"], pool=p0, stream=s0):
             with ac():
                 losses[2] = net.criterion(net.heads[-1](leaves[2]), label)
             losses[2].backward()
-        with torch.cuda.graph(g["bffm"], pool=p0, stream=s0):
-            torch.autograd.backward([fused], [leaves[2].grad])
+            if self.merge:
+                torch.autograd.backward([fused], [leaves[2].grad])
+        if not self.merge:
+            with torch.cuda.graph(g["bffm"], pool=p0, stream=s0):
+                torch.autograd.backward([fused], [leaves[2].grad])
         s0.wait_stream(s1)
         s0.wait_stream(s2)
         s1.wait_stream(s0)
@@ -421,7 +428,8 @@ class SegmentedStep(object):
                 g["h1"].replay()
         with cs(s0):
             g["hm"].replay()
-            g["bffm"].replay()
+            if not self.merge:
+                g["bffm"].replay()
             s0.wait_stream(s1)                           # aux head 0's gradient (and s1 is free for the detail branch's backward)
             s0.wait_stream(s2)
         s1.wait_stream(s0)

@@ -751,10 +751,14 @@ int tsg_conv3x3_wrw_tr_norm(const void* x, const float* in_ab, const void* dy, f
   return conv3_wrw_common(1, x, dy, dw, B, H, W, ws, ws_bytes, stream, in_ab);
 }
 
-// TSG_CONV_WRW_OCC=2 (default) | 1: stride-1 layers with >= 1024 pixel tiles run the two-blocks-per-CU variant of the
-// kernel (no register prefetch).  tools/bench_conv3wrw.py, us per layer, 1 -> 2: layer2 97 -> 88, layer3 107 -> 87,
-// layer4 127 -> 104, head1 193 -> 156 (0.99 PF), head2 99 -> 89; the 64^2 / 32^2 maps (<= 512 tiles) are a few us better
-// with one prefetching block per CU and keep it.
+// TSG_CONV_WRW_OCC=1 (default since round 6) | 2: with 2, stride-1 layers with >= 1024 pixel tiles run the two-blocks-per-CU
+// variant of the kernel (no register prefetch).  tools/bench_conv3wrw.py, us per layer ALONE, 1 -> 2: layer2 97 -> 88, layer3
+// 107 -> 87, layer4 127 -> 104, head1 193 -> 156 (0.99 PF), head2 99 -> 89; the 64^2 / 32^2 maps (<= 512 tiles) are a few us
+// better with one prefetching block per CU and keep it.  IN THE STEP the order is the other way round (round 6, interleaved
+// pairs on two boxes, profiles/r06_wrw_one_block_per_cu_in_the_step.txt): one block per CU writes 256 partials instead of
+// 512 (37.7 instead of 75 MB per launch, written and read again by the fold — and whoever runs next pays for a writer's
+// write-backs) and leaves half of every CU's wave slots to the kernel of the other queue: one graph 12.40 ->
+// 12.36 / 12.82 -> 12.72 ms, sixteen graphs 11.84 -> 11.80 / 12.16 -> 12.09 ms, eager with the side stream 12.26 -> 12.08 ms.
 // TSG_CONV_WRW_PF2=1 (opt-in): the stride-1 layers on the two-tiles-ahead kernel, one block per CU.  Measured SLOWER
 // (profiles/r03_conv3wrw_two_tiles_ahead.txt: 2.76 vs 2.37 ms per step, 1100 vs 1125 img/s on one box; layer3 at the same
 // occupancy 123 vs 105 us): the tile time is not the load latency the 2.1 us per tile suggested
@@ -763,7 +767,7 @@ static bool w3_pf2() {
   return v;
 }
 static bool w3_occ2(int64_t ntiles) {
-  static const int v = [] { const char* e = getenv("TSG_CONV_WRW_OCC"); return e ? atoi(e) : 2; }();
+  static const int v = [] { const char* e = getenv("TSG_CONV_WRW_OCC"); return e ? atoi(e) : 1; }();
   return !w3_pf2() && v == 2 && ntiles >= 1024;
 }
 
