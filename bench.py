@@ -258,7 +258,7 @@ class SegmentedStep(object):
         s0 = self.s0 = GraphedStep.capture_stream()
         s1, s2 = self.s1, self.s2 = wb._side_stream(dev, 1), wb._side_stream(dev, 2)
         G = torch.cuda.CUDAGraph
-        self.g = {k: G() for k in ("a1", "sp", "a2", "a2b", "ffm", "h0", "h1", "hm", "bffm", "bsp", "bctx_a", "wa", "opt_a", "bctx_b", "wb", "bctx_c", "opt")}
+        self.g = {k: G() for k in ("a1", "sp", "a2", "a2b", "ffm", "h0", "h1", "hm", "bffm", "wh", "bsp", "bctx_a", "wa", "opt_a", "bctx_b", "wb", "bctx_c", "opt")}
         g = self.g
         p0, p1, p2 = (torch.cuda.graph_pool_handle() for _ in range(3))             # one memory pool per stream's graphs
         from torchseg_amd import convwrw
@@ -298,9 +298,28 @@ class SegmentedStep(object):
         self.early_heads = os.environ.get("TSG_SEG_EARLY_HEADS", "1") != "0"
         losses = [None, None, None]
 
+        # TSG_SEG_DEFER_HEADS=1|0: the 3x3 weight gradients of the three heads are not launched inside the heads' graphs (the
+        # main head's sits on s0's critical path, the auxiliary heads' hold back the join in front of the context backward)
+        # but listed (convwrw._DEFER) and replayed as a graph of their own (wh) on s2 beside the first part of the context
+        # backward, where s2 has nothing else to do
+        self.defer_heads = os.environ.get("TSG_SEG_DEFER_HEADS", "1") != "0"
+        d_heads = []
+
+        @contextlib.contextmanager
+        def deferring():
+            if not self.defer_heads:
+                yield
+                return
+            convwrw._DEFER = []
+            try:
+                yield
+            finally:
+                d_heads.extend(convwrw._DEFER)
+                convwrw._DEFER = None
+
         def aux_head(i, side, key, pool, fm_leaf):
             side.wait_stream(s0)
-            with torch.cuda.graph(g[key], pool=pool, stream=side):
+            with deferring(), torch.cuda.graph(g[key], pool=pool, stream=side):
                 with ac():
                     losses[i] = net.criterion(net.heads[i](fm_leaf), label)
                 losses[i].backward()
@@ -335,7 +354,7 @@ class SegmentedStep(object):
         # (a graph boundary on the critical path is 7-30 us with no kernel on any queue, profiles/r06_segmented_replay_timeline.txt);
         # TSG_SEG_MERGE=0 keeps them apart
         self.merge = os.environ.get("TSG_SEG_MERGE", "1") != "0"
-        with torch.cuda.graph(g["hm"], pool=p0, stream=s0):
+        with deferring(), torch.cuda.graph(g["hm"], pool=p0, stream=s0):
             with ac():
                 losses[2] = net.criterion(net.heads[-1](leaves[2]), label)
             losses[2].backward()
@@ -347,6 +366,12 @@ class SegmentedStep(object):
         s0.wait_stream(s1)
         s0.wait_stream(s2)
         s1.wait_stream(s0)
+        self.wh = bool(d_heads)
+        if self.wh:
+            s2.wait_stream(s0)
+            with torch.cuda.graph(g["wh"], pool=p2, stream=s2):
+                for fn, _ops, _buf in d_heads:
+                    fn()
         with torch.cuda.graph(g["bsp"], pool=p1, stream=s1):
             torch.autograd.backward([sp], [sp_l.grad])
         # Context backward in three parts: layer2 .. layer4 + attention refinement | layer1 | stem.  The 3x3 weight gradients of
@@ -391,7 +416,7 @@ class SegmentedStep(object):
                 opt.step(only=late)
             else:
                 opt.step()
-        self.keep = [x1, x1_l, c2, c2_l, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses, d_a, d_b]   # d_a / d_b: operands read by wa / wb
+        self.keep = [x1, x1_l, c2, c2_l, sp, f16, f8, sp_l, f8_ffm, fused, leaves, losses, d_a, d_b, d_heads]   # d_a / d_b / d_heads: operands read by wa / wb / wh
 
     def __call__(self):
         g, s0, s1, s2 = self.g, self.s0, self.s1, self.s2
@@ -433,6 +458,10 @@ class SegmentedStep(object):
             s0.wait_stream(s1)                           # aux head 0's gradient (and s1 is free for the detail branch's backward)
             s0.wait_stream(s2)
         s1.wait_stream(s0)
+        if self.wh:
+            s2.wait_stream(s0)
+            with cs(s2):
+                g["wh"].replay()
         with cs(s1):
             g["bsp"].replay()
         with cs(s0):

@@ -78,3 +78,33 @@ def test_other_inputs_take_the_stock_forward(cuda):
         assert taken and y.dtype == torch.bfloat16
     finally:
         pwconv._PointwiseFn.apply = orig
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[3], CASES[4]])
+def test_deferred_weight_gradient_equals_the_one_launched_in_place(cuda, case):
+    """convwrw._DEFER (bench.SegmentedStep): backward hands autograd a still unwritten weight gradient and lists the launch;
+    launched later it is the in-place result bit for bit, written into the very tensor the parameter holds."""
+    from torchseg_amd import convwrw
+    B, cin, cout, H, W, st = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    conv = _conv(cuda, cin, cout, st)
+    x = torch.randn(B, cin, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    OH, OW = (H - 1) // st + 1, (W - 1) // st + 1
+    dy = torch.randn(B, cout, OH, OW, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    conv(x.clone().requires_grad_(True)).backward(dy)
+    want = conv.weight.grad.clone()
+    conv.weight.grad = None
+    convwrw._DEFER = []
+    try:
+        conv(x.clone().requires_grad_(True)).backward(dy)
+        listed = convwrw._DEFER
+    finally:
+        convwrw._DEFER = None
+    assert len(listed) == 1
+    fn, _ops, buf = listed[0]
+    held = conv.weight.grad
+    assert held.data_ptr() == buf.data_ptr() and held.shape == conv.weight.shape and held.dtype == torch.float32
+    buf.fill_(float("nan"))
+    fn()
+    torch.cuda.synchronize()
+    assert torch.equal(conv.weight.grad, want)

@@ -25,6 +25,8 @@ ENABLED = os.environ.get("TSG_PW_CONV", "1") != "0"
 _DGRAD_MM = os.environ.get("TSG_PW_DGRAD_MM", "1") != "0"
 # TSG_PW_SUB_FWD_MM=1|0 (default 1): the shortcut convolution on the sub-sampled map (forward_subsampled) as a GEMM as well
 _SUB_FWD_MM = os.environ.get("TSG_PW_SUB_FWD_MM", "1") != "0"
+# TSG_SEG_DEFER_PW=1|0 (default 1): the weight gradient joins a deferred-launch list when one is open (convwrw._DEFER)
+_DEFER_OK = os.environ.get("TSG_SEG_DEFER_PW", "1") != "0"
 _MIN_CHUNK = 128        # rows of a chunk: below this the batched GEMM's tiles run half empty
 
 
@@ -42,9 +44,10 @@ def _rows(t):
     return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
 
 
-def pointwise_wgrad(x, dy, stride):
+def pointwise_wgrad(x, dy, stride, out=None):
     """dw [C_out, C_in, 1, 1] fp32 of a 1x1 / padding 0 convolution: x [B, C_in, H, W], dy [B, C_out, OH, OW], both bf16
-    channels_last.  Chunked batched GEMM + ordered fold (see the module text)."""
+    channels_last.  Chunked batched GEMM + ordered fold (see the module text).  out: a dense fp32 [C_out, C_in, 1, 1] tensor
+    to write the result into (a deferred launch, convwrw._DEFER: autograd already holds that tensor)."""
     if stride != 1:
         x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)     # the pixels the convolution read
     xr, dr = _rows(x), _rows(dy)
@@ -52,6 +55,13 @@ def pointwise_wgrad(x, dy, stride):
     N = dr.shape[1]
     nb = _chunks(M)
     part = torch.bmm(dr.view(nb, M // nb, N).transpose(1, 2), xr.view(nb, M // nb, K), out_dtype=torch.float32)
+    if out is not None:
+        o2 = out.view(N, K)
+        if nb > 1:
+            torch.sum(part, dim=0, out=o2)
+        else:
+            o2.copy_(part[0])
+        return out
     dw = part.sum(0) if nb > 1 else part[0]
     return dw.view(N, K, 1, 1)
 
@@ -93,9 +103,22 @@ class _PointwiseFn(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, wb, None, [st, st], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        dw = pointwise_wgrad(x, dy, st) if ctx.needs_input_grad[1] else None
-        if dw is not None and dw.dtype != ctx.wdtype:
-            dw = dw.to(ctx.wdtype)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            from . import convwrw
+            if convwrw._DEFER is not None and _DEFER_OK and ctx.wdtype == torch.float32:
+                # bench.SegmentedStep: listed, launched later from a graph of its own beside the next part of the backward;
+                # autograd gets the still unwritten result (an alias of its own: see convwrw.wrw_on_side_stream)
+                buf = torch.empty((dy.shape[1], x.shape[1], 1, 1), dtype=torch.float32, device=dy.device)
+                def later():                                   # (outside backward: grad mode is on again, x may require grad)
+                    with torch.no_grad():
+                        pointwise_wgrad(x, dy, st, out=buf)
+                convwrw._DEFER.append((later, (x, dy), buf))
+                dw = buf.detach()
+            else:
+                dw = pointwise_wgrad(x, dy, st)
+                if dw.dtype != ctx.wdtype:
+                    dw = dw.to(ctx.wdtype)
         return dx, dw, None, None
 
 
