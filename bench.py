@@ -232,15 +232,15 @@ class GraphedStep(object):
 
 
 class SegmentedStep(object):
-    """The same step as FIFTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
+    """The same step as SIXTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
     overlaps under replay too (a captured graph with parallel BRANCHES is replayed node by node by the runtime and is slower than
     the single-stream graph; linear graphs on different streams overlap like eager launches):
-        s0: stem + layer1 | context tail ............ | fusion | main head (fwd+loss+bwd) | fusion bwd | layer2..4 bwd | layer1 bwd        | stem bwd          | optimizer
-        s1:               | detail branch (SpatialPath) |      | aux head 0               |            | detail-branch backward .............................. |
-        s2:                                                    | aux head 1               |                            | layer2..4 weight grads | layer1 weight grads |
+        s0: stem + layer1 | context tail, first stage | second stage | fusion | main head (fwd+loss+bwd) + fusion bwd | layer2..4 bwd | layer1 bwd | stem bwd | optimizer
+        s1:               | detail branch (SpatialPath) ........... | aux head 1 .............................. | detail-branch backward ......................... |
+        s2:                                         | aux head 0 ................................................... | heads' weight grads | layer2..4 weight grads | layer1 weight grads |
     The autograd graph is cut at the heads' and the fusion module's inputs (detached leaves whose gradients are handed to
     `torch.autograd.backward` of the segment in front): every kernel and every operand is the one the one-graph step runs, so
-    losses and gradients are the same bit for bit.  Our own BiSeNet builder only (context_head / context_tail / heads)."""
+    losses and gradients are the same bit for bit.  Our own BiSeNet builder only (context_head / context_tail_first / _second / heads)."""
 
     @staticmethod
     def applies(model, world):
@@ -1028,7 +1028,7 @@ def main():
                           "whole_graph_ms_per_step": round(ms_whole, 3),
                           "segmented_ms_per_step": None if ms_s is None else round(ms_s, 3),
                           "chosen": ("replay" if graphed is not segmented else "segmented replay") if replay else "eager",
-                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (fifteen linear graphs "
+                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (sixteen linear graphs "
                                   "on three streams: detail branch, heads and deferred weight gradients beside the context path) and "
                                   "eager launches (weight gradients, auxiliary heads and detail branch on side streams); same "
                                   "kernels and results"}
