@@ -944,13 +944,17 @@ def main():
     if run_stream is not None:
         run_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(run_stream) if run_stream is not None else contextlib.nullcontext():
+        probe = None
+        n_probe = min(3, n_eager)                        # instrumented warm-up steps: every launch = the minimum of its brackets
         for it in range(n_eager):
-            probe = None
-            if not args.no_kernel_timing and it == n_eager - 1:
+            if not args.no_kernel_timing and it == n_eager - n_probe:
                 probe = K.KernelTimer(K.provider())
             with serial_kernels(probe is not None):
                 loss = train_step(model, opt, batch, pol, it, world)
             if probe is not None:
+                torch.cuda.synchronize()
+                probe.mark_step()
+            if probe is not None and it == n_eager - 1:
                 probe.stop()
                 dom_family = probe.dominant_family()
                 fam = probe.family_stats().get(dom_family, {}).get("members") or []
@@ -1207,7 +1211,8 @@ def main():
             # step, the three largest families beside it; `timed_region` = the family's largest label bracketed with HIP
             # events over the K timed steps (the same kernels, measured live where `value` is measured)
             out["roofline"] = roof_probe.roofline(HBM_PEAK_GBS, os.path.join(ROOT, "profiles"), by_family=True)
-            out["roofline"]["measured_over"] = "fully instrumented last warm-up step (every launch of every family bracketed)"
+            out["roofline"]["measured_over"] = ("the last three warm-up steps, fully instrumented (every launch of every family bracketed; "
+                                               "a launch = the minimum of its three brackets: a bracket holds the host-side call too)")
             if timer is not roof_probe:
                 out["roofline"]["timed_region"] = timer.roofline(HBM_PEAK_GBS, os.path.join(ROOT, "profiles"))
                 out["roofline"]["timed_region"]["sampled"] = (

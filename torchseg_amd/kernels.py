@@ -1422,6 +1422,7 @@ class KernelTimer:
         self.names = list(names or _ALGO_BYTES.keys())
         self.enabled = True          # bench.py brackets only every few timed steps: two event records per launch cost GPU time
         self.records = {n: [] for n in self.names}
+        self.marks = []              # mark_step(): records per label at the end of every instrumented step
         self._orig = {}
         for n in self.names:
             self._wrap(n)
@@ -1448,6 +1449,31 @@ class KernelTimer:
 
         setattr(self.prov, name, timed)
 
+    def mark_step(self):
+        """End of one instrumented step.  With several marked steps of equal launch counts, every launch is represented by
+        the MINIMUM of its brackets over the steps: a bracket is start event, host-side call, kernel, end event — in a
+        host-bound instrumented step the GPU waits inside it for the host, and one host hiccup (a collection, an allocation)
+        used to put 10 ms on one stem launch and make `stem` the line's dominant family at 0.03 of its roof (round 6)."""
+        self.marks.append({n: len(r) for n, r in self.records.items()})
+
+    def _measured(self):
+        """label -> [(ms, algorithmic bytes, flops)] of ONE step"""
+        out = {}
+        steps = len(self.marks)
+        for n, recs in self.records.items():
+            if not recs:
+                continue
+            el = [(r[0].elapsed_time(r[1]), r[2], r[3]) for r in recs]
+            per = len(recs) // steps if steps > 1 else 0
+            if steps > 1 and per > 0 and all(m.get(n, 0) == per * (i + 1) for i, m in enumerate(self.marks)):
+                out[n] = [min((el[k * per + j] for k in range(steps)), key=lambda t: t[0]) for j in range(per)]
+            elif steps > 1:                              # launch counts differ from step to step: the last step as it is
+                lo = self.marks[-2].get(n, 0)
+                out[n] = el[lo:] or el
+            else:
+                out[n] = el
+        return out
+
     def stop(self):
         for n, fn in self._orig.items():
             try:
@@ -1456,11 +1482,12 @@ class KernelTimer:
                 setattr(self.prov, n, fn)
         torch.cuda.synchronize()
         self.stats = {}
-        for n, recs in self.records.items():
+        self.eff = self._measured()
+        for n, recs in self.eff.items():
             if recs:
-                ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-                by = sum(r[2] for r in recs)
-                fl = sum(r[3] for r in recs)
+                ms = sum(r[0] for r in recs)
+                by = sum(r[1] for r in recs)
+                fl = sum(r[2] for r in recs)
                 self.stats[n] = {"launches": len(recs), "total_ms": round(ms, 3), "avg_us": round(ms * 1e3 / len(recs), 2),
                                  "algo_MB_per_launch": round(by / len(recs) / 1e6, 3),
                                  "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
@@ -1489,17 +1516,17 @@ class KernelTimer:
         """Per family: launches, total ms, algorithmic GB/s (and TFLOP/s for the matrix kernels), summed over its labels."""
         fam = {}
         for name, members in self.FAMILIES.items():
-            recs = [r for m in members for r in self.records.get(m, ())]
+            recs = [r for m in members for r in self.eff.get(m, ())]
             if not recs:
                 continue
-            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-            by = sum(r[2] for r in recs)
-            fl = sum(r[3] for r in recs)
+            ms = sum(r[0] for r in recs)
+            by = sum(r[1] for r in recs)
+            fl = sum(r[2] for r in recs)
             if ms <= 0:
                 continue
             st = {"launches": len(recs), "total_ms": round(ms, 3), "avg_us": round(ms * 1e3 / len(recs), 2),
                   "algo_MB_per_launch": round(by / len(recs) / 1e6, 3), "GBps": round(by / (ms * 1e-3) / 1e9, 1),
-                  "members": [m for m in members if self.records.get(m)]}
+                  "members": [m for m in members if self.eff.get(m)]}
             if fl:
                 st["algo_GFLOP_per_launch"] = round(fl / len(recs) / 1e9, 3)
                 st["TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
