@@ -232,10 +232,10 @@ class GraphedStep(object):
 
 
 class SegmentedStep(object):
-    """The same step as SIXTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
+    """The same step as FIFTEEN linear hipGraphs instead of one, launched on three streams so that what eager launches overlap
     overlaps under replay too (a captured graph with parallel BRANCHES is replayed node by node by the runtime and is slower than
     the single-stream graph; linear graphs on different streams overlap like eager launches):
-        s0: stem + layer1 | context tail, first stage | second stage | fusion | main head (fwd+loss+bwd) + fusion bwd | layer2..4 bwd | layer1 bwd | stem bwd | optimizer
+        s0: stem + layer1 | context tail, first stage | second stage | fusion + main head (fwd+loss+bwd) + fusion bwd | layer2..4 bwd | layer1 bwd | stem bwd | optimizer
         s1:               | detail branch (SpatialPath) ........... | aux head 1 .............................. | detail-branch backward ......................... |
         s2:                                         | aux head 0 ................................................... | heads' weight grads | layer2..4 weight grads | layer1 weight grads |
     The autograd graph is cut at the heads' and the fusion module's inputs (detached leaves whose gradients are handed to
@@ -342,24 +342,38 @@ class SegmentedStep(object):
                 with ac():
                     f16, f8 = net.context_tail(c2_l)
             s0.wait_stream(s1)
-        with torch.cuda.graph(g["ffm"], pool=p0, stream=s0):
+        # fusion module, main head and the fusion module's backward: consecutive on s0 with no other stream waiting in
+        # between — ONE graph (a graph boundary on the critical path is 7-30 us with no kernel on any queue,
+        # profiles/r06_segmented_replay_timeline.txt); TSG_SEG_MERGE=0 keeps the three apart
+        self.merge = os.environ.get("TSG_SEG_MERGE", "1") != "0"
+        self.one = self.merge and self.early_heads       # (without the early heads the auxiliary heads wait for the fusion module)
+
+        def fusion_forward():
             sp_l, f8_ffm = leaf(sp), leaf(f8)
             with ac():
                 fused = net.ffm(sp_l, f8_ffm)
             leaves = [l16, l8, leaf(fused)] if self.early_heads else [leaf(f16), leaf(f8), leaf(fused)]
-        if not self.early_heads:
-            aux_head(0, s1, "h0", p1, leaves[0])
-            aux_head(1, s2, "h1", p2, leaves[1])
-        # main head and the fusion module's backward: consecutive on s0 with no other stream waiting in between — ONE graph
-        # (a graph boundary on the critical path is 7-30 us with no kernel on any queue, profiles/r06_segmented_replay_timeline.txt);
-        # TSG_SEG_MERGE=0 keeps them apart
-        self.merge = os.environ.get("TSG_SEG_MERGE", "1") != "0"
-        with deferring(), torch.cuda.graph(g["hm"], pool=p0, stream=s0):
+            return sp_l, f8_ffm, fused, leaves
+
+        def main_head(fused, leaves):
             with ac():
                 losses[2] = net.criterion(net.heads[-1](leaves[2]), label)
             losses[2].backward()
             if self.merge:
                 torch.autograd.backward([fused], [leaves[2].grad])
+
+        if self.one:
+            with deferring(), torch.cuda.graph(g["hm"], pool=p0, stream=s0):
+                sp_l, f8_ffm, fused, leaves = fusion_forward()
+                main_head(fused, leaves)
+        else:
+            with torch.cuda.graph(g["ffm"], pool=p0, stream=s0):
+                sp_l, f8_ffm, fused, leaves = fusion_forward()
+            if not self.early_heads:
+                aux_head(0, s1, "h0", p1, leaves[0])
+                aux_head(1, s2, "h1", p2, leaves[1])
+            with deferring(), torch.cuda.graph(g["hm"], pool=p0, stream=s0):
+                main_head(fused, leaves)
         if not self.merge:
             with torch.cuda.graph(g["bffm"], pool=p0, stream=s0):
                 torch.autograd.backward([fused], [leaves[2].grad])
@@ -438,8 +452,9 @@ class SegmentedStep(object):
             s1.wait_stream(s0)
             with cs(s1):
                 g["h1"].replay()
-            with cs(s0):
-                g["ffm"].replay()
+            if not self.one:
+                with cs(s0):
+                    g["ffm"].replay()
         else:
             with cs(s0):
                 g["a2"].replay()
@@ -1032,7 +1047,7 @@ def main():
                           "whole_graph_ms_per_step": round(ms_whole, 3),
                           "segmented_ms_per_step": None if ms_s is None else round(ms_s, 3),
                           "chosen": ("replay" if graphed is not segmented else "segmented replay") if replay else "eager",
-                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (sixteen linear graphs "
+                          "note": "timed region = the fastest of hipGraph replay (one stream), segmented replay (fifteen linear graphs "
                                   "on three streams: detail branch, heads and deferred weight gradients beside the context path) and "
                                   "eager launches (weight gradients, auxiliary heads and detail branch on side streams); same "
                                   "kernels and results"}

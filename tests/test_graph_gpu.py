@@ -111,7 +111,7 @@ def test_auxiliary_heads_on_side_streams_change_nothing(cuda):
 
 
 def test_segmented_replay_follows_the_same_trajectory_as_one_graph(cuda):
-    """bench.SegmentedStep (round 6): the step as sixteen linear hipGraphs (auxiliary heads behind their own feature maps, the
+    """bench.SegmentedStep (round 6): the step as fifteen linear hipGraphs (auxiliary heads behind their own feature maps, the
     heads' / the context path's weight gradients in graphs of their own), the autograd graph cut at the heads' inputs — against bench.GraphedStep (one graph) at the benched shape, same
     seed, 6 optimizer steps each: the same kernels on the same operands, so the losses agree bit for bit."""
     import bench
