@@ -745,7 +745,9 @@ def forced_collectives_run(args):
     (the reducer's hooks launch the buckets from inside the backward pass), same shape, same seed.  Zero wire time: what it
     prices is the host / launch side of the path every rank of a 2/4/8-GPU run starts from."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.forced_steps), "--warmup", "6",
+    # 12 warm-up steps: an eager step is ~400 launches from Python and the host needs some steps to reach its pace (with 6,
+    # one evidence run timed 16.2 ms of host time per step where every other run had 10.3)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.forced_steps), "--warmup", "12",
            "--config", args.config, "--batch", str(args.batch), "--size", str(args.size), "--labels", args.labels,
            "--dtype", args.dtype, "--network", args.network, "--optimizer", args.optimizer, "--graph", "0",
            "--no-cpu-baseline", "--no-ohem-probe", "--no-psa-probe", "--no-kernel-timing", "--i64-steps", "0",
@@ -855,7 +857,7 @@ def main():
     ap.add_argument("--mode-probe", type=int, default=6,
                     help="with the default --graph (-1) on one GPU: time this many replayed and this many eagerly launched steps "
                          "after the capture and run the timed region in the faster mode (config.mode_probe); 0 = always replay")
-    ap.add_argument("--forced-steps", type=int, default=10,
+    ap.add_argument("--forced-steps", type=int, default=20,
                     help="after everything else (rank 0, N = 1): time this many steps of the N > 1 CODE PATH on one rank "
                          "(TSG_FORCE_COLLECTIVES=1 in a process of its own: SyncBN exchanges + gradient buckets through "
                          "tsg_comm on a 1-rank RCCL group) -> config.forced_collectives; 0 = skip")
