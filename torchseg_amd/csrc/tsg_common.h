@@ -69,7 +69,13 @@ template <> struct Vec<float> {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
   __device__ __forceinline__ void store(float* p) const {
+#if defined(TSG_NT_STORE)
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+#else
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
   }
 };
 
@@ -100,7 +106,15 @@ template <> struct Vec<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+#if defined(TSG_NT_STORE)
+    // experiment (round 6): the streaming passes' outputs as non-temporal stores — does the NEXT kernel stop paying for
+    // this one's write-backs?  Built only with -DTSG_NT_STORE; see profiles/r06_nontemporal_stores.txt
+    typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+    const nt_u4 t = {w[0], w[1], w[2], w[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_u4*>(p));
+#else
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+#endif
   }
 };
 
