@@ -63,6 +63,18 @@ template <> struct Vec<float> {
   float v[4];
   typedef float4 Raw;
   static __device__ __forceinline__ Raw ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  // an operand nobody reads again soon: a NON-TEMPORAL load, so that it does not push what the next kernel will read out of
+  // L2 / Infinity Cache (round 6: the BatchNorm apply passes' inputs, step - 0.65 % in four interleaved pairs,
+  // profiles/r06_nontemporal_stores.txt; -DTSG_NO_NT_LOAD builds the plain loads)
+  static __device__ __forceinline__ Raw ldraw_dead(const float* p) {
+#if !defined(TSG_NO_NT_LOAD)
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return ldraw(p);
+#endif
+  }
   __device__ __forceinline__ void unpack(const Raw& t) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
   __device__ __forceinline__ void load(const float* p) {
     float4 t = *reinterpret_cast<const float4*>(p);
@@ -84,6 +96,15 @@ template <> struct Vec<bf16_t> {
   float v[8];
   typedef uint4 Raw;
   static __device__ __forceinline__ Raw ldraw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ Raw ldraw_dead(const bf16_t* p) {
+#if !defined(TSG_NO_NT_LOAD)
+    typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+    const nt_u4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return ldraw(p);
+#endif
+  }
   __device__ __forceinline__ void unpack(const Raw& t) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
